@@ -1,0 +1,36 @@
+"""Synthetic formula-image sets of SURVEY.md section 8(d) (host, NumPy).
+
+No dataset ships with the reference (images and train formulas are missing,
+data/.MISSING_LARGE_BLOBS) and there is no network, so every measured or
+parity-checked batch is generated here: white (255) background, `ink`
+fraction of pixels drawn uniformly from [0, 128); token ids uniform over the
+ordinary vocabulary (specials _UNK,_PAD,_END are the last three ids, as
+model/utils/text.py:12,60-61 numbers them).
+"""
+import numpy as np
+
+
+def make_set(n, H, W, n_tok, len_lo, len_hi, seed=1234, ink=0.08):
+    """-> (list of uint8[H,W,1], list of list[int]); lengths ~ U{len_lo..len_hi-1}."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    imgs, forms = [], []
+    n_ord = n_tok - 3
+    for _ in range(n):
+        img = np.full((H, W, 1), 255, dtype=np.uint8)
+        mask = rng.random((H, W, 1)) < ink
+        vals = rng.integers(0, 128, size=(H, W, 1), dtype=np.int64).astype(np.uint8)
+        img[mask] = vals[mask]
+        L = int(rng.integers(len_lo, len_hi))
+        forms.append([int(t) for t in rng.integers(0, n_ord, size=L)])
+        imgs.append(img)
+    return imgs, forms
+
+
+def config1(seed=1234):
+    """100 crops 32x128, vocab 50, lengths U{5..20} (BASELINE.json configs[0])."""
+    return make_set(100, 32, 128, 50, 5, 21, seed)
+
+
+def config3_batch(B=64, H=128, W=512, n_tok=500, seed=1234):
+    """One training batch of BASELINE.json configs[2]: lengths U{30..100}."""
+    return make_set(B, H, W, n_tok, 30, 101, seed)
