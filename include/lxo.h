@@ -1,0 +1,119 @@
+/* C ABI of the MI355X-native image->LaTeX hot path (liblxo.so).
+ *
+ * The reference (LinXueyuanStdio/LaTeX_OCR) has no FFI: its numeric boundary is
+ * `sess.run` inside model/img2seq.py (:169, :236, :263).  These entry points
+ * are what a binding for that boundary calls; each cites the reference code it
+ * replaces.  All pointers are DEVICE pointers owned by the caller, all calls
+ * are asynchronous on the given hipStream_t (passed as void*), none allocates.
+ * Return value: 0 = OK, negative = error (see lxo_last_error()).
+ */
+#ifndef LXO_H
+#define LXO_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LXO_F32 0
+#define LXO_BF16 1
+
+const char* lxo_last_error(void);
+int lxo_version(void);
+
+/* ---- building blocks (exposed for parity tests and for bindings that want
+ *      the encoder / projections alone) ---- */
+
+/* C[M,N] = act(alpha * A[M,K] * Bp[N,K]^T + bias) ; Bp is the K-contiguous
+ * ("transposed", TF [in,out] -> [out,in]) weight copy in the compute dtype.
+ * dt: compute dtype; a_f32/c_f32: A / C are float even when dt == LXO_BF16.
+ * Replaces tf.layers.dense / tf.matmul call sites (attention_mechanism.py:43,79;
+ * attention_cell.py:82-84). */
+int lxo_gemm_nt(int dt, int a_f32, int c_f32, int small, const void* A, const void* Bp, void* C,
+                int M, int N, int K, int lda, int ldb, int ldc, const float* bias, int act,
+                float alpha, int accumulate, void* stream);
+
+/* C[I,J] += sum_m A[m,I] * B[m,J] (f32 output, atomics across nsplit row ranges). */
+int lxo_gemm_tn(int dt, int a_f32, int b_f32, const void* A, const void* B, float* C,
+                int M, int I, int J, int lda, int ldb, int ldc, int nsplit, int atomic, void* stream);
+
+/* ---- the hot path proper ---- */
+
+/* Shape of one call.  H, W are the batch-max image extents after white padding
+ * (model/utils/image.py:27-44); T is the padded formula width Lmax+1
+ * (model/utils/text.py:157-162); V is Vocab.n_tok (text.py:16); C/E/U/O/D are the
+ * encoder width (512) and attn_cell_config {dim_e, num_units, dim_o, dim_embeddings}
+ * (configs/model.json:6-12). */
+typedef struct lxo_shape {
+    int B, H, W, T, V;
+    int C, E, U, O, D;
+    int dtype;      /* LXO_F32 (parity mode) or LXO_BF16 (bf16 storage, f32 accumulate) */
+    int beam;       /* decode only: beam width the workspace is sized for (>= 1) */
+    int max_steps;  /* decode only: step capacity (max_length_formula + 2) */
+} lxo_shape;
+
+/* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF
+ * checkpoint order.  id in [0, lxo_param_num()). */
+int lxo_param_num(void);
+const char* lxo_param_name(int id);
+long long lxo_param_total(const lxo_shape* s);
+int lxo_param_info(const lxo_shape* s, int id, long long* offset, long long* count);
+
+size_t lxo_wpack_bytes(const lxo_shape* s);
+size_t lxo_workspace_bytes(const lxo_shape* s);
+/* offset/size of a named workspace region (tests and bindings read activations,
+ * logits, loss statistics and attention weights through this) */
+int lxo_ws_region(const lxo_shape* s, const char* name, size_t* offset, size_t* bytes);
+
+/* refresh the compute-dtype GEMM operand copies from the f32 master parameters
+ * (call after every optimizer step / checkpoint load) */
+int lxo_pack_weights(const lxo_shape* s, const float* params, void* wpack, void* stream);
+
+/* Encoder.__call__ (model/encoder.py:17-68) + add_timing_signal_nd
+ * (model/components/positional.py:10-65): u8 [B,H,W,1] -> ws region "img" [B,R,C] */
+int lxo_encoder_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                    const uint8_t* img, void* stream);
+/* backward of conv layers last_layer..first_layer (6..1), accumulating into grads;
+ * layer 6 consumes ws region "d_img".  Split so a data-parallel caller can
+ * all-reduce finished buckets while earlier layers still run. */
+int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                    const uint8_t* img, float* grads, int last_layer, int first_layer, void* stream);
+
+/* Decoder.__call__ training branch (model/decoder.py:41-57): AttentionMechanism
+ * set-up (attention_mechanism.py:19-43,124-153), T steps of AttentionCell.step
+ * (attention_cell.py:58-89) under teacher forcing, logits for every step. */
+int lxo_decoder_train_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                          const int32_t* formula, void* stream);
+/* loss of model/img2seq.py:68-75 and d(loss)/d(logits).  inv_ntok = 1 / (number of
+ * unmasked tokens in the GLOBAL batch).  ws region "loss" = {sum CE, token count}. */
+int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula,
+                        const int32_t* lengths, float inv_ntok, void* stream);
+/* BPTT through the decoder (what TF autodiff does for img2seq.py:119-123);
+ * accumulates decoder gradients into grads and leaves d(enc) in ws region "d_img". */
+int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                          const int32_t* formula, float* grads, void* stream);
+
+/* tf.clip_by_global_norm scale (img2seq.py:119-121): scale_out[0] = clip / max(||g||, clip),
+ * scale_out[1] = ||g|| ; device memory, no host sync.  clip <= 0 -> scale 1. */
+int lxo_global_norm_scale(long long n, const float* grads, float clip, float* scale_out, void* stream);
+/* tf.train.AdamOptimizer update (img2seq.py:101), TF epsilon placement:
+ * m,v updated; theta -= lr_t * m / (sqrt(v) + eps), grads pre-multiplied by *scale_dev if given. */
+int lxo_adam_step(long long n, float* params, const float* grads, float* m, float* v,
+                  float lr_t, float beta1, float beta2, float eps, const float* scale_dev, void* stream);
+
+/* dynamic_decode + GreedyDecoderCell (dynamic_decode.py:17-74, greedy_decoder_cell.py:40-66):
+ * runs on the encoder output already in ws; ids_out int32 [B, max_steps] (device),
+ * *steps_out = number of steps executed (<= max_iter + 1).  Host-synchronising. */
+int lxo_greedy_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                      int id_end, int max_iter, int32_t* ids_out, int* steps_out, void* stream);
+/* dynamic_decode + BeamSearchDecoderCell (beam_search_decoder_cell.py:98-250),
+ * reference-faithful finalize (parents not followed): ids_out int32 [B, max_steps, beam],
+ * parents_out same shape (may be NULL). */
+int lxo_beam_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                    int id_end, int max_iter, int32_t* ids_out, int32_t* parents_out,
+                    int* steps_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+"""ctypes declaration of the C ABI in include/lxo.h (signatures only).
+
+`load()` opens the in-tree gfx950 library `latex_ocr_amd/liblxo.so` and fails
+loudly when it is missing: there is no CPU fallback in this package.
+"""
+import ctypes
+import os
+
+c_int, c_ll, c_size, c_float, c_void = ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p
+P = ctypes.POINTER
+
+LXO_F32, LXO_BF16 = 0, 1
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")
+
+
+class LxoShape(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("B", "H", "W", "T", "V", "C", "E", "U", "O", "D", "dtype", "beam", "max_steps")]
+
+
+def bind(lib):
+    """Attach argtypes/restypes of every entry point of include/lxo.h."""
+    S = P(LxoShape)
+    sig = {
+        "lxo_last_error": (ctypes.c_char_p, []),
+        "lxo_version": (c_int, []),
+        "lxo_gemm_nt": (c_int, [c_int] * 4 + [c_void] * 3 + [c_int] * 6 + [c_void, c_int, c_float, c_int, c_void]),
+        "lxo_gemm_tn": (c_int, [c_int] * 3 + [c_void] * 3 + [c_int] * 8 + [c_void]),
+        "lxo_param_num": (c_int, []),
+        "lxo_param_name": (ctypes.c_char_p, [c_int]),
+        "lxo_param_total": (c_ll, [S]),
+        "lxo_param_info": (c_int, [S, c_int, P(c_ll), P(c_ll)]),
+        "lxo_wpack_bytes": (c_size, [S]),
+        "lxo_workspace_bytes": (c_size, [S]),
+        "lxo_ws_region": (c_int, [S, ctypes.c_char_p, P(c_size), P(c_size)]),
+        "lxo_pack_weights": (c_int, [S, c_void, c_void, c_void]),
+        "lxo_encoder_fwd": (c_int, [S, c_void, c_void, c_void, c_void, c_void]),
+        "lxo_encoder_bwd": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_void]),
+        "lxo_decoder_train_fwd": (c_int, [S, c_void, c_void, c_void, c_void, c_void]),
+        "lxo_ce_loss_fwd_bwd": (c_int, [S, c_void, c_void, c_void, c_float, c_void]),
+        "lxo_decoder_train_bwd": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void]),
+        "lxo_global_norm_scale": (c_int, [c_ll, c_void, c_float, c_void, c_void]),
+        "lxo_adam_step": (c_int, [c_ll, c_void, c_void, c_void, c_void, c_float, c_float, c_float, c_float, c_void, c_void]),
+        "lxo_greedy_decode": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, P(c_int), c_void]),
+        "lxo_beam_decode": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, P(c_int), c_void]),
+    }
+    missing = []
+    for name, (res, args) in sig.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype, fn.argtypes = res, args
+    lib._lxo_missing = missing
+    return lib
+
+
+ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_param_num", "lxo_param_name",
+                "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
+                "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_decoder_train_fwd",
+                "lxo_ce_loss_fwd_bwd", "lxo_decoder_train_bwd", "lxo_global_norm_scale", "lxo_adam_step",
+                "lxo_greedy_decode", "lxo_beam_decode"]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "latex_ocr_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = bind(ctypes.CDLL(LIB_PATH))
+        if _lib._lxo_missing:
+            raise RuntimeError("liblxo.so lacks entry points: %s" % _lib._lxo_missing)
+    return _lib
+
+
+def check(lib, rc, what=""):
+    if rc != 0:
+        raise RuntimeError("%s failed: rc=%d %s" % (what, rc, lib.lxo_last_error().decode()))

@@ -1,0 +1,123 @@
+// extern "C" boundary of liblxo.so (see include/lxo.h).
+#include "lxo.h"
+#include "gemm.h"
+#include "impl.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s (code %d)", what, code);
+    return code < 0 ? code : -code;
+}
+#define CHECK_LAUNCH(expr, what) do { int rc_ = (expr); if (rc_ != 0) return fail(rc_, what); } while (0)
+
+extern "C" const char* lxo_last_error(void) { return g_err; }
+extern "C" int lxo_version(void) { return 1; }
+
+extern "C" int lxo_gemm_nt(int dt, int a_f32, int c_f32, int small, const void* A, const void* Bp, void* C,
+                           int M, int N, int K, int lda, int ldb, int ldc, const float* bias, int act,
+                           float alpha, int accumulate, void* stream) {
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.Bp = Bp; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.act = act; p.alpha = alpha; p.accumulate = accumulate; p.addend_rows = 1;
+    CHECK_LAUNCH(lxo_launch_gemm_nt(dt, a_f32, c_f32, small, p, (hipStream_t)stream), "lxo_gemm_nt");
+    return 0;
+}
+
+extern "C" int lxo_gemm_tn(int dt, int a_f32, int b_f32, const void* A, const void* B, float* C,
+                           int M, int I, int J, int lda, int ldb, int ldc, int nsplit, int atomic, void* stream) {
+    GemmTN p; memset(&p, 0, sizeof(p));
+    p.A = A; p.B = B; p.C = C; p.M = M; p.I = I; p.J = J; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.nsplit = nsplit; p.nbatch = 1; p.atomic = atomic;
+    CHECK_LAUNCH(lxo_launch_gemm_tn(dt, a_f32, b_f32, p, (hipStream_t)stream), "lxo_gemm_tn");
+    return 0;
+}
+
+// ---------------------------------------------------------------- plan ----
+#define MAKE_PLAN(P, s) if (!(s)) return fail(-1, "null shape"); Plan P(*(s)); \
+    { char m_[200]; int v_ = P.validate(m_, sizeof(m_)); if (v_) { snprintf(g_err, sizeof(g_err), "%s", m_); return v_; } }
+
+extern "C" int lxo_param_num(void) { return P_COUNT; }
+extern "C" long long lxo_param_total(const lxo_shape* s) { if (!s) return -1; Plan P(*s); return P.ptotal; }
+extern "C" int lxo_param_info(const lxo_shape* s, int id, long long* offset, long long* count) {
+    if (!s || id < 0 || id >= P_COUNT) return fail(-1, "lxo_param_info");
+    Plan P(*s);
+    if (offset) *offset = P.poff[id];
+    if (count) *count = P.pcount[id];
+    return 0;
+}
+extern "C" size_t lxo_wpack_bytes(const lxo_shape* s) { if (!s) return 0; Plan P(*s); return P.ktotal; }
+extern "C" size_t lxo_workspace_bytes(const lxo_shape* s) { if (!s) return 0; Plan P(*s); return P.wtotal; }
+extern "C" int lxo_ws_region(const lxo_shape* s, const char* name, size_t* offset, size_t* bytes) {
+    if (!s || !name) return fail(-1, "lxo_ws_region");
+    Plan P(*s);
+    for (int i = 0; i < W_COUNT; ++i)
+        if (strcmp(name, lxo_ws_name(i)) == 0) {
+            if (offset) *offset = P.woff[i];
+            if (bytes) *bytes = P.wbytes[i];
+            return 0;
+        }
+    return fail(-1, "unknown workspace region");
+}
+extern "C" int lxo_pack_weights(const lxo_shape* s, const float* params, void* wpack, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_pack_weights(P, params, wpack, (hipStream_t)stream), "lxo_pack_weights");
+    return 0;
+}
+extern "C" int lxo_encoder_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                               const uint8_t* img, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_encoder_fwd(P, params, wpack, ws, img, (hipStream_t)stream), "lxo_encoder_fwd");
+    return 0;
+}
+extern "C" int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                               const uint8_t* img, float* grads, int last_layer, int first_layer, void* stream) {
+    MAKE_PLAN(P, s);
+    if (last_layer > 6 || first_layer < 1 || last_layer < first_layer) return fail(-1, "lxo_encoder_bwd: layer range");
+    CHECK_LAUNCH(lxo_impl_encoder_bwd(P, params, wpack, ws, img, grads, last_layer, first_layer, (hipStream_t)stream), "lxo_encoder_bwd");
+    return 0;
+}
+
+#include "decoder_kernels.h"
+extern "C" int lxo_decoder_train_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                     const int32_t* formula, void* stream) {
+    MAKE_PLAN(P, s);
+    if (s->T <= 0) return fail(-1, "T must be positive");
+    CHECK_LAUNCH(lxo_impl_decoder_train_fwd(P, params, wpack, ws, formula, (hipStream_t)stream), "lxo_decoder_train_fwd");
+    return 0;
+}
+extern "C" int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula, const int32_t* lengths,
+                                   float inv_ntok, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_ce_loss(P, ws, formula, lengths, inv_ntok, (hipStream_t)stream), "lxo_ce_loss_fwd_bwd");
+    return 0;
+}
+extern "C" int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                     const int32_t* formula, float* grads, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, (hipStream_t)stream), "lxo_decoder_train_bwd");
+    return 0;
+}
+extern "C" int lxo_global_norm_scale(long long n, const float* grads, float clip, float* scale_out, void* stream) {
+    // scale_out needs 3 floats: {scale, norm, scratch}
+    CHECK_LAUNCH(lxo_k_global_norm_scale(n, grads, clip, scale_out + 2, scale_out, (hipStream_t)stream), "lxo_global_norm_scale");
+    return 0;
+}
+extern "C" int lxo_adam_step(long long n, float* params, const float* grads, float* m, float* v,
+                             float lr_t, float beta1, float beta2, float eps, const float* scale_dev, void* stream) {
+    CHECK_LAUNCH(lxo_k_adam(params, grads, m, v, n, lr_t, beta1, beta2, eps, scale_dev, (hipStream_t)stream), "lxo_adam_step");
+    return 0;
+}
+extern "C" int lxo_greedy_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                 int id_end, int max_iter, int32_t* ids_out, int* steps_out, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_greedy_decode(P, params, wpack, ws, id_end, max_iter, ids_out, steps_out, (hipStream_t)stream), "lxo_greedy_decode");
+    return 0;
+}
+extern "C" int lxo_beam_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                               int id_end, int max_iter, int32_t* ids_out, int32_t* parents_out, int* steps_out, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_beam_decode(P, params, wpack, ws, id_end, max_iter, ids_out, parents_out, steps_out, (hipStream_t)stream), "lxo_beam_decode");
+    return 0;
+}

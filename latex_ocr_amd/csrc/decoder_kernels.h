@@ -1,0 +1,31 @@
+// Launchers of the non-GEMM decoder / loss / optimizer / decode kernels.
+#pragma once
+#include "lxo_common.h"
+int lxo_k_rowmean(int dt, const void* img, float* mean, int B, int R, int C, hipStream_t st);
+int lxo_k_embed_gather(int dt, const float* table, const float* start, const int* formula, void* out, int B, int T, int D, int Dp, int V, hipStream_t st);
+int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* ids, void* out, int n, int D, int Dp, int V, hipStream_t st);
+int lxo_k_lstm_fwd(const float* z, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st);
+int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, const float* dh1, int ld1, const float* dh2, int ld2,
+                   float* dcc, float* dz, int B, int U, hipStream_t st);
+int lxo_k_tanh_bwd(const float* a, int lda, const float* b, int ldb, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st);
+int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* ctx, int ldctx,
+                   int nv, int R, int Rp, int E, int C, int beam, hipStream_t st);
+int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
+                   const float* dctx, int lddc, const float* ctx, int ldctx, float* de, float* datth,
+                   int nv, int R, int Rp, int E, int C, hipStream_t st);
+int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
+                   int T, int B, int R, int Rp, int E, hipStream_t st);
+int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st);
+int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
+                  int B, int T, int V, int Vp, hipStream_t st);
+int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t st);
+int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st);
+int lxo_k_init_bwd(const float* dcc, const float* dxh, int ldx, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st);
+int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids_step, int* ids_out, int max_steps, int step,
+                 int* finished, int* n_unfinished, hipStream_t st);
+int lxo_k_beam_step(const float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float* logp, int* finished,
+                    int* ids_step, int* parents_step, int* ids_out, int* par_out, int max_steps, int* n_unfinished, hipStream_t st);
+int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, hipStream_t st);
+int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k, int cols, hipStream_t st);
+int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sumsq_tmp, float* out, hipStream_t st);
+int lxo_k_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps, const float* scale, hipStream_t st);

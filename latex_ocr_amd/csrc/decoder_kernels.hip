@@ -1,0 +1,740 @@
+// Decoder kernels that are not GEMMs.  One workgroup of 4 waves per sample for the
+// attention stream (attention_mechanism.py:46-94): scores, softmax over the R regions
+// and the context sum in ONE launch, att_img and img each read exactly once.
+#include "decoder_kernels.h"
+
+namespace {
+
+constexpr int MAXR = 10240;   // regions per sample held in LDS (Plan::validate)
+
+// 4 consecutive k of one row as floats
+LXO_DEV void load4(const float* p, float (&v)[4]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+LXO_DEV void load4(const bf16_t* p, float (&v)[4]) {
+    u32x2 a = *reinterpret_cast<const u32x2*>(p);
+    v[0] = __uint_as_float(a[0] << 16); v[1] = __uint_as_float(a[0] & 0xffff0000u);
+    v[2] = __uint_as_float(a[1] << 16); v[3] = __uint_as_float(a[1] & 0xffff0000u);
+}
+LXO_DEV void store4(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = a; }
+LXO_DEV void store4(bf16_t* p, const float (&v)[4]) { u32x2 a = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}; *reinterpret_cast<u32x2*>(p) = a; }
+
+// mean over regions: img [B][R][C] -> mean [B][C]   (attention_mechanism.py:148)
+template <typename CT>
+__global__ __launch_bounds__(256) void rowmean_kernel(const CT* __restrict__ img, float* __restrict__ mean, int R, int C) {
+    __shared__ float red[4][512];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < C)
+        for (int r = wave; r < R; r += 4) {
+            float v[8];
+            load8(img + ((long long)b * R + r) * C + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    if (c0 < C) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][c0 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        mean[(long long)b * C + c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)R;
+}
+
+// teacher-forcing inputs (decoder.py:75-95): row t*B+b = t ? table[formula[b][t-1]] : start_token
+template <typename CT>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const float* __restrict__ start,
+                                                          const int* __restrict__ formula, CT* __restrict__ out,
+                                                          int B, int T, int D, int Dp, int V) {
+    const long long total = (long long)T * B * Dp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int d = (int)(i % Dp);
+        const long long row = i / Dp;
+        const int b = (int)(row % B), t = (int)(row / B);
+        float v = 0.f;
+        if (d < D) {
+            if (t == 0) v = start[d];
+            else {
+                int id = formula[(long long)b * T + t - 1];
+                id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+                v = table[(long long)id * D + d];
+            }
+        }
+        out[i] = from_f32<CT>(v);
+    }
+}
+// rows gathered by explicit ids (decode): out[v] = ids ? table[ids[v]] : start
+template <typename CT>
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ table, const float* __restrict__ start,
+                                                        const int* __restrict__ ids, CT* __restrict__ out,
+                                                        int n, int D, int Dp, int V) {
+    const long long total = (long long)n * Dp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int d = (int)(i % Dp);
+        const int r = (int)(i / Dp);
+        float v = 0.f;
+        if (d < D) {
+            if (!ids) v = start[d];
+            else {
+                int id = ids[r];
+                id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+                v = table[(long long)id * D + d];
+            }
+        }
+        out[i] = from_f32<CT>(v);
+    }
+}
+
+// TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71)
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ z, const float* __restrict__ c_prev,
+                                                      float* __restrict__ gates, float* __restrict__ c_out,
+                                                      float* __restrict__ h_out, int ldh, int B, int U) {
+    const int total = B * U;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i / U, u = i - b * U;
+        const float* zr = z + (long long)b * 4 * U;
+        const float gi = sigmoidf_(zr[u]), gj = tanhf(zr[U + u]);
+        const float gf = sigmoidf_(zr[2 * U + u] + 1.0f), go = sigmoidf_(zr[3 * U + u]);
+        const float c = gf * c_prev[i] + gi * gj;
+        const float h = go * tanhf(c);
+        if (gates) {
+            float* gr = gates + (long long)b * 4 * U;
+            gr[u] = gi; gr[U + u] = gj; gr[2 * U + u] = gf; gr[3 * U + u] = go;
+        }
+        c_out[i] = c;
+        h_out[(long long)b * ldh + u] = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                      const float* __restrict__ c_cur, const float* __restrict__ dh1, int ld1,
+                                                      const float* __restrict__ dh2, int ld2, float* __restrict__ dcc,
+                                                      float* __restrict__ dz, int B, int U) {
+    const int total = B * U;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i / U, u = i - b * U;
+        const float* gr = gates + (long long)b * 4 * U;
+        const float gi = gr[u], gj = gr[U + u], gf = gr[2 * U + u], go = gr[3 * U + u];
+        const float dh = dh1[(long long)b * ld1 + u] + dh2[(long long)b * ld2 + u];
+        const float tc = tanhf(c_cur[i]);
+        const float dc = dcc[i] + dh * go * (1.f - tc * tc);
+        float* dr = dz + (long long)b * 4 * U;
+        dr[u] = dc * gj * gi * (1.f - gi);
+        dr[U + u] = dc * gi * (1.f - gj * gj);
+        dr[2 * U + u] = dc * c_prev[i] * gf * (1.f - gf);
+        dr[3 * U + u] = dh * tc * go * (1.f - go);
+        dcc[i] = dc * gf;
+    }
+}
+
+// g = (a + b) * (1 - o^2)      (backward through o = tanh(.), attention_cell.py:82)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                      const float* __restrict__ o, int ldo, float* __restrict__ g, int ldg,
+                                                      int rows, int cols) {
+    const int total = rows * cols;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / cols, c = i - r * cols;
+        const float ov = o[(long long)r * ldo + c];
+        float d = a ? a[(long long)r * lda + c] : 0.f;
+        if (b) d += b[(long long)r * ldb + c];
+        g[(long long)r * ldg + c] = d * (1.f - ov * ov);
+    }
+}
+
+// ---- attention forward: one workgroup per (virtual) sample ----
+template <typename CT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+                                                      const float* __restrict__ att_h, const float* __restrict__ beta,
+                                                      float* __restrict__ alpha, float* __restrict__ ctx, int ldctx,
+                                                      int R, int Rp, int E, int C, int beam) {
+    __shared__ float sc[MAXR];
+    __shared__ float redc[4][512];
+    __shared__ float red[8];
+    const int v = blockIdx.x, bi = v / beam;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const CT* ai = att_img + (long long)bi * R * E;
+    const CT* im = img + (long long)bi * R * C;
+    const int KC = (E + 255) >> 8;
+    float ah[4][4], bt[4][4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        const int k0 = kc * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = kc < KC && k0 + j < E;
+            ah[kc][j] = ok ? att_h[(long long)v * E + k0 + j] : 0.f;
+            bt[kc][j] = ok ? beta[k0 + j] : 0.f;
+        }
+    }
+    // scores e[r] = sum_k beta_k tanh(att_img[r][k] + att_h[k])       (attention_mechanism.py:83-91)
+    for (int r = wave; r < R; r += 4) {
+        float part = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            if (kc < KC && k0 < E) {
+                float x[4];
+                load4(ai + (long long)r * E + k0, x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part = fmaf(tanhf(x[j] + ah[kc][j]), bt[kc][j], part);
+            }
+        }
+        part = wave_sum(part);
+        if (lane == 0) sc[r] = part;
+    }
+    __syncthreads();
+    // softmax over regions                                            (attention_mechanism.py:94)
+    float m = -3.0e38f;
+    for (int r = tid; r < R; r += 256) m = fmaxf(m, sc[r]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int r = tid; r < R; r += 256) { const float p = expf(sc[r] - m); sc[r] = p; l += p; }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int r = tid; r < R; r += 256) { const float a = sc[r] * inv; sc[r] = a; alpha[(long long)v * Rp + r] = a; }
+    __syncthreads();
+    // context = sum_r alpha[r] * img[r][:]                            (attention_mechanism.py:73-74)
+    const int c0 = lane * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < C)
+        for (int r = wave; r < R; r += 4) {
+            float x[8];
+            load8(im + (long long)r * C + c0, x);
+            const float a = sc[r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(a, x[e], acc[e]);
+        }
+    if (c0 < C) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256)
+        ctx[(long long)v * ldctx + c] = redc[0][c] + redc[1][c] + redc[2][c] + redc[3][c];
+}
+
+// ---- attention backward (per step): d_e and d_att_h; d_img / d_att_img are deferred ----
+template <typename CT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+                                                      const float* __restrict__ att_h, const float* __restrict__ beta,
+                                                      const float* __restrict__ alpha, const float* __restrict__ dctx, int lddc,
+                                                      const float* __restrict__ ctx, int ldctx,
+                                                      float* __restrict__ de, float* __restrict__ datth,
+                                                      int R, int Rp, int E, int C) {
+    __shared__ float sc[MAXR];
+    __shared__ float rede[4][1024];
+    __shared__ float red[4];
+    const int v = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const CT* ai = att_img + (long long)v * R * E;
+    const CT* im = img + (long long)v * R * C;
+    const int KC = (E + 255) >> 8;
+    // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r
+    float s = 0.f;
+    for (int c = tid; c < C; c += 256) s = fmaf(ctx[(long long)v * ldctx + c], dctx[(long long)v * lddc + c], s);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    const int c0 = lane * 8;
+    float dc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dc[e] = (c0 + e < C) ? dctx[(long long)v * lddc + c0 + e] : 0.f;
+    for (int r = wave; r < R; r += 4) {
+        float part = 0.f;
+        if (c0 < C) {
+            float x[8];
+            load8(im + (long long)r * C + c0, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = fmaf(x[e], dc[e], part);
+        }
+        part = wave_sum(part);
+        if (lane == 0) {
+            const float d = alpha[(long long)v * Rp + r] * (part - s);   // softmax backward
+            sc[r] = d;
+            de[(long long)v * Rp + r] = d;
+        }
+    }
+    __syncthreads();
+    float ah[4][4], bt[4][4], acc[4][4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        const int k0 = kc * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = kc < KC && k0 + j < E;
+            ah[kc][j] = ok ? att_h[(long long)v * E + k0 + j] : 0.f;
+            bt[kc][j] = ok ? beta[k0 + j] : 0.f;
+            acc[kc][j] = 0.f;
+        }
+    }
+    for (int r = wave; r < R; r += 4) {
+        const float d = sc[r];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            if (kc < KC && k0 < E) {
+                float x[4];
+                load4(ai + (long long)r * E + k0, x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float tau = tanhf(x[j] + ah[kc][j]);
+                    acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        const int k0 = kc * 256 + lane * 4;
+        if (kc < KC && k0 < E) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rede[wave][k0 + j] = acc[kc][j] * bt[kc][j];
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < E; k += 256)
+        datth[(long long)v * E + k] = rede[0][k] + rede[1][k] + rede[2][k] + rede[3][k];
+}
+
+// deferred: d_att_img[b][r][k] = beta_k sum_t de[t][b][r] (1 - tau^2),  d_beta_k += sum de * tau
+template <typename CT>
+__global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ att_img, const float* __restrict__ att_h,
+                                                      const float* __restrict__ beta, const float* __restrict__ de,
+                                                      CT* __restrict__ dout, float* __restrict__ dbeta,
+                                                      int T, int B, int R, int Rp, int E) {
+    __shared__ float redb[4][1024];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KC = (E + 255) >> 8;
+    float bt[4][4], db[4][4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        const int k0 = kc * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bt[kc][j] = (kc < KC && k0 + j < E) ? beta[k0 + j] : 0.f; db[kc][j] = 0.f; }
+    }
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = blockIdx.x * 16 + wave * 4 + rr;
+        if (r >= R) continue;                       // wave-uniform
+        float x[4][4], acc[4][4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[kc][j] = 0.f; acc[kc][j] = 0.f; }
+            if (kc < KC && k0 < E) load4(att_img + ((long long)b * R + r) * E + k0, x[kc]);
+        }
+        for (int t = 0; t < T; ++t) {
+            const float d = de[((long long)t * B + b) * Rp + r];
+            const float* ah = att_h + ((long long)t * B + b) * E;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int k0 = kc * 256 + lane * 4;
+                if (kc < KC && k0 < E) {
+                    float a[4];
+                    load4(ah + k0, a);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float tau = tanhf(x[kc][j] + a[j]);
+                        acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
+                        db[kc][j] = fmaf(d, tau, db[kc][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            if (kc < KC && k0 < E) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = acc[kc][j] * bt[kc][j];
+                store4(dout + ((long long)b * R + r) * E + k0, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        const int k0 = kc * 256 + lane * 4;
+        if (kc < KC && k0 < E) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) redb[wave][k0 + j] = db[kc][j];
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < E; k += 256) atomicAdd(&dbeta[k], redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k]);
+}
+
+// d_img[b][r][c] += dmean[b][c] / R      (backward of the region mean)
+__global__ __launch_bounds__(256) void add_mean_grad_kernel(float* __restrict__ dimg, const float* __restrict__ dmean, int B, int R, int C) {
+    const long long total = (long long)B * R * C;
+    const float inv = 1.0f / (float)R;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((long long)R * C));
+        dimg[i] += dmean[(long long)b * C + c] * inv;
+    }
+}
+
+// loss of img2seq.py:68-75 + gradient; one wave per (t, b) row
+template <typename CT>
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int* __restrict__ formula,
+                                                     const int* __restrict__ lengths, CT* __restrict__ dlogits,
+                                                     float* __restrict__ loss_acc, float inv_ntok, int B, int T, int V, int Vp) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T * B) return;                              // wave-uniform exit
+    const int t = row / B, b = row - t * B;
+    const float* lg = logits + (long long)row * Vp;
+    CT* dl = dlogits + (long long)row * Vp;
+    const bool valid = t < lengths[b];
+    int tgt = formula[(long long)b * T + t];
+    tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+    float m = -3.0e38f;
+    for (int j = lane; j < V; j += 64) m = fmaxf(m, lg[j]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < V; j += 64) l += expf(lg[j] - m);
+    l = wave_sum(l);
+    const float lse = m + logf(l);
+    const float scale = valid ? inv_ntok : 0.f;
+    for (int j = lane; j < Vp; j += 64) {
+        float g = 0.f;
+        if (j < V) g = (expf(lg[j] - lse) - (j == tgt ? 1.f : 0.f)) * scale;
+        dl[j] = from_f32<CT>(g);
+    }
+    if (lane == 0 && valid) {
+        atomicAdd(&loss_acc[0], lse - lg[tgt]);
+        atomicAdd(&loss_acc[1], 1.0f);
+    }
+}
+
+// out[n] += sum_m a[m][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += a[(long long)m * lda + n];
+    atomicAdd(&out[n], s);
+}
+
+// d_emb rows -> embedding_table / start_token gradients (decoder.py:90-93 backward)
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ demb, const int* __restrict__ formula,
+                                                           float* __restrict__ dtable, float* __restrict__ dstart,
+                                                           int B, int T, int D, int V) {
+    const long long total = (long long)T * B * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int d = (int)(i % D);
+        const long long row = i / D;
+        const int b = (int)(row % B), t = (int)(row / B);
+        const float g = demb[i];
+        if (t == 0) atomicAdd(&dstart[d], g);
+        else {
+            int id = formula[(long long)b * T + t - 1];
+            id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+            atomicAdd(&dtable[(long long)id * D + d], g);
+        }
+    }
+}
+
+// dpre = d_s0 * (1 - s0^2) for s in (c, h, o) -> [B][U+U+O]   (attention_mechanism.py:151 backward)
+__global__ __launch_bounds__(256) void init_bwd_kernel(const float* __restrict__ dcc, const float* __restrict__ dxh, int ldx,
+                                                      const float* __restrict__ c0, const float* __restrict__ rec0, int ldr,
+                                                      float* __restrict__ dpre, int B, int U, int O) {
+    const int W = 2 * U + O;
+    const int total = B * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i / W, k = i - b * W;
+        float d, s;
+        if (k < U) { d = dcc[(long long)b * U + k]; s = c0[(long long)b * U + k]; }
+        else if (k < 2 * U) { d = dxh[(long long)b * ldx + O + (k - U)]; s = rec0[(long long)b * ldr + O + (k - U)]; }
+        else { d = dxh[(long long)b * ldx + (k - 2 * U)]; s = rec0[(long long)b * ldr + (k - 2 * U)]; }
+        dpre[i] = d * (1.f - s * s);
+    }
+}
+
+// ---- decode ----
+// greedy_decoder_cell.py:58-64: id = argmax (first max), finished |= id == END; one wave per row
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int Vp, int V, int n, int id_end,
+                                                    int* __restrict__ ids_step, int* __restrict__ ids_out, int max_steps, int step,
+                                                    int* __restrict__ finished, int* __restrict__ n_unfinished) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* lg = logits + (long long)row * Vp;
+    float best = -3.0e38f; int bi = 0x7fffffff;
+    for (int j = lane; j < V; j += 64) { const float x = lg[j]; if (x > best) { best = x; bi = j; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+        if (bi >= V) bi = 0;
+        ids_step[row] = bi;
+        ids_out[(long long)row * max_steps + step] = bi;
+        const int f = finished[row] | (bi == id_end ? 1 : 0);
+        finished[row] = f;
+        if (!f) atomicAdd(n_unfinished, 1);
+    }
+}
+
+// One block per image: beam_search_decoder_cell.py:146-187.
+//  log_softmax, mask finished beams (0 at END, f32 lowest elsewhere), add running log-probs,
+//  top-k over k*V (beam 0 only at time 0), ids = idx % V, parents = idx / V, gather finished.
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, int Vp, int V, int k, int id_end, int time,
+                                                       float* __restrict__ logp, int* __restrict__ finished,
+                                                       int* __restrict__ ids_step, int* __restrict__ parents_step,
+                                                       int* __restrict__ ids_out, int* __restrict__ par_out, int max_steps,
+                                                       int* __restrict__ n_unfinished) {
+    __shared__ float lse[16];
+    __shared__ float cand_v[16 * 4]; __shared__ int cand_i[16 * 4];
+    __shared__ float sel_v[16]; __shared__ int sel_i[16];
+    __shared__ int fin_old[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float FMIN = -3.40282347e38f;
+    // log-sum-exp per beam (one wave per beam, round-robin)
+    for (int j = wave; j < k; j += 4) {
+        const float* lg = logits + ((long long)b * k + j) * Vp;
+        float m = -3.0e38f;
+        for (int c = lane; c < V; c += 64) m = fmaxf(m, lg[c]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int c = lane; c < V; c += 64) l += expf(lg[c] - m);
+        l = wave_sum(l);
+        if (lane == 0) lse[j] = m + logf(l);
+    }
+    if (tid < k) fin_old[tid] = finished[b * k + tid];
+    __syncthreads();
+    const int nb = time > 0 ? k : 1;
+    const int total = nb * V;
+    for (int sel = 0; sel < k; ++sel) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < total; i += 256) {
+            const int j = i / V, c = i - j * V;
+            bool taken = false;
+            for (int q = 0; q < sel; ++q) taken |= (sel_i[q] == i);
+            if (taken) continue;
+            float sl = logits[((long long)b * k + j) * Vp + c] - lse[j];
+            const float f = fin_old[j] ? 1.f : 0.f;
+            sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
+            const float val = logp[b * k + j] + sl;
+            if (val > best || (val == best && i < bi)) { best = val; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { cand_v[wave] = best; cand_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = cand_v[0]; int bx = cand_i[0];
+            for (int w = 1; w < 4; ++w)
+                if (cand_v[w] > bv || (cand_v[w] == bv && cand_i[w] < bx)) { bv = cand_v[w]; bx = cand_i[w]; }
+            sel_v[sel] = bv; sel_i[sel] = bx;
+        }
+        __syncthreads();
+    }
+    if (tid < k) {
+        const int idx = sel_i[tid];
+        const int id = idx % V, par = idx / V;
+        const int f = fin_old[par] | (id == id_end ? 1 : 0);
+        ids_step[b * k + tid] = id;
+        parents_step[b * k + tid] = par;
+        ids_out[((long long)b * max_steps + time) * k + tid] = id;
+        if (par_out) par_out[((long long)b * max_steps + time) * k + tid] = par;
+        logp[b * k + tid] = sel_v[tid];
+        finished[b * k + tid] = f;
+        if (!f) atomicAdd(n_unfinished, 1);
+    }
+}
+
+// new[v] = old[b*k + parents[v]] for the carried state (o | h of rec, and c)   (beam_search_decoder_cell.py:176-178)
+__global__ __launch_bounds__(256) void beam_gather_kernel(const float* __restrict__ rec, int ldr, int XH, const float* __restrict__ cs, int U,
+                                                         const int* __restrict__ parents, int k, float* __restrict__ tmp_rec, float* __restrict__ tmp_cs, int n) {
+    const int W = XH + U;
+    const long long total = (long long)n * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i / W), c = (int)(i - (long long)v * W);
+        const int src = (v / k) * k + parents[v];
+        if (c < XH) tmp_rec[(long long)v * XH + c] = rec[(long long)src * ldr + c];
+        else tmp_cs[(long long)v * U + (c - XH)] = cs[(long long)src * U + (c - XH)];
+    }
+}
+__global__ __launch_bounds__(256) void beam_scatter_kernel(float* __restrict__ rec, int ldr, int XH, float* __restrict__ cs, int U,
+                                                          const float* __restrict__ tmp_rec, const float* __restrict__ tmp_cs, int n) {
+    const int W = XH + U;
+    const long long total = (long long)n * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i / W), c = (int)(i - (long long)v * W);
+        if (c < XH) rec[(long long)v * ldr + c] = tmp_rec[(long long)v * XH + c];
+        else cs[(long long)v * U + (c - XH)] = tmp_cs[(long long)v * U + (c - XH)];
+    }
+}
+// row v of dst = row v / k of src (tile the initial state over the beam, beam_search_decoder_cell.py:98-109)
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int n, int k, int cols) {
+    const long long total = (long long)n * cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i / cols), c = (int)(i - (long long)v * cols);
+        dst[(long long)v * ldd + c] = src[(long long)(v / k) * lds + c];
+    }
+}
+
+// ---- optimizer ----
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float clip, float* __restrict__ out) {
+    const float gn = sqrtf(sumsq[0]);
+    out[1] = gn;
+    out[0] = clip > 0.f ? clip / fmaxf(gn, clip) : 1.0f;
+}
+// TF AdamOptimizer: theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the host
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  long long n, float lr_t, float b1, float b2, float eps, const float* __restrict__ scale) {
+    const float sc = scale ? scale[0] : 1.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * sc;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+inline int grid1(long long items, int per_block = 256, int cap = 2048) {
+    long long g = (items + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+}  // namespace
+
+#define LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, __VA_ARGS__)
+#define BYCT(dt, kern, grid, ...) do { if ((dt) == LXO_BF16) LAUNCH((kern<bf16_t>), grid, __VA_ARGS__); else LAUNCH((kern<float>), grid, __VA_ARGS__); } while (0)
+#define DONE return (int)hipGetLastError()
+
+int lxo_k_rowmean(int dt, const void* img, float* mean, int B, int R, int C, hipStream_t st) {
+    if (dt == LXO_BF16) LAUNCH((rowmean_kernel<bf16_t>), B, (const bf16_t*)img, mean, R, C);
+    else LAUNCH((rowmean_kernel<float>), B, (const float*)img, mean, R, C);
+    DONE;
+}
+int lxo_k_embed_gather(int dt, const float* table, const float* start, const int* formula, void* out, int B, int T, int D, int Dp, int V, hipStream_t st) {
+    const int g = grid1((long long)T * B * Dp);
+    if (dt == LXO_BF16) LAUNCH((embed_gather_kernel<bf16_t>), g, table, start, formula, (bf16_t*)out, B, T, D, Dp, V);
+    else LAUNCH((embed_gather_kernel<float>), g, table, start, formula, (float*)out, B, T, D, Dp, V);
+    DONE;
+}
+int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* ids, void* out, int n, int D, int Dp, int V, hipStream_t st) {
+    const int g = grid1((long long)n * Dp);
+    if (dt == LXO_BF16) LAUNCH((embed_rows_kernel<bf16_t>), g, table, start, ids, (bf16_t*)out, n, D, Dp, V);
+    else LAUNCH((embed_rows_kernel<float>), g, table, start, ids, (float*)out, n, D, Dp, V);
+    DONE;
+}
+int lxo_k_lstm_fwd(const float* z, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st) {
+    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U), z, c_prev, gates, c_out, h_out, ldh, B, U);
+    DONE;
+}
+int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, const float* dh1, int ld1, const float* dh2, int ld2,
+                   float* dcc, float* dz, int B, int U, hipStream_t st) {
+    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U), gates, c_prev, c_cur, dh1, ld1, dh2, ld2, dcc, dz, B, U);
+    DONE;
+}
+int lxo_k_tanh_bwd(const float* a, int lda, const float* b, int ldb, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st) {
+    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols), a, lda, b, ldb, o, ldo, g, ldg, rows, cols);
+    DONE;
+}
+int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* ctx, int ldctx,
+                   int nv, int R, int Rp, int E, int C, int beam, hipStream_t st) {
+    if (R > MAXR || E > 1024 || C > 512) return -2;
+    if (dt == LXO_BF16) LAUNCH((attn_fwd_kernel<bf16_t>), nv, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, ctx, ldctx, R, Rp, E, C, beam);
+    else LAUNCH((attn_fwd_kernel<float>), nv, (const float*)att_img, (const float*)img, att_h, beta, alpha, ctx, ldctx, R, Rp, E, C, beam);
+    DONE;
+}
+int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
+                   const float* dctx, int lddc, const float* ctx, int ldctx, float* de, float* datth,
+                   int nv, int R, int Rp, int E, int C, hipStream_t st) {
+    if (R > MAXR || E > 1024 || C > 512) return -2;
+    if (dt == LXO_BF16) LAUNCH((attn_bwd_kernel<bf16_t>), nv, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C);
+    else LAUNCH((attn_bwd_kernel<float>), nv, (const float*)att_img, (const float*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C);
+    DONE;
+}
+int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
+                   int T, int B, int R, int Rp, int E, hipStream_t st) {
+    dim3 grid(cdiv(R, 16), B);
+    if (dt == LXO_BF16) hipLaunchKernelGGL((datt_img_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, T, B, R, Rp, E);
+    else hipLaunchKernelGGL((datt_img_kernel<float>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, T, B, R, Rp, E);
+    DONE;
+}
+int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st) {
+    LAUNCH(add_mean_grad_kernel, grid1((long long)B * R * C), dimg, dmean, B, R, C);
+    DONE;
+}
+int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
+                  int B, int T, int V, int Vp, hipStream_t st) {
+    const int g = cdiv(T * B, 4);
+    if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, inv_ntok, B, T, V, Vp);
+    else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, inv_ntok, B, T, V, Vp);
+    DONE;
+}
+int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t st) {
+    const int rpb = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, st, a, lda, out, M, N, rpb);
+    DONE;
+}
+int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st) {
+    LAUNCH(embed_scatter_kernel, grid1((long long)T * B * D), demb, formula, dtable, dstart, B, T, D, V);
+    DONE;
+}
+int lxo_k_init_bwd(const float* dcc, const float* dxh, int ldx, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st) {
+    LAUNCH(init_bwd_kernel, grid1((long long)B * (2 * U + O)), dcc, dxh, ldx, c0, rec0, ldr, dpre, B, U, O);
+    DONE;
+}
+int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids_step, int* ids_out, int max_steps, int step,
+                 int* finished, int* n_unfinished, hipStream_t st) {
+    LAUNCH(argmax_kernel, cdiv(n, 4), logits, Vp, V, n, id_end, ids_step, ids_out, max_steps, step, finished, n_unfinished);
+    DONE;
+}
+int lxo_k_beam_step(const float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float* logp, int* finished,
+                    int* ids_step, int* parents_step, int* ids_out, int* par_out, int max_steps, int* n_unfinished, hipStream_t st) {
+    if (k > 16) return -2;
+    LAUNCH(beam_step_kernel, nimg, logits, Vp, V, k, id_end, time, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
+    DONE;
+}
+int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, hipStream_t st) {
+    LAUNCH(beam_gather_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, parents, k, tmp_rec, tmp_cs, n);
+    LAUNCH(beam_scatter_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, tmp_rec, tmp_cs, n);
+    DONE;
+}
+int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k, int cols, hipStream_t st) {
+    LAUNCH(tile_rows_kernel, grid1((long long)n * cols), src, lds, dst, ldd, n, k, cols);
+    DONE;
+}
+int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sumsq_tmp, float* out, hipStream_t st) {
+    hipMemsetAsync(sumsq_tmp, 0, sizeof(float), st);
+    LAUNCH(sumsq_kernel, grid1(n, 256 * 8, 1024), g, n, sumsq_tmp);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq_tmp, clip, out);
+    DONE;
+}
+int lxo_k_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps, const float* scale, hipStream_t st) {
+    LAUNCH(adam_kernel, grid1(n, 256 * 4, 4096), p, g, m, v, n, lr_t, b1, b2, eps, scale);
+    DONE;
+}

@@ -1,0 +1,405 @@
+// Non-GEMM encoder kernels (all HBM-bound, NHWC, 8 channels = 16 B per lane):
+//   conv1_pool_fwd   : u8 image -> (x-128)/128 -> 3x3 SAME conv 1->64 + bias + ReLU
+//                      -> 2x2 SAME max-pool, fused so the 64-channel full-resolution
+//                      activation never reaches HBM (model/encoder.py:26-34)
+//   conv1_pool_bwd   : recomputes the four conv outputs of each pooled pixel to find
+//                      the arg-max / ReLU mask, accumulates dW1, db1 (no dgrad: the
+//                      image needs no gradient)
+//   maxpool_fwd/bwd  : SAME max-pool with window == stride in {2x2, 2x1, 1x2}
+//                      (encoder.py:39,47,52); bwd routes to the FIRST max of the
+//                      window in (dy,dx) scan order, applies the ReLU mask of the
+//                      pre-pool activation and accumulates the bias gradient
+//   mask_convert     : d_y6 = d_img(f32) * (y6 > 0) -> compute dtype, + bias gradient
+//   timing_signal    : positional.py:42-64 table [Hp*Wp][C] f32
+#include "encoder_kernels.h"
+
+namespace {
+
+template <typename CT>
+__global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, CT* __restrict__ out,
+                                                            int B, int H, int W, int Hp, int Wp) {
+    const int cg = threadIdx.x & 7;            // channels cg*8 .. cg*8+7
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[t][e] = w[t * 64 + cg * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) br[e] = bias[cg * 8 + e];
+    const long long npix = (long long)B * Hp * Wp;
+    for (long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (long long)gridDim.x * 32) {
+        const int px = (int)(pix % Wp);
+        const int py = (int)((pix / Wp) % Hp);
+        const int b = (int)(pix / ((long long)Wp * Hp));
+        const uint8_t* im = img + (long long)b * H * W;
+        float patch[4][4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int y = 2 * py - 1 + dy, x = 2 * px - 1 + dx;
+                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? ((float)im[(long long)y * W + x] - 128.f) / 128.f : 0.f;
+            }
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = -3.0e38f;
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+            for (int qx = 0; qx < 2; ++qx) {
+                if (2 * py + qy >= H || 2 * px + qx >= W) continue;   // SAME pool ignores padding
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = br[e];
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) a = fmaf(patch[qy + kh][qx + kw], wr[kh * 3 + kw][e], a);
+                    best[e] = fmaxf(best[e], fmaxf(a, 0.f));
+                }
+            }
+        store8(out + pix * 64 + cg * 8, best);
+    }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const CT* __restrict__ dout,
+                                                            float* __restrict__ dw, float* __restrict__ db,
+                                                            int B, int H, int W, int Hp, int Wp) {
+    __shared__ float red[4][8][80];
+    const int cg = threadIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wr[9][8], br[8], gw[9][8], gb[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { wr[t][e] = w[t * 64 + cg * 8 + e]; gw[t][e] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { br[e] = bias[cg * 8 + e]; gb[e] = 0.f; }
+    const long long npix = (long long)B * Hp * Wp;
+    // every lane iterates the same number of times so the wave stays convergent
+    const long long iters = (npix + (long long)gridDim.x * 32 - 1) / ((long long)gridDim.x * 32);
+    for (long long it = 0; it < iters; ++it) {
+        const long long pix = (it * gridDim.x + blockIdx.x) * 32 + (threadIdx.x >> 3);
+        if (pix >= npix) continue;
+        const int px = (int)(pix % Wp);
+        const int py = (int)((pix / Wp) % Hp);
+        const int b = (int)(pix / ((long long)Wp * Hp));
+        const uint8_t* im = img + (long long)b * H * W;
+        float patch[4][4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int y = 2 * py - 1 + dy, x = 2 * px - 1 + dx;
+                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? ((float)im[(long long)y * W + x] - 128.f) / 128.f : 0.f;
+            }
+        float g[8];
+        load8(dout + pix * 64 + cg * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float best = -3.0e38f; int bq = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int qy = q >> 1, qx = q & 1;
+                if (2 * py + qy >= H || 2 * px + qx >= W) continue;
+                float a = br[e];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) a = fmaf(patch[qy + kh][qx + kw], wr[kh * 3 + kw][e], a);
+                a = fmaxf(a, 0.f);
+                if (a > best) { best = a; bq = q; }
+            }
+            const float d = best > 0.f ? g[e] : 0.f;
+            gb[e] += d;
+            const int qy = bq >> 1, qx = bq & 1;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // select the patch element of the winning position without dynamic register indexing
+                    const float x00 = patch[kh][kw], x01 = patch[kh][kw + 1], x10 = patch[kh + 1][kw], x11 = patch[kh + 1][kw + 1];
+                    const float xv = qy ? (qx ? x11 : x10) : (qx ? x01 : x00);
+                    gw[kh * 3 + kw][e] = fmaf(xv, d, gw[kh * 3 + kw][e]);
+                }
+        }
+    }
+    // reduce over the 8 lanes-groups of a wave that share a channel group (lane bits 3..5)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = gw[t][e];
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            gw[t][e] = v;
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = gb[e];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        gb[e] = v;
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave][cg][t * 8 + e] = gw[t][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][cg][72 + e] = gb[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 640; i += 256) {
+        const int g8 = i / 80, k = i % 80;
+        const float v = red[0][g8][k] + red[1][g8][k] + red[2][g8][k] + red[3][g8][k];
+        if (k < 72) atomicAdd(&dw[(k >> 3) * 64 + g8 * 8 + (k & 7)], v);
+        else atomicAdd(&db[g8 * 8 + (k - 72)], v);
+    }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const CT* __restrict__ in, CT* __restrict__ out,
+                                                         int B, int H, int W, int C, int ph, int pw, int Ho, int Wo) {
+    const int cgs = C >> 3;
+    const long long total = (long long)B * Ho * Wo * cgs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        const long long pix = i / cgs;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = -3.0e38f;
+        for (int dy = 0; dy < ph; ++dy)
+            for (int dx = 0; dx < pw; ++dx) {
+                const int y = oy * ph + dy, x = ox * pw + dx;
+                if (y >= H || x >= W) continue;
+                float v[8];
+                load8(in + (((long long)b * H + y) * W + x) * C + cg * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
+            }
+        store8(out + pix * C + cg * 8, best);
+    }
+}
+
+// d_y = route(d_p) * (y > 0); db[c] += sum d_y.   One thread per pooled pixel x 8 channels.
+template <typename CT>
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const CT* __restrict__ y, const CT* __restrict__ dp,
+                                                              CT* __restrict__ dyo, float* __restrict__ db,
+                                                              int B, int H, int W, int C, int ph, int pw, int Ho, int Wo) {
+    __shared__ float dbs[512];
+    for (int i = threadIdx.x; i < C; i += 256) dbs[i] = 0.f;
+    __syncthreads();
+    const int cgs = C >> 3;                   // divides 256 (C in {64,128,256,512})
+    const int cg = threadIdx.x % cgs;
+    const int ppb = 256 / cgs;                // pooled pixels per block per iteration
+    const long long npix = (long long)B * Ho * Wo;
+    float gb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gb[e] = 0.f;
+    for (long long pix = (long long)blockIdx.x * ppb + threadIdx.x / cgs; pix < npix; pix += (long long)gridDim.x * ppb) {
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+        float best[8]; int bq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -3.0e38f; bq[e] = 0; }
+        for (int qy = 0; qy < ph; ++qy)
+            for (int qx = 0; qx < pw; ++qx) {
+                const int yy = oy * ph + qy, xx = ox * pw + qx;
+                if (yy >= H || xx >= W) continue;
+                float v[8];
+                load8(y + (((long long)b * H + yy) * W + xx) * C + cg * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > best[e]) { best[e] = v[e]; bq[e] = qy * pw + qx; }
+            }
+        float g[8];
+        load8(dp + pix * C + cg * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[e] = best[e] > 0.f ? g[e] : 0.f; gb[e] += g[e]; }
+        for (int qy = 0; qy < ph; ++qy)
+            for (int qx = 0; qx < pw; ++qx) {
+                const int yy = oy * ph + qy, xx = ox * pw + qx;
+                if (yy >= H || xx >= W) continue;
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bq[e] == qy * pw + qx) ? g[e] : 0.f;
+                store8(dyo + (((long long)b * H + yy) * W + xx) * C + cg * 8, o);
+            }
+    }
+    if (db) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&dbs[cg * 8 + e], gb[e]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&db[i], dbs[i]);
+    }
+}
+
+// out = d(f32) * (ref > 0) in the compute dtype; db[c] += column sums.
+template <typename CT>
+__global__ __launch_bounds__(256) void mask_convert_kernel(const float* __restrict__ d, const CT* __restrict__ ref,
+                                                          CT* __restrict__ out, float* __restrict__ db,
+                                                          long long rows, int C) {
+    __shared__ float dbs[512];
+    for (int i = threadIdx.x; i < C; i += 256) dbs[i] = 0.f;
+    __syncthreads();
+    const int cgs = C >> 3;
+    const int cg = threadIdx.x % cgs;
+    const int rpb = 256 / cgs;
+    float gb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gb[e] = 0.f;
+    for (long long r = (long long)blockIdx.x * rpb + threadIdx.x / cgs; r < rows; r += (long long)gridDim.x * rpb) {
+        float g[8], v[8];
+        load8(d + r * C + cg * 8, g);
+        load8(ref + r * C + cg * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[e] = v[e] > 0.f ? g[e] : 0.f; gb[e] += g[e]; }
+        store8(out + r * C + cg * 8, g);
+    }
+    if (db) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&dbs[cg * 8 + e], gb[e]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&db[i], dbs[i]);
+    }
+}
+
+// positional.py:42-64: channels [sin_h | cos_h | sin_w | cos_w], C/4 timescales each
+__global__ __launch_bounds__(256) void timing_signal_kernel(float* __restrict__ pos, int Hp, int Wp, int C) {
+    const int nts = C / 4;
+    const float inc = logf(1.0e4f / 1.0f) / ((float)nts - 1.f);
+    const long long total = (long long)Hp * Wp * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int w = (int)((i / C) % Wp), h = (int)(i / ((long long)C * Wp));
+        const int q = c / nts, k = c - q * nts;
+        const float inv = expf((float)k * -inc);
+        const float t = (q < 2 ? (float)h : (float)w) * inv;
+        pos[i] = (q & 1) ? cosf(t) : sinf(t);
+    }
+}
+
+// ---- weight packing (master f32 TF layouts -> compute-dtype GEMM operands) ----
+// dst[n][coff + k] = k < K ? src[k*lds + n] : 0   for n < N, k < Kpad
+template <typename CT>
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ src, CT* __restrict__ dst,
+                                                            int K, int N, int lds, int ldd, int coff, int Kpad) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? src[(long long)k * lds + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < Kpad) dst[(long long)n * ldd + coff + k] = from_f32<CT>(tile[tx][r]);
+    }
+}
+// dst[r][c] = c < Ccols ? src[r*lds + c] : 0   for r < R, c < Cpad
+template <typename CT>
+__global__ __launch_bounds__(256) void pack_copy_kernel(const float* __restrict__ src, CT* __restrict__ dst,
+                                                       int R, int Ccols, int lds, int ldd, int Cpad) {
+    const long long total = (long long)R * Cpad;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % Cpad); const long long r = i / Cpad;
+        dst[r * ldd + c] = from_f32<CT>(c < Ccols ? src[r * lds + c] : 0.f);
+    }
+}
+// conv dgrad operand: dst[ci][(a*3+b)*Cout + co] = W[((2-a)*3+(2-b))*Cin + ci][co]
+template <typename CT>
+__global__ __launch_bounds__(256) void pack_conv_dgrad_kernel(const float* __restrict__ w, CT* __restrict__ dst, int Cin, int Cout) {
+    const long long total = (long long)Cin * 9 * Cout;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        const int tap = (int)((i / Cout) % 9);
+        const int ci = (int)(i / ((long long)Cout * 9));
+        const int a = tap / 3, b = tap - 3 * a;
+        dst[i] = from_f32<CT>(w[((long long)((2 - a) * 3 + (2 - b)) * Cin + ci) * Cout + co]);
+    }
+}
+
+inline int grid_for(long long items, int per_block, int cap = 2048) {
+    long long g = (items + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+}  // namespace
+
+#define DISPATCH_CT(dt, FN, ...) do { if ((dt) == LXO_BF16) { FN<bf16_t>(__VA_ARGS__); } else { FN<float>(__VA_ARGS__); } } while (0)
+
+template <typename CT> static void conv1_fwd_t(const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s) {
+    const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
+    hipLaunchKernelGGL((conv1_pool_fwd_kernel<CT>), dim3(grid_for((long long)B * Hp * Wp, 32, 4096)), dim3(256), 0, s,
+                       img, w, b, (CT*)out, B, H, W, Hp, Wp);
+}
+int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s) {
+    DISPATCH_CT(dt, conv1_fwd_t, img, w, b, out, B, H, W, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void conv1_bwd_t(const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s) {
+    const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
+    hipLaunchKernelGGL((conv1_pool_bwd_kernel<CT>), dim3(grid_for((long long)B * Hp * Wp, 32 * 16, 512)), dim3(256), 0, s,
+                       img, w, b, (const CT*)dout, dw, db, B, H, W, Hp, Wp);
+}
+int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s) {
+    DISPATCH_CT(dt, conv1_bwd_t, img, w, b, dout, dw, db, B, H, W, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void pool_fwd_t(const void* in, void* out, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
+    const int Ho = (H + ph - 1) / ph, Wo = (W + pw - 1) / pw;
+    hipLaunchKernelGGL((maxpool_fwd_kernel<CT>), dim3(grid_for((long long)B * Ho * Wo * (C / 8), 256, 8192)), dim3(256), 0, s,
+                       (const CT*)in, (CT*)out, B, H, W, C, ph, pw, Ho, Wo);
+}
+int lxo_k_maxpool_fwd(int dt, const void* in, void* out, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
+    if (C % 8 || C > 512 || 256 % (C / 8)) return -2;
+    DISPATCH_CT(dt, pool_fwd_t, in, out, B, H, W, C, ph, pw, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void pool_bwd_t(const void* y, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
+    const int Ho = (H + ph - 1) / ph, Wo = (W + pw - 1) / pw;
+    const int ppb = 256 / (C / 8);
+    hipLaunchKernelGGL((maxpool_relu_bwd_kernel<CT>), dim3(grid_for((long long)B * Ho * Wo, ppb * 8, 2048)), dim3(256), 0, s,
+                       (const CT*)y, (const CT*)dp, (CT*)dy, db, B, H, W, C, ph, pw, Ho, Wo);
+}
+int lxo_k_maxpool_relu_bwd(int dt, const void* y, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
+    if (C % 8 || C > 512 || 256 % (C / 8)) return -2;
+    DISPATCH_CT(dt, pool_bwd_t, y, dp, dy, db, B, H, W, C, ph, pw, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void mask_convert_t(const float* d, const void* ref, void* out, float* db, long long rows, int C, hipStream_t s) {
+    const int rpb = 256 / (C / 8);
+    hipLaunchKernelGGL((mask_convert_kernel<CT>), dim3(grid_for(rows, rpb * 8, 2048)), dim3(256), 0, s,
+                       d, (const CT*)ref, (CT*)out, db, rows, C);
+}
+int lxo_k_mask_convert(int dt, const float* d, const void* ref, void* out, float* db, long long rows, int C, hipStream_t s) {
+    if (C % 8 || C > 512 || 256 % (C / 8)) return -2;
+    DISPATCH_CT(dt, mask_convert_t, d, ref, out, db, rows, C, s);
+    return (int)hipGetLastError();
+}
+int lxo_k_timing_signal(float* pos, int Hp, int Wp, int C, hipStream_t s) {
+    hipLaunchKernelGGL(timing_signal_kernel, dim3(grid_for((long long)Hp * Wp * C, 256, 1024)), dim3(256), 0, s, pos, Hp, Wp, C);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void pack_tr_t(const float* src, void* dst, int K, int N, int lds, int ldd, int coff, int Kpad, hipStream_t s) {
+    hipLaunchKernelGGL((pack_transpose_kernel<CT>), dim3(cdiv(Kpad, 32), cdiv(N, 32)), dim3(256), 0, s, src, (CT*)dst, K, N, lds, ldd, coff, Kpad);
+}
+int lxo_k_pack_transpose(int dt, const float* src, void* dst, int K, int N, int lds, int ldd, int coff, int Kpad, hipStream_t s) {
+    DISPATCH_CT(dt, pack_tr_t, src, dst, K, N, lds, ldd, coff, Kpad, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void pack_cp_t(const float* src, void* dst, int R, int Ccols, int lds, int ldd, int Cpad, hipStream_t s) {
+    hipLaunchKernelGGL((pack_copy_kernel<CT>), dim3(grid_for((long long)R * Cpad, 256, 2048)), dim3(256), 0, s, src, (CT*)dst, R, Ccols, lds, ldd, Cpad);
+}
+int lxo_k_pack_copy(int dt, const float* src, void* dst, int R, int Ccols, int lds, int ldd, int Cpad, hipStream_t s) {
+    DISPATCH_CT(dt, pack_cp_t, src, dst, R, Ccols, lds, ldd, Cpad, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void pack_dg_t(const float* w, void* dst, int Cin, int Cout, hipStream_t s) {
+    hipLaunchKernelGGL((pack_conv_dgrad_kernel<CT>), dim3(grid_for((long long)Cin * 9 * Cout, 256, 2048)), dim3(256), 0, s, w, (CT*)dst, Cin, Cout);
+}
+int lxo_k_pack_conv_dgrad(int dt, const float* w, void* dst, int Cin, int Cout, hipStream_t s) {
+    DISPATCH_CT(dt, pack_dg_t, w, dst, Cin, Cout, s);
+    return (int)hipGetLastError();
+}

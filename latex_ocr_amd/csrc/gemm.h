@@ -1,0 +1,43 @@
+// Host-visible parameter blocks and launchers of the two MFMA GEMM families.
+#pragma once
+#include "lxo_common.h"
+
+// C[M,N] = epilogue( A[M,K] * Bp[N,K]^T )   ("NT": both operands K-contiguous)
+// A is either a dense row-major matrix (lda) or the implicit im2col view of an
+// NHWC tensor for a 3x3 stride-1 convolution (row m = (b,oy,ox), k = (kh,kw,ci)).
+struct GemmNT {
+    const void* A; const void* Bp; void* C;
+    int M, N, K;               // K % 32 == 0
+    int lda, ldb, ldc;         // elements; lda, ldb % 8 == 0
+    // implicit-im2col geometry (conv != 0)
+    int conv, H, W, Cin, Ho, Wo, pad;   // input H x W x Cin, output grid Ho x Wo
+    // epilogue: v = alpha*acc + bias[n]; v = act(v); [out_pre = v]; v += addend[m % addend_rows][n];
+    //           v *= (relu_ref[m][n] > 0); colsum[n] += v; C = (accumulate ? C : 0) + v
+    const float* bias;
+    const float* addend; int addend_rows;
+    int act;                   // 0 none, 1 relu, 2 tanh
+    const void* relu_ref; int ldr;
+    void* out_pre;
+    int accumulate;
+    float* colsum;
+    float alpha;
+};
+
+// C[I,J] (+)= sum_m A[m,I] * B[m,J]      ("TN": reduction over rows)
+// A is dense [M][lda] or the implicit im2col view (I = 9*Cin); output is f32,
+// reduced across `nsplit` row ranges with atomics.  Batched over `nbatch`.
+struct GemmTN {
+    const void* A; const void* B; float* C;
+    int M, I, J;
+    int lda, ldb, ldc;
+    int conv, H, W, Cin, Ho, Wo, pad;
+    int nsplit, nbatch;
+    long long strideA, strideB, strideC;
+    int atomic;                // 1: atomicAdd into C (C pre-initialised); 0: plain store (nsplit must be 1)
+};
+
+// dt: LXO_F32 / LXO_BF16 = compute type (type of Bp / conv tensors);
+// a_f32 / c_f32: the dense A operand / the output is float even when dt == bf16.
+// small != 0 selects the 64x64 tile (M <= 64 step GEMMs).
+int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p, hipStream_t s);
+int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_t s);

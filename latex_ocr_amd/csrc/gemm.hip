@@ -1,0 +1,429 @@
+// MFMA GEMM families for gfx950.
+//
+//  gemm_nt_kernel : C = epi(A * Bp^T), A dense or implicit-im2col (3x3 conv fwd
+//                   and dgrad), 4 waves, each wave a grid of 32x32 MFMA tiles,
+//                   global -> registers -> LDS staging with the next K-tile's
+//                   loads in flight under the current tile's MFMAs.
+//  gemm_tn_kernel : C += A^T * B reduced over rows (conv wgrad, every dense
+//                   weight gradient, the deferred d_img outer-product sum).
+//                   The reduction index is the strided one in memory, so rows
+//                   are paired and written to LDS as packed bf16x2 dwords, which
+//                   makes the MFMA operand reads contiguous without a per-element
+//                   scatter.
+//
+// bf16 mode uses v_mfma_f32_32x32x16_bf16 (f32 accumulate); f32 mode (parity
+// mode) uses v_mfma_f32_32x32x2_f32, which is an exact fmaf chain.
+#include "gemm.h"
+
+namespace {
+
+template <typename CT> struct StageReg;
+template <> struct StageReg<bf16_t> { u32x4 v; };
+template <> struct StageReg<float> { f32x4 lo, hi; };
+
+template <typename CT, typename TA>
+LXO_DEV StageReg<CT> stage_load(const TA* p, bool ok) {
+    StageReg<CT> r;
+    if constexpr (is_bf16<CT>::value) {
+        if constexpr (is_bf16<TA>::value) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            r.v = ok ? *reinterpret_cast<const u32x4*>(p) : z;
+        } else {
+            float v[8];
+            if (ok) load8(p, v);
+            else { for (int i = 0; i < 8; ++i) v[i] = 0.f; }
+            u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            r.v = t;
+        }
+    } else {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        r.lo = ok ? *reinterpret_cast<const f32x4*>(p) : z;
+        r.hi = ok ? *reinterpret_cast<const f32x4*>(p + 4) : z;
+    }
+    return r;
+}
+
+template <typename CT>
+LXO_DEV void stage_store_rowmajor(CT* lds, const StageReg<CT>& r) {
+    if constexpr (is_bf16<CT>::value) {
+        *reinterpret_cast<u32x4*>(lds) = r.v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lds[e] = r.lo[e]; lds[4 + e] = r.hi[e]; }
+    }
+}
+
+LXO_DEV f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ NT ----
+template <typename CT, bool CONV, typename TA, typename OT, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
+    constexpr bool BF = is_bf16<CT>::value;
+    constexpr int BK = 32;
+    constexpr int PITCH = BF ? 40 : 33;
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave (2x2 waves)
+    constexpr int AC = BM / 64, BC = BN / 64;     // 8-element chunks per thread
+    __shared__ __attribute__((aligned(16))) CT As[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) CT Bs[BN * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const TA* __restrict__ A = reinterpret_cast<const TA*>(p.A);
+    const CT* __restrict__ Bp = reinterpret_cast<const CT*>(p.Bp);
+
+    const int srow = tid >> 2, skc = (tid & 3) * 8;
+    // per-thread row descriptors
+    bool a_ok[AC]; long long a_base[AC]; int a_oy[AC], a_ox[AC];
+#pragma unroll
+    for (int j = 0; j < AC; ++j) {
+        const int m = m0 + srow + 64 * j;
+        a_ok[j] = m < p.M;
+        if constexpr (CONV) {
+            const int mm = a_ok[j] ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_oy[j] = oy - p.pad; a_ox[j] = ox - p.pad;
+            a_base[j] = (long long)b * p.H * p.W;
+        } else {
+            a_base[j] = (long long)m * p.lda;
+            a_oy[j] = a_ox[j] = 0;
+        }
+    }
+    bool b_ok[BC]; long long b_base[BC];
+#pragma unroll
+    for (int j = 0; j < BC; ++j) {
+        const int n = n0 + srow + 64 * j;
+        b_ok[j] = n < p.N;
+        b_base[j] = (long long)n * p.ldb;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    StageReg<CT> ra[AC], rb[BC];
+    auto gload = [&](int k0) {
+        int kh = 0, kw = 0, ci0 = k0;
+        if constexpr (CONV) {
+            const int tap = k0 / p.Cin;
+            ci0 = k0 - tap * p.Cin;
+            kh = tap / 3; kw = tap - 3 * kh;
+        }
+#pragma unroll
+        for (int j = 0; j < AC; ++j) {
+            if constexpr (CONV) {
+                const int iy = a_oy[j] + kh, ix = a_ox[j] + kw;
+                const bool ok = a_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const long long off = ok ? (a_base[j] + (long long)iy * p.W + ix) * p.Cin + ci0 + skc : 0;
+                ra[j] = stage_load<CT, TA>(A + off, ok);
+            } else {
+                const long long off = a_ok[j] ? a_base[j] + k0 + skc : 0;
+                ra[j] = stage_load<CT, TA>(A + off, a_ok[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+            const long long off = b_ok[j] ? b_base[j] + k0 + skc : 0;
+            rb[j] = stage_load<CT, CT>(Bp + off, b_ok[j]);
+        }
+    };
+
+    gload(0);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < AC; ++j) stage_store_rowmajor<CT>(&As[(srow + 64 * j) * PITCH + skc], ra[j]);
+#pragma unroll
+        for (int j = 0; j < BC; ++j) stage_store_rowmajor<CT>(&Bs[(srow + 64 * j) * PITCH + skc], rb[j]);
+        __syncthreads();
+        if (k0 + BK < p.K) gload(k0 + BK);
+        if constexpr (BF) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 af[TM], bfr[TN];
+                const int kof = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const u32x4*>(&As[(wm * (BM / 2) + i * 32 + (lane & 31)) * PITCH + kof]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[j] = *reinterpret_cast<const u32x4*>(&Bs[(wn * (BN / 2) + j * 32 + (lane & 31)) * PITCH + kof]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[i], bfr[j], acc[i][j]);
+            }
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < 16; ++ks) {
+                float af[TM], bfr[TN];
+                const int kof = ks * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[(wm * (BM / 2) + i * 32 + (lane & 31)) * PITCH + kof];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = Bs[(wn * (BN / 2) + j * 32 + (lane & 31)) * PITCH + kof];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    OT* __restrict__ C = reinterpret_cast<OT*>(p.C);
+    OT* __restrict__ Cpre = reinterpret_cast<OT*>(p.out_pre);
+    const CT* __restrict__ ref = reinterpret_cast<const CT*>(p.relu_ref);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        const bool n_ok = n < p.N;
+        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (!(n_ok && m < p.M)) continue;
+                float v = p.alpha * acc[i][j][r] + bias;
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                else if (p.act == 2) v = tanhf(v);
+                const long long o = (long long)m * p.ldc + n;
+                if (Cpre) Cpre[o] = from_f32<OT>(v);
+                if (p.addend) v += p.addend[(long long)(m % p.addend_rows) * p.N + n];
+                if (ref) v = (to_f32(ref[(long long)m * p.ldr + n]) > 0.f) ? v : 0.f;
+                csum += v;
+                if (p.accumulate) v += to_f32(C[o]);
+                C[o] = from_f32<OT>(v);
+            }
+        }
+        if (p.colsum) {
+            csum += __shfl_xor(csum, 32);
+            if (lane < 32 && n_ok) atomicAdd(&p.colsum[n], csum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ TN ----
+template <typename CT, bool CONV, typename TA, typename TB>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+    constexpr bool BF = is_bf16<CT>::value;
+    constexpr int BI = 128, BJ = 128, BR = 32;
+    constexpr int PITCH = BF ? 36 : 33;
+    __shared__ __attribute__((aligned(16))) CT As[BI * PITCH];
+    __shared__ __attribute__((aligned(16))) CT Bs[BJ * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = blockIdx.y * BI, j0 = blockIdx.x * BJ;
+    const int batch = blockIdx.z / p.nsplit, split = blockIdx.z - batch * p.nsplit;
+    const int per = ((p.M + p.nsplit - 1) / p.nsplit + BR - 1) / BR * BR;
+    const int mbeg = split * per;
+    const int mend = min(p.M, mbeg + per);
+    const TA* __restrict__ A = reinterpret_cast<const TA*>(p.A) + (long long)batch * p.strideA;
+    const TB* __restrict__ B = reinterpret_cast<const TB*>(p.B) + (long long)batch * p.strideB;
+    float* __restrict__ C = p.C + (long long)batch * p.strideC;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging geometry
+    //  bf16: one (row-pair, 8-column chunk) of A and of B per thread
+    //  f32 : two (row, 8-column chunk) of A and of B per thread
+    constexpr int NQ = BF ? 1 : 2;
+    int s_r[NQ], s_c[NQ];           // row offset within the 32-row slab, chunk index (0..15)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if constexpr (BF) { s_r[q] = 2 * (lane & 15); s_c[q] = (lane >> 4) + 4 * wave; }
+        else { const int c = tid + 256 * q; s_r[q] = c & 31; s_c[q] = c >> 5; }
+    }
+    // conv: decode of the A column chunk (tap, channel) is loop invariant
+    int c_kh[NQ], c_kw[NQ], c_ci[NQ];
+    bool ai_ok[NQ], bj_ok[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = i0 + s_c[q] * 8;
+        ai_ok[q] = i < p.I;
+        bj_ok[q] = (j0 + s_c[q] * 8) < p.J;
+        c_kh[q] = c_kw[q] = c_ci[q] = 0;
+        if constexpr (CONV) {
+            const int ii = ai_ok[q] ? i : 0;
+            const int tap = ii / p.Cin;
+            c_ci[q] = ii - tap * p.Cin;
+            c_kh[q] = tap / 3; c_kw[q] = tap - 3 * c_kh[q];
+        }
+    }
+    constexpr int NR = BF ? 2 : 1;   // rows per staged item
+    auto a_ptr = [&](int q, int m, bool& ok) -> const TA* {
+        ok = ai_ok[q] && m < mend;
+        if (!ok) return A;
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int iy = oy - p.pad + c_kh[q], ix = ox - p.pad + c_kw[q];
+            ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (!ok) return A;
+            return A + (((long long)b * p.H + iy) * p.W + ix) * p.Cin + c_ci[q];
+        } else {
+            return A + (long long)m * p.lda + i0 + s_c[q] * 8;
+        }
+    };
+
+    float va[NQ][NR][8], vb[NQ][NR][8];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const int m = mb + s_r[q] + rr;
+                bool ok; const TA* pa = a_ptr(q, m, ok);
+                if (ok) load8(pa, va[q][rr]);
+                else { for (int e = 0; e < 8; ++e) va[q][rr][e] = 0.f; }
+                const bool okb = bj_ok[q] && m < mend;
+                if (okb) load8(B + (long long)m * p.ldb + j0 + s_c[q] * 8, vb[q][rr]);
+                else { for (int e = 0; e < 8; ++e) vb[q][rr][e] = 0.f; }
+            }
+    };
+
+    if (mbeg < mend) gload(mbeg);
+    for (int mb = mbeg; mb < mend; mb += BR) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (BF) {
+                    *reinterpret_cast<unsigned*>(&As[(s_c[q] * 8 + e) * PITCH + s_r[q]]) = pack_bf2(va[q][0][e], va[q][1][e]);
+                    *reinterpret_cast<unsigned*>(&Bs[(s_c[q] * 8 + e) * PITCH + s_r[q]]) = pack_bf2(vb[q][0][e], vb[q][1][e]);
+                } else {
+                    As[(s_c[q] * 8 + e) * PITCH + s_r[q]] = va[q][0][e];
+                    Bs[(s_c[q] * 8 + e) * PITCH + s_r[q]] = vb[q][0][e];
+                }
+            }
+        }
+        __syncthreads();
+        if (mb + BR < mend) gload(mb + BR);
+        if constexpr (BF) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 af[2], bfr[2];
+                const int kof = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const CT* pa = &As[(wi * 64 + i * 32 + (lane & 31)) * PITCH + kof];
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pa), hi = *reinterpret_cast<const u32x2*>(pa + 4);
+                    af[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    const CT* pb = &Bs[(wj * 64 + i * 32 + (lane & 31)) * PITCH + kof];
+                    const u32x2 lo2 = *reinterpret_cast<const u32x2*>(pb), hi2 = *reinterpret_cast<const u32x2*>(pb + 4);
+                    bfr[i] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[i], bfr[j], acc[i][j]);
+            }
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < 16; ++ks) {
+                float af[2], bfr[2];
+                const int kof = ks * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = As[(wi * 64 + i * 32 + (lane & 31)) * PITCH + kof];
+                    bfr[i] = Bs[(wj * 64 + i * 32 + (lane & 31)) * PITCH + kof];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int jj = j0 + wj * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ii = i0 + wi * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (ii < p.I && jj < p.J) {
+                    float* dst = &C[(long long)ii * p.ldc + jj];
+                    if (p.atomic) atomicAdd(dst, acc[i][j][r]);
+                    else *dst = acc[i][j][r];
+                }
+            }
+    }
+}
+
+template <typename CT, bool CONV, typename TA, typename OT, int BM, int BN>
+int launch_nt(const GemmNT& p, hipStream_t s) {
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM));
+    hipLaunchKernelGGL((gemm_nt_kernel<CT, CONV, TA, OT, BM, BN>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+template <typename CT, bool CONV, typename TA, typename TB>
+int launch_tn(const GemmTN& p, hipStream_t s) {
+    dim3 grid(cdiv(p.J, 128), cdiv(p.I, 128), p.nbatch * p.nsplit);
+    hipLaunchKernelGGL((gemm_tn_kernel<CT, CONV, TA, TB>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return 0;
+    if (p.K % 32 != 0 || p.K <= 0) return -2;
+    if (dt == LXO_F32) {
+        if (p.conv) return launch_nt<float, true, float, float, 128, 128>(p, s);
+        if (small) return launch_nt<float, false, float, float, 64, 64>(p, s);
+        return launch_nt<float, false, float, float, 128, 128>(p, s);
+    }
+    if (p.conv) {
+        if (a_f32 || c_f32) return -3;
+        return launch_nt<bf16_t, true, bf16_t, bf16_t, 128, 128>(p, s);
+    }
+    if (small) {
+        if (!(a_f32 && c_f32)) return -3;
+        return launch_nt<bf16_t, false, float, float, 64, 64>(p, s);
+    }
+    if (!a_f32 && !c_f32) return launch_nt<bf16_t, false, bf16_t, bf16_t, 128, 128>(p, s);
+    if (!a_f32 && c_f32) return launch_nt<bf16_t, false, bf16_t, float, 128, 128>(p, s);
+    if (a_f32 && c_f32) return launch_nt<bf16_t, false, float, float, 128, 128>(p, s);
+    return -3;
+}
+
+int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_t s) {
+    if (p.I <= 0 || p.J <= 0 || p.M <= 0) return 0;
+    if (!p.atomic && p.nsplit != 1) return -2;
+    if (dt == LXO_F32) {
+        if (p.conv) return launch_tn<float, true, float, float>(p, s);
+        return launch_tn<float, false, float, float>(p, s);
+    }
+    if (p.conv) {
+        if (a_f32 || b_f32) return -3;
+        return launch_tn<bf16_t, true, bf16_t, bf16_t>(p, s);
+    }
+    if (!a_f32 && !b_f32) return launch_tn<bf16_t, false, bf16_t, bf16_t>(p, s);
+    if (a_f32 && !b_f32) return launch_tn<bf16_t, false, float, bf16_t>(p, s);
+    if (a_f32 && b_f32) return launch_tn<bf16_t, false, float, float>(p, s);
+    return -3;
+}

@@ -1,0 +1,87 @@
+// Device-side common definitions for the gfx950 (MI355X / CDNA4) kernels.
+// Wavefront = 64 lanes everywhere; MFMA lane layouts per the CDNA4 ISA:
+//   32x32x16 bf16 : A[i=l&31][k=(l>>5)*8+e]  B[k=(l>>5)*8+e][j=l&31]
+//   32x32x2  f32  : A[i=l&31][k=l>>5]        B[k=l>>5][j=l&31]
+//   C/D (both)    : col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+#define LXO_DEV __device__ __forceinline__
+
+LXO_DEV float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet)
+LXO_DEV bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+LXO_DEV unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <class T> struct is_bf16 { static constexpr bool value = false; };
+template <> struct is_bf16<bf16_t> { static constexpr bool value = true; };
+
+LXO_DEV float to_f32(float v) { return v; }
+LXO_DEV float to_f32(bf16_t v) { return bf2f(v); }
+template <class T> LXO_DEV T from_f32(float v);
+template <> LXO_DEV float from_f32<float>(float v) { return v; }
+template <> LXO_DEV bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+
+// 8 consecutive elements -> float[8] (pointer must be 16-byte aligned for bf16,
+// 16-byte aligned for float)
+LXO_DEV void load8(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+LXO_DEV void load8(const bf16_t* p, float (&v)[8]) {
+    u32x4 a = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(a[i] << 16);
+        v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+    }
+}
+LXO_DEV void store8(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+LXO_DEV void store8(bf16_t* p, const float (&v)[8]) {
+    u32x4 a = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    *reinterpret_cast<u32x4*>(p) = a;
+}
+
+LXO_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+LXO_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+LXO_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// dtype codes of the C ABI (include/lxo.h)
+#ifndef LXO_F32
+#define LXO_F32 0
+#define LXO_BF16 1
+#endif
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }

@@ -1,0 +1,285 @@
+// Host orchestration of the decoder: attention set-up, the T-step recurrent loop
+// (forward and BPTT), loss, deferred weight-gradient GEMMs, greedy and beam decode.
+// Reference graph: model/decoder.py:41-72, model/components/attention_mechanism.py,
+// model/components/attention_cell.py:58-89, model/img2seq.py:68-75.
+#include "plan.h"
+#include "gemm.h"
+#include "decoder_kernels.h"
+#include "api_util.h"
+
+namespace {
+// dense C = act(A * Bp^T + bias) on the compute dtype `dt`
+int nt(const Plan& P, bool a_f32, bool c_f32, bool small, const void* A, int lda, const void* Bp, int ldb, void* C, int ldc,
+       int M, int N, int K, const float* bias, int act, bool accumulate, hipStream_t st) {
+    GemmNT g; memset(&g, 0, sizeof(g));
+    g.A = A; g.Bp = Bp; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.bias = bias; g.act = act; g.alpha = 1.f; g.accumulate = accumulate ? 1 : 0; g.addend_rows = 1;
+    if (P.s.dtype == LXO_F32) { a_f32 = true; c_f32 = true; }
+    return lxo_launch_gemm_nt(P.s.dtype, a_f32, c_f32, small, g, st);
+}
+// C[I][J] += A^T B over M rows
+int tn(const Plan& P, bool a_f32, bool b_f32, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+       int M, int I, int J, hipStream_t st) {
+    GemmTN g; memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.M = M; g.I = I; g.J = J; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    const int tiles = cdiv(I, 128) * cdiv(J, 128);
+    int ns = cdiv(512, tiles);
+    const int maxs = M / 64 > 0 ? M / 64 : 1;
+    if (ns > maxs) ns = maxs;
+    g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
+    if (P.s.dtype == LXO_F32) { a_f32 = true; b_f32 = true; }
+    return lxo_launch_gemm_tn(P.s.dtype, a_f32, b_f32, g, st);
+}
+}  // namespace
+
+// att_img projection + initial states (attention_mechanism.py:19-43, 124-153; attention_cell.py:51-56)
+// nv = number of decoder rows (B for training/greedy, B*beam for beam search; rows v use image v / beam).
+static int attention_prepare(const Plan& P, const float* prm, const void* wp, void* ws, int beam, hipStream_t st) {
+    const int B = P.s.B, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
+    RC(nt(P, false, false, false, P.ws<void>(ws, W_IMG), C, P.pk(wp, K_ATT_IMG_T), C, P.ws<void>(ws, W_ATT_IMG), E,
+          B * P.R, E, C, nullptr, 0, false, st));
+    RC(lxo_k_rowmean(P.s.dtype, P.ws<void>(ws, W_IMG), P.ws<float>(ws, W_MEAN), B, P.R, C, st));
+    float* rec0 = P.ws<float>(ws, W_REC);
+    float* cs0 = P.ws<float>(ws, W_CS);
+    const char* wt = (const char*)P.pk(wp, K_INIT_T);
+    float* mean = P.ws<float>(ws, W_MEAN);
+    if (beam <= 1) {
+        RC(nt(P, true, true, true, mean, C, wt, C, cs0, U, B, U, C, prm + P.poff[P_BC0], 2, false, st));
+        RC(nt(P, true, true, true, mean, C, wt + (size_t)U * C * P.esz, C, rec0 + O, P.REC, B, U, C, prm + P.poff[P_BH0], 2, false, st));
+        RC(nt(P, true, true, true, mean, C, wt + (size_t)2 * U * C * P.esz, C, rec0, P.REC, B, O, C, prm + P.poff[P_BO0], 2, false, st));
+    } else {
+        // compute once per image into the beam scratch, then tile over the beam (beam_search_decoder_cell.py:98-109)
+        float* tmp = P.ws<float>(ws, W_BEAM_TMP);
+        float* tc = tmp; float* th = tmp + (size_t)B * U; float* to = th + (size_t)B * U;
+        RC(nt(P, true, true, true, mean, C, wt, C, tc, U, B, U, C, prm + P.poff[P_BC0], 2, false, st));
+        RC(nt(P, true, true, true, mean, C, wt + (size_t)U * C * P.esz, C, th, U, B, U, C, prm + P.poff[P_BH0], 2, false, st));
+        RC(nt(P, true, true, true, mean, C, wt + (size_t)2 * U * C * P.esz, C, to, O, B, O, C, prm + P.poff[P_BO0], 2, false, st));
+        RC(lxo_k_tile_rows(tc, U, cs0, U, B * beam, beam, U, st));
+        RC(lxo_k_tile_rows(th, U, rec0 + O, P.REC, B * beam, beam, U, st));
+        RC(lxo_k_tile_rows(to, O, rec0, P.REC, B * beam, beam, O, st));
+    }
+    return 0;
+}
+
+// One AttentionCell.step (attention_cell.py:58-89) for nv rows.  zx_t must already hold
+// emb_t * K[0:D] + b; rec_prev/cs_prev = state t-1, rec_cur/cs_cur receive state t.
+static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam,
+                     float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
+                     float* gates_t, float* atth_t, float* alpha_t, hipStream_t st) {
+    const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
+    // z = zx + [o_prev, h_prev] K[D:]            (attention_cell.py:70-71)
+    RC(nt(P, true, true, true, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, zx_t, 4 * U, nv, 4 * U, P.XH, nullptr, 0, true, st));
+    RC(lxo_k_lstm_fwd(zx_t, cs_prev, gates_t, cs_cur, rec_cur + O, P.REC, nv, U, st));
+    // att_h = h W                                 (attention_mechanism.py:79)
+    RC(nt(P, true, true, true, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, atth_t, E, nv, E, U, nullptr, 0, false, st));
+    RC(lxo_k_attn_fwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), atth_t, prm + P.poff[P_BETA], alpha_t,
+                      rec_cur + P.XH, P.REC, nv, P.R, P.Rp, E, C, beam, st));
+    // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
+    RC(nt(P, true, true, true, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, rec_cur, P.REC, nv, O, P.HC, nullptr, 2, false, st));
+    return 0;
+}
+
+int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, hipStream_t st) {
+    const int B = P.s.B, T = P.s.T, U = P.s.U, O = P.s.O, E = P.s.E, D = P.s.D, V = P.s.V;
+    RC(attention_prepare(P, prm, wp, ws, 1, st));
+    RC(lxo_k_embed_gather(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], formula, P.ws<void>(ws, W_EMB_IN), B, T, D, P.Dp, V, st));
+    float* zx = P.ws<float>(ws, W_ZX);
+    RC(nt(P, false, true, false, P.ws<void>(ws, W_EMB_IN), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, T * B, 4 * U, P.Dp,
+          prm + P.poff[P_LSTM_B], 0, false, st));
+    float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
+    for (int t = 0; t < T; ++t) {
+        RC(cell_step(P, prm, wp, ws, B, 1, zx + (size_t)t * B * 4 * U,
+                     rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
+                     rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
+                     P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
+                     P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
+                     P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, st));
+    }
+    // logits_t = o_t y_W_o for every step at once  (attention_cell.py:84)
+    RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
+          T * B, V, O, nullptr, 0, false, st));
+    return 0;
+}
+
+int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, hipStream_t st) {
+    hipMemsetAsync(P.ws<float>(ws, W_LOSS), 0, 64, st);
+    RC(lxo_k_ce_loss(P.s.dtype, P.ws<float>(ws, W_LOGITS), formula, lengths, P.ws<void>(ws, W_DLOGITS), P.ws<float>(ws, W_LOSS),
+                     inv_ntok, P.s.B, P.s.T, P.s.V, P.Vp, st));
+    return 0;
+}
+
+int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads, hipStream_t st) {
+    const int B = P.s.B, T = P.s.T, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
+    const int TB = T * B;
+    auto gw = [&](int pid) { return grads + P.poff[pid]; };
+    float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
+    float* dolog = P.ws<float>(ws, W_DOLOG); float* gall = P.ws<float>(ws, W_G); float* dhc = P.ws<float>(ws, W_DHC);
+    float* de = P.ws<float>(ws, W_DE); float* datth = P.ws<float>(ws, W_DATTH); float* dz = P.ws<float>(ws, W_DZ);
+    float* dxh = P.ws<float>(ws, W_DXH); float* dcc = P.ws<float>(ws, W_DCC);
+    float* gates = P.ws<float>(ws, W_GATES); float* atth = P.ws<float>(ws, W_ATTH); float* alpha = P.ws<float>(ws, W_ALPHA);
+    const void* dlog = P.ws<void>(ws, W_DLOGITS);
+
+    // d_o (from logits) for every step, and dy_W_o
+    RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
+    RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
+
+    hipMemsetAsync(dxh, 0, (size_t)B * P.XH * 4, st);
+    hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st);
+    for (int t = T - 1; t >= 0; --t) {
+        const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
+        float* g_t = gall + (size_t)t * B * O;
+        float* dhc_t = dhc + (size_t)t * B * P.HC;
+        // g = (d_o_logits + d_o_carry) * (1 - o^2)
+        RC(lxo_k_tanh_bwd(dolog + (size_t)t * B * O, O, dxh, P.XH, rec_cur, P.REC, g_t, O, B, O, st));
+        // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
+        RC(nt(P, true, true, true, g_t, O, P.pk(wp, K_OW), O, dhc_t, P.HC, B, P.HC, O, nullptr, 0, false, st));
+        RC(lxo_k_attn_bwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), atth + (size_t)t * B * E, prm + P.poff[P_BETA],
+                          alpha + (size_t)t * B * P.Rp, dhc_t + U, P.HC, rec_cur + P.XH, P.REC,
+                          de + (size_t)t * B * P.Rp, datth + (size_t)t * B * E, B, P.R, P.Rp, E, C, st));
+        // d_h carry += d_att_h W_att_h^T   (accumulates onto the carry written by the previous iteration)
+        RC(nt(P, true, true, true, datth + (size_t)t * B * E, E, P.pk(wp, K_ATT_H), E, dxh + O, P.XH, B, U, E, nullptr, 0, true, st));
+        RC(lxo_k_lstm_bwd(gates + (size_t)t * B * 4 * U, cs + (size_t)t * B * U, cs + (size_t)(t + 1) * B * U,
+                          dhc_t, P.HC, dxh + O, P.XH, dcc, dz + (size_t)t * B * 4 * U, B, U, st));
+        // [d_o carry | d_h carry] = d_z K[D:]^T
+        RC(nt(P, true, true, true, dz + (size_t)t * B * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
+              dxh, P.XH, B, P.XH, 4 * U, nullptr, 0, false, st));
+    }
+    // ---- deferred weight gradients over all steps ----
+    RC(tn(P, true, true, rec + (size_t)B * P.REC + O, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));       // d[o_W_h; o_W_c]
+    RC(tn(P, true, true, rec + (size_t)B * P.REC + O, P.REC, datth, E, gw(P_ATT_H), E, TB, U, E, st));       // dW_att_h
+    RC(tn(P, false, true, P.ws<void>(ws, W_EMB_IN), P.Dp, dz, 4 * U, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st)); // dK rows 0..D
+    RC(tn(P, true, true, rec, P.REC, dz, 4 * U, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st)); // dK rows D..
+    RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, st));
+    // embeddings
+    float* demb = P.ws<float>(ws, W_DEMB);
+    RC(nt(P, true, true, false, dz, 4 * U, P.pk(wp, K_LSTM), 4 * U, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
+    RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, st));
+    // ---- initial states ----
+    float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
+    const int W3 = 2 * U + O;
+    RC(lxo_k_init_bwd(dcc, dxh, P.XH, cs, rec, P.REC, dpre, B, U, O, st));
+    RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, st));
+    RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, st));
+    RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, st));
+    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, st));
+    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, st));
+    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, st));
+    const char* wi = (const char*)P.pk(wp, K_INIT);
+    RC(nt(P, true, true, true, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, 0, false, st));
+    RC(nt(P, true, true, true, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, 0, true, st));
+    RC(nt(P, true, true, true, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, 0, true, st));
+    // ---- d_img = sum_t alpha_t (x) d_ctx_t  (batched over samples)  + d_mean / R + d_att_img W_att_img^T ----
+    float* dimg = P.ws<float>(ws, W_DIMG);
+    {
+        GemmTN g; memset(&g, 0, sizeof(g));
+        g.A = alpha; g.B = dhc + U; g.C = dimg; g.M = T; g.I = P.R; g.J = C;
+        g.lda = B * P.Rp; g.ldb = B * P.HC; g.ldc = C;
+        g.nsplit = 1; g.nbatch = B; g.strideA = P.Rp; g.strideB = P.HC; g.strideC = (long long)P.R * C; g.atomic = 0;
+        RC(lxo_launch_gemm_tn(P.s.dtype, 1, 1, g, st));
+    }
+    RC(lxo_k_add_mean_grad(dimg, dmean, B, P.R, C, st));
+    RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
+                      T, B, P.R, P.Rp, E, st));
+    RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
+    RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------ decode ----
+static int decode_common_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam, int cur, const int* ids_prev, hipStream_t st) {
+    const int U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V, E = P.s.E;
+    float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
+    float* zx = P.ws<float>(ws, W_DEC_ZX);
+    // next input embedding (start token at time 0), its LSTM x-part, then the cell step
+    RC(lxo_k_embed_rows(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], ids_prev, P.ws<void>(ws, W_DEC_EMB), nv, D, P.Dp, V, st));
+    RC(nt(P, false, true, false, P.ws<void>(ws, W_DEC_EMB), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, nv, 4 * U, P.Dp,
+          prm + P.poff[P_LSTM_B], 0, false, st));
+    const int prev = cur ^ 1;
+    RC(cell_step(P, prm, wp, ws, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
+                 rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U, nullptr,
+                 P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), st));
+    RC(nt(P, true, true, nv <= 64, rec + (size_t)cur * nv * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_DEC_LOGITS), P.Vp,
+          nv, V, O, nullptr, 0, false, st));
+    (void)E;
+    return 0;
+}
+
+int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter,
+                           int* ids_out, int* steps_out, hipStream_t st) {
+    const int B = P.s.B, ms = P.s.max_steps;
+    if (ms < max_iter + 1) return -5;
+    RC(attention_prepare(P, prm, wp, ws, 1, st));
+    int* flags = P.ws<int>(ws, W_DEC_FLAGS);          // [0..63]: per-step unfinished counters ; [64..]: finished[B]
+    int* finished = flags + 64;
+    int* ids_step = P.ws<int>(ws, W_DEC_IDS);
+    hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st);
+    // rec/cs slot 0 holds the initial state; slots alternate
+    int steps = 0;
+    const int CHUNK = 8;                               // host checks "all finished" every CHUNK steps
+    int host_cnt[64];
+    bool done = false;
+    while (!done) {
+        hipMemsetAsync(flags, 0, 64 * sizeof(int), st);
+        int issued = 0;
+        for (int c = 0; c < CHUNK && steps + c <= max_iter; ++c) {
+            const int time = steps + c;
+            const int cur = (time + 1) & 1;
+            RC(decode_common_step(P, prm, wp, ws, B, 1, cur, time == 0 ? nullptr : ids_step, st));
+            RC(lxo_k_argmax(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, id_end, ids_step, ids_out, ms, time, finished, flags + c, st));
+            ++issued;
+        }
+        hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        // dynamic_decode.py:38-51: stop after the first step that leaves nothing unfinished, or after step max_iter
+        for (int c = 0; c < issued; ++c) {
+            ++steps;
+            if (host_cnt[c] == 0 || steps - 1 >= max_iter) { done = true; break; }
+        }
+        if (issued == 0) done = true;
+    }
+    if (steps_out) *steps_out = steps;
+    return 0;
+}
+
+int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter,
+                         int* ids_out, int* parents_out, int* steps_out, hipStream_t st) {
+    const int B = P.s.B, k = P.s.beam, ms = P.s.max_steps, nv = B * k, U = P.s.U;
+    if (ms < max_iter + 1 || k < 1 || k > 16) return -5;
+    RC(attention_prepare(P, prm, wp, ws, k, st));
+    int* flags = P.ws<int>(ws, W_DEC_FLAGS);
+    int* finished = flags + 64;
+    int* ids_step = P.ws<int>(ws, W_DEC_IDS);
+    int* par_step = P.ws<int>(ws, W_BEAM_PAR);
+    float* logp = P.ws<float>(ws, W_BEAM_LP);
+    float* tmp = P.ws<float>(ws, W_BEAM_TMP);
+    hipMemsetAsync(flags, 0, 256 + (size_t)nv * 4, st);
+    hipMemsetAsync(logp, 0, (size_t)nv * 4, st);
+    float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
+    int steps = 0;
+    const int CHUNK = 8;
+    int host_cnt[64];
+    bool done = false;
+    while (!done) {
+        hipMemsetAsync(flags, 0, 64 * sizeof(int), st);
+        int issued = 0;
+        for (int c = 0; c < CHUNK && steps + c <= max_iter; ++c) {
+            const int time = steps + c;
+            const int cur = (time + 1) & 1;
+            RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st));
+            RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, logp, finished, ids_step, par_step,
+                               ids_out, parents_out, ms, flags + c, st));
+            RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
+                                 tmp, tmp + (size_t)nv * P.XH, nv, st));
+            ++issued;
+        }
+        hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st);
+        hipStreamSynchronize(st);
+        for (int c = 0; c < issued; ++c) {
+            ++steps;
+            if (host_cnt[c] == 0 || steps - 1 >= max_iter) { done = true; break; }
+        }
+        if (issued == 0) done = true;
+    }
+    if (steps_out) *steps_out = steps;
+    return 0;
+}

@@ -1,0 +1,147 @@
+// Host orchestration of the encoder: weight packing, forward, backward.
+// Reference graph: model/encoder.py:25-68 (+ positional.py:42-64).
+#include "plan.h"
+#include "gemm.h"
+#include "encoder_kernels.h"
+#include "api_util.h"
+
+// ---------------------------------------------------------------- pack ----
+int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t st) {
+    const int dt = P.s.dtype, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
+    for (int l = 1; l < 6; ++l) {
+        const int ci = P.convCin[l], co = P.convCout[l];
+        const float* w = prm + P.poff[2 * l];
+        RC(lxo_k_pack_transpose(dt, w, P.pk(wp, (PackId)(K_CONV2_F + l - 1)), 9 * ci, co, co, 9 * ci, 0, 9 * ci, st));
+        RC(lxo_k_pack_conv_dgrad(dt, w, P.pk(wp, (PackId)(K_CONV2_D + l - 1)), ci, co, st));
+    }
+    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_ATT_IMG], P.pk(wp, K_ATT_IMG_T), C, E, E, C, 0, C, st));
+    RC(lxo_k_pack_copy(dt, prm + P.poff[P_ATT_IMG], P.pk(wp, K_ATT_IMG), C, E, E, E, E, st));
+    {   // init-state projections, order (c, h, o)
+        const int pid[3] = {P_WC0, P_WH0, P_WO0};
+        const int nout[3] = {U, U, O};
+        size_t offT = 0, offN = 0;
+        for (int i = 0; i < 3; ++i) {
+            RC(lxo_k_pack_transpose(dt, prm + P.poff[pid[i]], (char*)P.pk(wp, K_INIT_T) + offT, C, nout[i], nout[i], C, 0, C, st));
+            RC(lxo_k_pack_copy(dt, prm + P.poff[pid[i]], (char*)P.pk(wp, K_INIT) + offN, C, nout[i], nout[i], nout[i], nout[i], st));
+            offT += (size_t)nout[i] * C * P.esz; offN += (size_t)C * nout[i] * P.esz;
+        }
+    }
+    const float* K = prm + P.poff[P_LSTM_K];
+    RC(lxo_k_pack_transpose(dt, K, P.pk(wp, K_LSTM_XT), D, 4 * U, 4 * U, P.Dp, 0, P.Dp, st));
+    RC(lxo_k_pack_transpose(dt, K + (long long)D * 4 * U, P.pk(wp, K_LSTM_RT), P.XH, 4 * U, 4 * U, P.XH, 0, P.XH, st));
+    RC(lxo_k_pack_copy(dt, K, P.pk(wp, K_LSTM), D + P.XH, 4 * U, 4 * U, 4 * U, 4 * U, st));
+    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_ATT_H], P.pk(wp, K_ATT_H_T), U, E, E, U, 0, U, st));
+    RC(lxo_k_pack_copy(dt, prm + P.poff[P_ATT_H], P.pk(wp, K_ATT_H), U, E, E, E, E, st));
+    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_OWH], P.pk(wp, K_OW_T), U, O, O, P.HC, 0, U, st));
+    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_OWC], P.pk(wp, K_OW_T), C, O, O, P.HC, U, C, st));
+    RC(lxo_k_pack_copy(dt, prm + P.poff[P_OWH], P.pk(wp, K_OW), U, O, O, O, O, st));
+    RC(lxo_k_pack_copy(dt, prm + P.poff[P_OWC], (char*)P.pk(wp, K_OW) + (size_t)U * O * P.esz, C, O, O, O, O, st));
+    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_YWO], P.pk(wp, K_YWO_T), O, V, V, O, 0, O, st));
+    RC(lxo_k_pack_copy(dt, prm + P.poff[P_YWO], P.pk(wp, K_YWO), O, V, V, P.Vp, P.Vp, st));
+    return 0;
+}
+
+// -------------------------------------------------------------- conv ------
+// fwd: out[b,oy,ox,:] = relu(sum in[b,oy+kh-pad,ox+kw-pad,:] * W + bias)
+static int conv_fwd(const Plan& P, const void* in, const void* wpk, const float* bias, void* out,
+                    int H, int W, int Cin, int Cout, bool valid, const float* addend, int addend_rows,
+                    void* out_pre, hipStream_t st) {
+    GemmNT g; memset(&g, 0, sizeof(g));
+    g.A = in; g.Bp = wpk; g.C = out;
+    g.conv = 1; g.H = H; g.W = W; g.Cin = Cin;
+    g.Ho = valid ? H - 2 : H; g.Wo = valid ? W - 2 : W; g.pad = valid ? 0 : 1;
+    g.M = P.s.B * g.Ho * g.Wo; g.N = Cout; g.K = 9 * Cin;
+    g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
+    g.bias = bias; g.act = 1; g.alpha = 1.f;
+    g.addend = addend; g.addend_rows = addend_rows > 0 ? addend_rows : 1; g.out_pre = out_pre;
+    return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
+}
+// dgrad: d_in[b,y,x,ci] = sum d_out[b,y+a-padd,x+b-padd,co] * Wd[ci][(a,b,co)], optional ReLU mask of the
+// producing layer's activation (relu_ref, same shape as d_in) and its bias gradient (colsum)
+static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din, int Hout, int Wout, int Cout,
+                      int Hin, int Win, int Cin, bool valid, const void* relu_ref, float* colsum, hipStream_t st) {
+    GemmNT g; memset(&g, 0, sizeof(g));
+    g.A = dout; g.Bp = wd; g.C = din;
+    g.conv = 1; g.H = Hout; g.W = Wout; g.Cin = Cout;
+    g.Ho = Hin; g.Wo = Win; g.pad = valid ? 2 : 1;
+    g.M = P.s.B * Hin * Win; g.N = Cin; g.K = 9 * Cout;
+    g.lda = Cout; g.ldb = 9 * Cout; g.ldc = Cin;
+    g.act = 0; g.alpha = 1.f; g.addend_rows = 1;
+    g.relu_ref = relu_ref; g.ldr = Cin; g.colsum = colsum;
+    return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
+}
+// wgrad: dW[(kh,kw,ci)][co] += sum_m in[m shifted][ci] * d_out[m][co]
+static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw, int H, int W, int Cin, int Cout,
+                      bool valid, hipStream_t st) {
+    GemmTN g; memset(&g, 0, sizeof(g));
+    g.A = in; g.B = dout; g.C = dw;
+    g.conv = 1; g.H = H; g.W = W; g.Cin = Cin;
+    g.Ho = valid ? H - 2 : H; g.Wo = valid ? W - 2 : W; g.pad = valid ? 0 : 1;
+    g.M = P.s.B * g.Ho * g.Wo; g.I = 9 * Cin; g.J = Cout;
+    g.lda = Cin; g.ldb = Cout; g.ldc = Cout;
+    const int tiles = cdiv(g.I, 128) * cdiv(g.J, 128);
+    int ns = cdiv(1024, tiles);
+    const int maxs = g.M / 256 > 0 ? g.M / 256 : 1;
+    if (ns > maxs) ns = maxs;
+    g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
+    return lxo_launch_gemm_tn(P.s.dtype, 0, 0, g, st);
+}
+
+int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, hipStream_t st) {
+    const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
+    void* p1 = P.ws<void>(ws, W_P1);
+    RC(lxo_k_conv1_pool_fwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], p1, B, P.s.H, P.s.W, st));
+    RC(conv_fwd(P, p1, P.pk(wp, K_CONV2_F), prm + P.poff[P_CONV2_B], P.ws<void>(ws, W_Y2), P.H1, P.W1, 64, 128, false, nullptr, 0, nullptr, st));
+    RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y2), P.ws<void>(ws, W_P2), B, P.H1, P.W1, 128, 2, 2, st));
+    RC(conv_fwd(P, P.ws<void>(ws, W_P2), P.pk(wp, K_CONV3_F), prm + P.poff[P_CONV3_B], P.ws<void>(ws, W_Y3), P.H2, P.W2, 128, 256, false, nullptr, 0, nullptr, st));
+    RC(conv_fwd(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.ws<void>(ws, W_Y4), P.H2, P.W2, 256, 256, false, nullptr, 0, nullptr, st));
+    RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y4), P.ws<void>(ws, W_P4), B, P.H2, P.W2, 256, 2, 1, st));
+    RC(conv_fwd(P, P.ws<void>(ws, W_P4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
+    RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_P5), B, P.H4, P.W2, C, 1, 2, st));
+    RC(lxo_k_timing_signal(P.ws<float>(ws, W_POS), P.Hp, P.Wp, C, st));
+    RC(conv_fwd(P, P.ws<void>(ws, W_P5), P.pk(wp, K_CONV6_F), prm + P.poff[P_CONV6_B], P.ws<void>(ws, W_IMG), P.H4, P.W5, C, C, true,
+                P.ws<float>(ws, W_POS), P.R, P.ws<void>(ws, W_Y6), st));
+    return 0;
+}
+
+// Layers are numbered 1..6.  Layer 6 reads d_img (f32); each layer leaves the gradient of its
+// input in the ping-pong scratch for the next (lower) layer.
+int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, float* grads,
+                         int last_layer, int first_layer, hipStream_t st) {
+    const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
+    void* G0 = P.ws<void>(ws, W_G0); void* G1 = P.ws<void>(ws, W_G1);
+    auto gw = [&](int pid) { return grads + P.poff[pid]; };
+    for (int l = last_layer; l >= first_layer; --l) {
+        switch (l) {
+        case 6:   // d_y6 = d_img * (y6>0) -> G0 ; wgrad6 ; d_p5 = dgrad6 -> G1
+            RC(lxo_k_mask_convert(dt, P.ws<float>(ws, W_DIMG), P.ws<void>(ws, W_Y6), G0, gw(P_CONV6_B), (long long)B * P.R, C, st));
+            RC(conv_wgrad(P, P.ws<void>(ws, W_P5), G0, gw(P_CONV6_W), P.H4, P.W5, C, C, true, st));
+            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV6_D), G1, P.Hp, P.Wp, C, P.H4, P.W5, C, true, nullptr, nullptr, st));
+            break;
+        case 5:   // d_y5 = route(d_p5 in G1) -> G0 ; wgrad5 ; d_p4 = dgrad5 -> G1
+            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), G1, G0, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            RC(conv_wgrad(P, P.ws<void>(ws, W_P4), G0, gw(P_CONV5_W), P.H4, P.W2, 256, C, false, st));
+            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV5_D), G1, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, st));
+            break;
+        case 4:   // d_y4 = route(d_p4 in G1) -> G0 ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> G1 (+ db3)
+            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), G1, G0, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
+            RC(conv_wgrad(P, P.ws<void>(ws, W_Y3), G0, gw(P_CONV4_W), P.H2, P.W2, 256, 256, false, st));
+            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV4_D), G1, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), st));
+            break;
+        case 3:   // d_y3 in G1 ; wgrad3 ; d_p2 = dgrad3 -> G0
+            RC(conv_wgrad(P, P.ws<void>(ws, W_P2), G1, gw(P_CONV3_W), P.H2, P.W2, 128, 256, false, st));
+            RC(conv_dgrad(P, G1, P.pk(wp, K_CONV3_D), G0, P.H2, P.W2, 256, P.H2, P.W2, 128, false, nullptr, nullptr, st));
+            break;
+        case 2:   // d_y2 = route(d_p2 in G0) -> G1 ; wgrad2 ; d_p1 = dgrad2 -> G0
+            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), G0, G1, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            RC(conv_wgrad(P, P.ws<void>(ws, W_P1), G1, gw(P_CONV2_W), P.H1, P.W1, 64, 128, false, st));
+            RC(conv_dgrad(P, G1, P.pk(wp, K_CONV2_D), G0, P.H1, P.W1, 128, P.H1, P.W1, 64, false, nullptr, nullptr, st));
+            break;
+        case 1:   // d_p1 in G0 ; recompute conv1, route through pool+ReLU, dW1, db1
+            RC(lxo_k_conv1_pool_bwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], G0, gw(P_CONV1_W), gw(P_CONV1_B), B, P.s.H, P.s.W, st));
+            break;
+        default: return -4;
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,68 @@
+// Shape-derived plan of the hot path: encoder geometry, offsets of every variable
+// in the flat f32 parameter/gradient buffers (TF variable order of SURVEY.md
+// Appendix B), offsets of the packed compute-dtype weight copies, and the carve-up
+// of the caller-provided workspace.  Pure host arithmetic; no allocation.
+#pragma once
+#include "lxo.h"
+#include "lxo_common.h"
+
+enum ParamId {
+    P_CONV1_W, P_CONV1_B, P_CONV2_W, P_CONV2_B, P_CONV3_W, P_CONV3_B, P_CONV4_W, P_CONV4_B,
+    P_CONV5_W, P_CONV5_B, P_CONV6_W, P_CONV6_B,
+    P_EMB, P_START, P_ATT_IMG, P_WC0, P_BC0, P_WH0, P_BH0, P_WO0, P_BO0,
+    P_LSTM_K, P_LSTM_B, P_ATT_H, P_BETA, P_OWH, P_OWC, P_YWO, P_COUNT
+};
+
+enum PackId {
+    K_CONV2_F, K_CONV3_F, K_CONV4_F, K_CONV5_F, K_CONV6_F,      // [Cout][9*Cin]
+    K_CONV2_D, K_CONV3_D, K_CONV4_D, K_CONV5_D, K_CONV6_D,      // [Cin][9*Cout] flipped
+    K_ATT_IMG_T,   // [E][C]
+    K_ATT_IMG,     // [C][E]
+    K_INIT_T,      // [3][U][C]   (c, h, o) ; o block is [O][C]
+    K_INIT,        // [3][C][U]
+    K_LSTM_XT,     // [4U][Dp]
+    K_LSTM_RT,     // [4U][O+U]
+    K_LSTM,        // [D+O+U][4U]
+    K_ATT_H_T,     // [E][U]
+    K_ATT_H,       // [U][E]
+    K_OW_T,        // [O][U+C]
+    K_OW,          // [U+C][O]
+    K_YWO_T,       // [V][O]
+    K_YWO,         // [O][Vp]
+    K_COUNT
+};
+
+enum WsId {
+    W_P1, W_Y2, W_P2, W_Y3, W_Y4, W_P4, W_Y5, W_P5, W_Y6, W_IMG, W_POS,
+    W_ATT_IMG, W_MEAN, W_EMB_IN, W_ZX, W_REC, W_CS, W_GATES, W_ATTH, W_ALPHA, W_LOGITS,
+    W_DLOGITS, W_LOSS, W_DOLOG, W_G, W_DHC, W_DE, W_DATTH, W_DZ, W_DXH, W_DCC, W_DIMG, W_DATTIMG,
+    W_DEMB, W_DPRE0, W_DMEAN, W_G0, W_G1, W_GNORM,
+    // decode-only
+    W_DEC_IDS, W_DEC_FLAGS, W_DEC_EMB, W_DEC_ZX, W_DEC_LOGITS, W_BEAM_LP, W_BEAM_PAR, W_BEAM_TMP,
+    W_COUNT
+};
+
+struct Plan {
+    lxo_shape s;
+    bool bf;                 // compute dtype is bf16
+    size_t esz;              // bytes per compute-dtype element
+    // encoder geometry
+    int H1, W1, H2, W2, H4, W5, Hp, Wp, R;
+    int convCin[6], convCout[6];
+    int Vp, Dp, Rp, XH, HC, REC;   // padded V / D / R (row pitches), O+U, U+C, O+U+C
+    // flat parameter buffer
+    long long poff[P_COUNT], pcount[P_COUNT], ptotal;
+    // packed weights (bytes)
+    size_t koff[K_COUNT], ktotal;
+    // workspace (bytes)
+    size_t woff[W_COUNT], wbytes[W_COUNT], wtotal;
+
+    explicit Plan(const lxo_shape& sh, int beam = 1);
+    int validate(char* msg, size_t n) const;
+
+    template <class T> T* ws(void* base, WsId id) const { return reinterpret_cast<T*>(static_cast<char*>(base) + woff[id]); }
+    const void* pk(const void* base, PackId id) const { return static_cast<const char*>(base) + koff[id]; }
+    void* pk(void* base, PackId id) const { return static_cast<char*>(base) + koff[id]; }
+};
+
+const char* lxo_param_name(int id);

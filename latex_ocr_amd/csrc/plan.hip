@@ -1,0 +1,160 @@
+// Host-side plan arithmetic (see plan.h).
+#include "plan.h"
+#include <stdio.h>
+#include <string.h>
+
+static const char* kParamNames[P_COUNT] = {
+    "Encoder/convolutional_encoder/conv2d/kernel", "Encoder/convolutional_encoder/conv2d/bias",
+    "Encoder/convolutional_encoder/conv2d_1/kernel", "Encoder/convolutional_encoder/conv2d_1/bias",
+    "Encoder/convolutional_encoder/conv2d_2/kernel", "Encoder/convolutional_encoder/conv2d_2/bias",
+    "Encoder/convolutional_encoder/conv2d_3/kernel", "Encoder/convolutional_encoder/conv2d_3/bias",
+    "Encoder/convolutional_encoder/conv2d_4/kernel", "Encoder/convolutional_encoder/conv2d_4/bias",
+    "Encoder/convolutional_encoder/conv2d_5/kernel", "Encoder/convolutional_encoder/conv2d_5/bias",
+    "Decoder/embedding_table", "Decoder/start_token",
+    "Decoder/AttentionCell/att_img/kernel",
+    "Decoder/AttentionCell/att_mechanism/W_c_0", "Decoder/AttentionCell/att_mechanism/b_c_0",
+    "Decoder/AttentionCell/att_mechanism/W_h_0", "Decoder/AttentionCell/att_mechanism/b_h_0",
+    "Decoder/AttentionCell/att_mechanism/W_o_0", "Decoder/AttentionCell/att_mechanism/b_o_0",
+    "Decoder/AttentionCell/rnn/lstm_cell/kernel", "Decoder/AttentionCell/rnn/lstm_cell/bias",
+    "Decoder/AttentionCell/rnn/att_mechanism/dense/kernel", "Decoder/AttentionCell/rnn/att_mechanism/att_beta",
+    "Decoder/AttentionCell/rnn/o_W_h", "Decoder/AttentionCell/rnn/o_W_c", "Decoder/AttentionCell/rnn/y_W_o",
+};
+const char* lxo_param_name(int id) { return (id >= 0 && id < P_COUNT) ? kParamNames[id] : ""; }
+
+static const char* kWsNames[W_COUNT] = {
+    "p1", "y2", "p2", "y3", "y4", "p4", "y5", "p5", "y6", "img", "pos",
+    "att_img", "mean", "emb_in", "zx", "rec", "cs", "gates", "att_h", "alpha", "logits",
+    "dlogits", "loss", "do_log", "g", "dhc", "de", "datth", "dz", "dxh", "dcc", "d_img", "d_att_img",
+    "d_emb", "dpre0", "dmean", "g0", "g1", "gnorm",
+    "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
+};
+const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
+
+static inline int cd2(int n) { return (n + 1) / 2; }
+static inline size_t al256(size_t n) { return (n + 255) / 256 * 256; }
+
+Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
+    bf = s.dtype == LXO_BF16;
+    esz = bf ? 2 : 4;
+    const int B = s.B, C = s.C, E = s.E, U = s.U, O = s.O, D = s.D, V = s.V, T = s.T > 0 ? s.T : 1;
+    H1 = cd2(s.H); W1 = cd2(s.W);          // after conv1's 2x2 pool      (encoder.py:34)
+    H2 = cd2(H1); W2 = cd2(W1);            // after conv2's 2x2 pool      (encoder.py:39)
+    H4 = cd2(H2);                          // after conv4's (2,1) pool    (encoder.py:47)
+    W5 = cd2(W2);                          // after conv5's (1,2) pool    (encoder.py:52)
+    Hp = H4 - 2; Wp = W5 - 2;              // conv6 VALID                 (encoder.py:59)
+    R = Hp > 0 && Wp > 0 ? Hp * Wp : 0;
+    const int ci[6] = {1, 64, 128, 256, 256, C}, co[6] = {64, 128, 256, 256, C, C};
+    for (int i = 0; i < 6; ++i) { convCin[i] = ci[i]; convCout[i] = co[i]; }
+    Vp = (V + 31) / 32 * 32;
+    Dp = (D + 31) / 32 * 32;
+    Rp = (R + 7) / 8 * 8;
+    XH = O + U; HC = U + C; REC = O + U + C;
+
+    long long cnt[P_COUNT];
+    for (int i = 0; i < 6; ++i) { cnt[2 * i] = 9LL * ci[i] * co[i]; cnt[2 * i + 1] = co[i]; }
+    cnt[P_EMB] = (long long)V * D; cnt[P_START] = D; cnt[P_ATT_IMG] = (long long)C * E;
+    cnt[P_WC0] = (long long)C * U; cnt[P_BC0] = U; cnt[P_WH0] = (long long)C * U; cnt[P_BH0] = U;
+    cnt[P_WO0] = (long long)C * O; cnt[P_BO0] = O;
+    cnt[P_LSTM_K] = (long long)(D + O + U) * 4 * U; cnt[P_LSTM_B] = 4LL * U;
+    cnt[P_ATT_H] = (long long)U * E; cnt[P_BETA] = E;
+    cnt[P_OWH] = (long long)U * O; cnt[P_OWC] = (long long)C * O; cnt[P_YWO] = (long long)O * V;
+    ptotal = 0;
+    for (int i = 0; i < P_COUNT; ++i) { poff[i] = ptotal; pcount[i] = cnt[i]; ptotal += cnt[i]; }
+
+    size_t kb[K_COUNT];
+    for (int l = 1; l < 6; ++l) {
+        kb[K_CONV2_F + l - 1] = (size_t)co[l] * 9 * ci[l] * esz;
+        kb[K_CONV2_D + l - 1] = (size_t)ci[l] * 9 * co[l] * esz;
+    }
+    kb[K_ATT_IMG_T] = (size_t)E * C * esz; kb[K_ATT_IMG] = (size_t)C * E * esz;
+    kb[K_INIT_T] = (size_t)(2 * U + O) * C * esz; kb[K_INIT] = (size_t)C * (2 * U + O) * esz;
+    kb[K_LSTM_XT] = (size_t)4 * U * Dp * esz; kb[K_LSTM_RT] = (size_t)4 * U * XH * esz;
+    kb[K_LSTM] = (size_t)(D + O + U) * 4 * U * esz;
+    kb[K_ATT_H_T] = (size_t)E * U * esz; kb[K_ATT_H] = (size_t)U * E * esz;
+    kb[K_OW_T] = (size_t)O * HC * esz; kb[K_OW] = (size_t)HC * O * esz;
+    kb[K_YWO_T] = (size_t)V * O * esz; kb[K_YWO] = (size_t)O * Vp * esz;
+    ktotal = 0;
+    for (int i = 0; i < K_COUNT; ++i) { koff[i] = ktotal; ktotal += al256(kb[i] + 64); }
+
+    const size_t f4 = 4;
+    size_t wb[W_COUNT];
+    memset(wb, 0, sizeof(wb));
+    const size_t BL = (size_t)B;
+    wb[W_P1] = BL * H1 * W1 * 64 * esz;
+    wb[W_Y2] = BL * H1 * W1 * 128 * esz;  wb[W_P2] = BL * H2 * W2 * 128 * esz;
+    wb[W_Y3] = BL * H2 * W2 * 256 * esz;  wb[W_Y4] = BL * H2 * W2 * 256 * esz;
+    wb[W_P4] = BL * H4 * W2 * 256 * esz;
+    wb[W_Y5] = BL * H4 * W2 * C * esz;    wb[W_P5] = BL * H4 * W5 * C * esz;
+    wb[W_Y6] = BL * R * C * esz;          wb[W_IMG] = BL * R * C * esz;
+    wb[W_POS] = (size_t)R * C * f4;
+    const int nb = s.beam > 1 ? s.beam : 1;
+    const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)
+    const size_t TB = (size_t)T * B;
+    wb[W_ATT_IMG] = BL * R * E * esz;
+    wb[W_MEAN] = BL * C * f4;
+    wb[W_EMB_IN] = TB * Dp * esz;
+    wb[W_ZX] = TB * 4 * U * f4;
+    wb[W_REC] = (size_t)(T + 1) * B * REC * f4;
+    wb[W_CS] = (size_t)(T + 1) * B * U * f4;
+    wb[W_GATES] = TB * 4 * U * f4;
+    wb[W_ATTH] = TB * E * f4;
+    wb[W_ALPHA] = TB * Rp * f4;
+    wb[W_LOGITS] = TB * Vp * f4;
+    wb[W_DLOGITS] = TB * Vp * esz;
+    wb[W_LOSS] = 64;
+    wb[W_DOLOG] = TB * O * f4;
+    wb[W_G] = TB * O * f4;
+    wb[W_DHC] = TB * HC * f4;
+    wb[W_DE] = TB * Rp * f4;
+    wb[W_DATTH] = TB * E * f4;
+    wb[W_DZ] = TB * 4 * U * f4;
+    wb[W_DXH] = BL * XH * f4;
+    wb[W_DCC] = BL * U * f4;
+    wb[W_DIMG] = BL * R * C * f4;
+    wb[W_DATTIMG] = BL * R * E * esz;
+    wb[W_DEMB] = TB * D * f4;
+    wb[W_DPRE0] = BL * (2 * U + O) * f4;
+    wb[W_DMEAN] = BL * C * f4;
+    // encoder-backward ping-pong scratch: the largest activation gradient is d_y2
+    size_t gmax = wb[W_Y2];
+    const size_t cand[] = {wb[W_P1], wb[W_P2], wb[W_Y3], wb[W_Y4], wb[W_P4], wb[W_Y5], wb[W_P5], wb[W_Y6]};
+    for (size_t c : cand) if (c > gmax) gmax = c;
+    wb[W_G0] = gmax; wb[W_G1] = gmax;
+    wb[W_GNORM] = 64;
+    const int ms = s.max_steps > 0 ? s.max_steps : 0;
+    if (ms > 0) {
+        wb[W_DEC_IDS] = BK_ * ms * 4;
+        wb[W_DEC_FLAGS] = 256 + BK_ * 4;
+        wb[W_DEC_EMB] = BK_ * Dp * esz;
+        wb[W_DEC_ZX] = BK_ * 4 * U * f4;
+        wb[W_DEC_LOGITS] = BK_ * Vp * f4;
+        wb[W_BEAM_LP] = BK_ * 2 * f4;
+        wb[W_BEAM_PAR] = BK_ * ms * 4;
+        wb[W_BEAM_TMP] = 3 * (BK_ * REC + BK_ * U) * f4 / 3 + BK_ * 64;
+        // decode reuses rec / cs / att_h / alpha with (T = 2 ping-pong) rows per beam
+        const size_t recd = 2 * BK_ * REC * f4, csd = 2 * BK_ * U * f4;
+        if (wb[W_REC] < recd) wb[W_REC] = recd;
+        if (wb[W_CS] < csd) wb[W_CS] = csd;
+        if (wb[W_GATES] < BK_ * 4 * U * f4) wb[W_GATES] = BK_ * 4 * U * f4;
+        if (wb[W_ATTH] < BK_ * E * f4) wb[W_ATTH] = BK_ * E * f4;
+        if (wb[W_ALPHA] < BK_ * Rp * f4) wb[W_ALPHA] = BK_ * Rp * f4;
+        if (wb[W_ZX] < BK_ * 4 * U * f4) wb[W_ZX] = BK_ * 4 * U * f4;
+    }
+    wtotal = 0;
+    for (int i = 0; i < W_COUNT; ++i) { wbytes[i] = wb[i]; woff[i] = wtotal; wtotal += al256(wb[i] + 256); }
+}
+
+int Plan::validate(char* msg, size_t n) const {
+#define BAD(cond, text) if (cond) { snprintf(msg, n, "lxo_shape invalid: %s", text); return -10; }
+    BAD(s.B <= 0 || s.H <= 0 || s.W <= 0, "B/H/W must be positive");
+    BAD(Hp <= 0 || Wp <= 0, "image too small: need ceil(H/8) >= 3 and ceil(W/8) >= 3");
+    BAD(s.V < 4, "V < 4");
+    BAD(s.C != 512 && s.C != 256 && s.C != 128 && s.C != 64, "C must be 64/128/256/512");
+    BAD(s.E % 64 || s.U % 64 || s.O % 64 || s.E <= 0 || s.U <= 0 || s.O <= 0, "E, U, O must be positive multiples of 64");
+    BAD(s.D % 8 || s.D <= 0, "D must be a positive multiple of 8");
+    BAD(s.dtype != LXO_F32 && s.dtype != LXO_BF16, "dtype");
+    BAD(s.E > 1024 || s.C > 512, "E <= 1024, C <= 512");
+    BAD(R > 10240, "more than 10240 regions");
+#undef BAD
+    return 0;
+}
