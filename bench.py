@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""Headline benchmark: formula-images/sec of one full training step (encoder + attention
+decoder forward, loss, BPTT, Adam, weight re-pack [+ gradient all-reduce]) on synthetic
+128x512 crops, batch 64 per GPU, vocab 500, bf16 storage / f32 accumulate
+(BASELINE.json configs[2]; metric quoted at 1/2/4/8 MI355X, weak scaling).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GF_TRAIN_PER_IMG = 55.925e9      # conv fwd+dgrad+wgrad FLOPs per 128x512 image
+MFMA_BF16_PEAK = 2.5e15          # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def conv_layers(B, H, W, C=512):
+    """(name, M, N, K) of the implicit GEMMs of conv2..conv6 forward at this input size."""
+    c = lambda n: -(-n // 2)
+    H1, W1 = c(H), c(W); H2, W2 = c(H1), c(W1); H4 = c(H2); W5 = c(W2)
+    return [("conv2", B * H1 * W1, 128, 9 * 64), ("conv3", B * H2 * W2, 256, 9 * 128), ("conv4", B * H2 * W2, 256, 9 * 256),
+            ("conv5", B * H4 * W2, C, 9 * 256), ("conv6", B * (H4 - 2) * (W5 - 2), C, 9 * C)]
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle restatement of the reference trainer (kind "port": TF-1.12 cannot run here),
+    timed on the host cores on a bounded sample of the same workload: batch 2 of 128x512,
+    vocab 500, formula lengths U{30..100}."""
+    import torch
+    from latex_ocr_amd import synthetic
+    from latex_ocr_amd.model.utils.image import pad_batch_images
+    from latex_ocr_amd.model.utils.text import pad_batch_formulas
+    from oracle import ref_model as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    V, B = 500, 2
+    imgs, forms = synthetic.make_set(B, 128, 512, V, 30, 101, seed=99)
+    img = torch.from_numpy(pad_batch_images(imgs))
+    f, l = pad_batch_formulas(forms, V - 2, V - 1)
+    f, l = torch.from_numpy(f), torch.from_numpy(l)
+    P = R.init_params(V, 0)
+    opt = R.AdamTF(P)
+    R.train_step(P, opt, img, f, l, 1e-4)          # warm-up
+    t0 = time.time(); n = 0
+    while True:
+        R.train_step(P, opt, img, f, l, 1e-4); n += 1
+        if time.time() - t0 > seconds_budget or n >= 20:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ref_model.py train_step (torch-CPU f32), %d steps of batch %d, 128x512, V=500, T=%d"
+                      % (n, B, f.shape[1])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--vocab", type=int, default=500)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        from latex_ocr_amd.dist import DataParallel
+        dist = DataParallel(device=dev)
+
+    from latex_ocr_amd import synthetic
+    from latex_ocr_amd.engine import Engine
+    from latex_ocr_amd.model.utils.image import pad_batch_images
+    from latex_ocr_amd.model.utils.text import pad_batch_formulas
+
+    B, H, W, V = args.batch, args.height, args.width, args.vocab
+    imgs, forms = synthetic.make_set(B, H, W, V, 30, 101, seed=1234 + rank)
+    img = torch.from_numpy(pad_batch_images(imgs)).to(dev)
+    f, l = pad_batch_formulas(forms, V - 2, V - 1)
+    f_d = torch.from_numpy(f).to(dev)
+    T = int(f.shape[1])
+    eng = Engine(V, dtype=args.dtype, device=dev, seed=0)
+
+    def step():
+        return eng.train_step(img, f_d, l, 1e-3, dist=dist, sync_loss=False)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce_max(tt)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    value = B * world / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel family: the implicit-GEMM conv (MFMA bound) ----
+        roof = eng.time_conv_gemms(img) if hasattr(eng, "time_conv_gemms") else None
+        out = {
+            "metric": "formula-images/sec training step (batch 64, 128x512)", "value": round(value, 2), "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[2]: full encoder+attention+decoder training step, batch %d/GPU, %dx%d, vocab %d, "
+                                   "T=%d (lengths U{30..100}), Adam" % (B, H, W, V, T),
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "conv_roofline_fraction_e2e": round(GF_TRAIN_PER_IMG * (H * W / (128.0 * 512.0)) * value / world / MFMA_BF16_PEAK, 4),
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

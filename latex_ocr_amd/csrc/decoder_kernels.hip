@@ -2,6 +2,7 @@
 // attention stream (attention_mechanism.py:46-94): scores, softmax over the R regions
 // and the context sum in ONE launch, att_img and img each read exactly once.
 #include "decoder_kernels.h"
+#include "api_util.h"
 
 namespace {
 
@@ -729,7 +730,7 @@ int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k
     DONE;
 }
 int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sumsq_tmp, float* out, hipStream_t st) {
-    hipMemsetAsync(sumsq_tmp, 0, sizeof(float), st);
+    HIPRC(hipMemsetAsync(sumsq_tmp, 0, sizeof(float), st));
     LAUNCH(sumsq_kernel, grid1(n, 256 * 8, 1024), g, n, sumsq_tmp);
     hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq_tmp, clip, out);
     DONE;

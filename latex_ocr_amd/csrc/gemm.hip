@@ -425,5 +425,5 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
     if (!a_f32 && !b_f32) return launch_tn<bf16_t, false, bf16_t, bf16_t>(p, s);
     if (a_f32 && !b_f32) return launch_tn<bf16_t, false, float, bf16_t>(p, s);
     if (a_f32 && b_f32) return launch_tn<bf16_t, false, float, float>(p, s);
-    return -3;
+    return launch_tn<bf16_t, false, bf16_t, float>(p, s);
 }

@@ -102,7 +102,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
 }
 
 int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, hipStream_t st) {
-    hipMemsetAsync(P.ws<float>(ws, W_LOSS), 0, 64, st);
+    HIPRC(hipMemsetAsync(P.ws<float>(ws, W_LOSS), 0, 64, st));
     RC(lxo_k_ce_loss(P.s.dtype, P.ws<float>(ws, W_LOGITS), formula, lengths, P.ws<void>(ws, W_DLOGITS), P.ws<float>(ws, W_LOSS),
                      inv_ntok, P.s.B, P.s.T, P.s.V, P.Vp, st));
     return 0;
@@ -123,8 +123,8 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
     RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
 
-    hipMemsetAsync(dxh, 0, (size_t)B * P.XH * 4, st);
-    hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st);
+    HIPRC(hipMemsetAsync(dxh, 0, (size_t)B * P.XH * 4, st));
+    HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
     for (int t = T - 1; t >= 0; --t) {
         const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
         float* g_t = gall + (size_t)t * B * O;
@@ -212,14 +212,14 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
     int* flags = P.ws<int>(ws, W_DEC_FLAGS);          // [0..63]: per-step unfinished counters ; [64..]: finished[B]
     int* finished = flags + 64;
     int* ids_step = P.ws<int>(ws, W_DEC_IDS);
-    hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st);
+    HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st));
     // rec/cs slot 0 holds the initial state; slots alternate
     int steps = 0;
     const int CHUNK = 8;                               // host checks "all finished" every CHUNK steps
     int host_cnt[64];
     bool done = false;
     while (!done) {
-        hipMemsetAsync(flags, 0, 64 * sizeof(int), st);
+        HIPRC(hipMemsetAsync(flags, 0, 64 * sizeof(int), st));
         int issued = 0;
         for (int c = 0; c < CHUNK && steps + c <= max_iter; ++c) {
             const int time = steps + c;
@@ -228,8 +228,8 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
             RC(lxo_k_argmax(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, id_end, ids_step, ids_out, ms, time, finished, flags + c, st));
             ++issued;
         }
-        hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st);
-        hipStreamSynchronize(st);
+        HIPRC(hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPRC(hipStreamSynchronize(st));
         // dynamic_decode.py:38-51: stop after the first step that leaves nothing unfinished, or after step max_iter
         for (int c = 0; c < issued; ++c) {
             ++steps;
@@ -252,15 +252,15 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
     int* par_step = P.ws<int>(ws, W_BEAM_PAR);
     float* logp = P.ws<float>(ws, W_BEAM_LP);
     float* tmp = P.ws<float>(ws, W_BEAM_TMP);
-    hipMemsetAsync(flags, 0, 256 + (size_t)nv * 4, st);
-    hipMemsetAsync(logp, 0, (size_t)nv * 4, st);
+    HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)nv * 4, st));
+    HIPRC(hipMemsetAsync(logp, 0, (size_t)nv * 4, st));
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     int steps = 0;
     const int CHUNK = 8;
     int host_cnt[64];
     bool done = false;
     while (!done) {
-        hipMemsetAsync(flags, 0, 64 * sizeof(int), st);
+        HIPRC(hipMemsetAsync(flags, 0, 64 * sizeof(int), st));
         int issued = 0;
         for (int c = 0; c < CHUNK && steps + c <= max_iter; ++c) {
             const int time = steps + c;
@@ -272,8 +272,8 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
                                  tmp, tmp + (size_t)nv * P.XH, nv, st));
             ++issued;
         }
-        hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st);
-        hipStreamSynchronize(st);
+        HIPRC(hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPRC(hipStreamSynchronize(st));
         for (int c = 0; c < issued; ++c) {
             ++steps;
             if (host_cnt[c] == 0 || steps - 1 >= max_iter) { done = true; break; }

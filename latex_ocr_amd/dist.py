@@ -1,0 +1,55 @@
+"""Data-parallel plumbing over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm;
+"gloo" for the CPU tests).  One process per GPU; samples are independent through encoder,
+decoder and loss, so the only exchanges are (1) the global token count that normalises the
+loss (model/img2seq.py:69-71 takes the mean over ALL unmasked tokens of the batch) and (2)
+the gradient sum.  Gradients are all-reduced in three buckets on a side HIP stream as soon
+as backward has finalised them (decoder first, then conv6-5, then conv4-1), overlapping the
+remaining encoder backward; Adam is replicated.
+"""
+import torch
+import torch.distributed as td
+
+
+class DataParallel(object):
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        self.world = td.get_world_size()
+        self.rank = td.get_rank()
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(self.device) if self.cuda else None
+        self._pending = False
+
+    def sum_scalar(self, x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return float(t.item())
+
+    def all_reduce(self, t):
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+
+    def all_reduce_max(self, t):
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+
+    def barrier(self):
+        td.barrier()
+
+    def reduce_range_fn(self, flat):
+        """-> comm(lo, hi): sum flat[lo:hi] over ranks, asynchronously w.r.t. the compute stream."""
+        def comm(lo, hi):
+            seg = flat[lo:hi]
+            if not self.cuda:
+                td.all_reduce(seg, op=td.ReduceOp.SUM)
+                return
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                td.all_reduce(seg, op=td.ReduceOp.SUM)
+            self._pending = True
+        return comm
+
+    def finish(self):
+        """Make the compute stream wait for every bucket before the optimizer reads the gradients."""
+        if self.cuda and self._pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._pending = False

@@ -1,0 +1,252 @@
+"""Device-side engine: owns the flat parameter / gradient / Adam buffers, the packed
+compute-dtype weights and the workspace (all torch CUDA tensors -- PyTorch is the
+allocator and stream provider only) and drives the C ABI of liblxo.so.
+
+Every numeric operation happens inside liblxo.so (hand-written gfx950 kernels);
+there is no eager/PyTorch compute path and no CPU fallback here.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _abi
+from .model import params as PP
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Engine(object):
+    def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None):
+        self.lib = lib if lib is not None else _abi.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda" and lib is None:
+            raise RuntimeError("latex_ocr_amd.Engine needs a CUDA/HIP device (no CPU fallback)")
+        self.dims = dict(PP.DEFAULT_DIMS, **(dims or {}))
+        self.n_tok = int(n_tok)
+        self.dtype = _abi.LXO_BF16 if dtype in ("bf16", 1) else _abi.LXO_F32
+        self.beam, self.max_steps = int(beam), int(max_steps)
+        self.specs = PP.param_specs(self.n_tok, self.dims)
+        self.n_params = PP.n_params(self.n_tok, self.dims)
+        probe = self._shape(1, 32, 32, 1)
+        assert self.lib.lxo_param_total(ctypes.byref(probe)) == self.n_params
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.n_params, **f32)
+        self.grads = torch.zeros(self.n_params, **f32)
+        self.adam_m = torch.zeros(self.n_params, **f32)
+        self.adam_v = torch.zeros(self.n_params, **f32)
+        self.adam_t = 0
+        self.scale = torch.zeros(4, **f32)
+        self.wpack = torch.zeros(self.lib.lxo_wpack_bytes(ctypes.byref(probe)) + 256, dtype=torch.uint8, device=self.device)
+        self.ws = None
+        self.ws_key = None
+        self.shape = None
+        self._offsets = OrderedDict()
+        off = 0
+        for name, shp, _ in self.specs:
+            n = int(np.prod(shp))
+            self._offsets[name] = (off, n, shp)
+            off += n
+        # gradient buckets for data-parallel all-reduce, in the order backward finishes them
+        first_dec = self._offsets["Decoder/embedding_table"][0]
+        c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]
+        self.buckets = [(first_dec, self.n_params), (c5, first_dec), (0, c5)]
+        self.load_params(PP.init_params(self.n_tok, seed, self.dims))
+
+    # ------------------------------------------------------------ plumbing --
+    def _shape(self, B, H, W, T):
+        d = self.dims
+        return _abi.LxoShape(B, H, W, T, self.n_tok, d["C"], d["E"], d["U"], d["O"], d["D"], self.dtype,
+                             self.beam, self.max_steps)
+
+    def _stream(self):
+        if self.device.type == "cuda":
+            return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return ctypes.c_void_p(0)
+
+    def _ck(self, rc, what):
+        _abi.check(self.lib, rc, what)
+
+    def ensure(self, B, H, W, T):
+        """Bind a call shape; grow the workspace when a larger batch arrives."""
+        shape = self._shape(B, H, W, T)
+        need = self.lib.lxo_workspace_bytes(ctypes.byref(shape)) + 256
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = None
+            self.ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        self.shape = shape
+        return shape
+
+    def sref(self):
+        return ctypes.byref(self.shape)
+
+    def region(self, name, kind="f32", shape=None):
+        """View of a named workspace region as a torch tensor (float32, int32 or compute dtype)."""
+        off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+        self._ck(self.lib.lxo_ws_region(self.sref(), name.encode(), ctypes.byref(off), ctypes.byref(nb)), "ws_region")
+        raw = self.ws[off.value:off.value + nb.value]
+        if kind == "ct":
+            t = raw.view(torch.bfloat16) if self.dtype == _abi.LXO_BF16 else raw.view(torch.float32)
+        elif kind == "i32":
+            t = raw.view(torch.int32)
+        else:
+            t = raw.view(torch.float32)
+        if shape is not None:
+            t = t[:int(np.prod(shape))].view(*shape)
+        return t
+
+    # ------------------------------------------------------------- params --
+    def load_params(self, P):
+        flat = np.concatenate([np.asarray(P[k], dtype=np.float32).reshape(-1) for k, _, _ in self.specs])
+        self.params.copy_(torch.from_numpy(flat))
+        self.pack()
+
+    def get_params(self):
+        flat = self.params.detach().cpu().numpy()
+        return OrderedDict((k, flat[o:o + n].reshape(s).copy()) for k, (o, n, s) in self._offsets.items())
+
+    def grad_dict(self):
+        flat = self.grads.detach().cpu().numpy()
+        return OrderedDict((k, flat[o:o + n].reshape(s).copy()) for k, (o, n, s) in self._offsets.items())
+
+    def pack(self):
+        shape = self.shape if self.shape is not None else self._shape(1, 32, 32, 1)
+        self._ck(self.lib.lxo_pack_weights(ctypes.byref(shape), _p(self.params), _p(self.wpack), self._stream()), "pack_weights")
+
+    def state_dict(self):
+        return {"params": self.get_params(), "adam_m": self.adam_m.cpu().numpy(), "adam_v": self.adam_v.cpu().numpy(),
+                "adam_t": self.adam_t}
+
+    def load_state_dict(self, sd):
+        self.load_params(sd["params"])
+        if "adam_m" in sd:
+            self.adam_m.copy_(torch.from_numpy(np.asarray(sd["adam_m"], np.float32)))
+            self.adam_v.copy_(torch.from_numpy(np.asarray(sd["adam_v"], np.float32)))
+            self.adam_t = int(sd.get("adam_t", 0))
+
+    # -------------------------------------------------------------- inputs --
+    def _to_dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+
+    # ---------------------------------------------------------------- steps --
+    def forward(self, img, formula):
+        """Encoder + teacher-forced decoder; leaves logits in the workspace."""
+        B, H, W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+        T = int(formula.shape[1])
+        self.ensure(B, H, W, T)
+        self._img = self._to_dev(img, torch.uint8)
+        self._formula = self._to_dev(formula, torch.int32)
+        st = self._stream()
+        self._ck(self.lib.lxo_encoder_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), st), "encoder_fwd")
+        self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
+                 "decoder_train_fwd")
+
+    def loss(self, lengths, inv_ntok):
+        self._lengths = self._to_dev(lengths, torch.int32)
+        self._ck(self.lib.lxo_ce_loss_fwd_bwd(self.sref(), _p(self.ws), _p(self._formula), _p(self._lengths),
+                                              ctypes.c_float(inv_ntok), self._stream()), "ce_loss")
+        return self.region("loss")[:2]
+
+    def backward(self, comm=None):
+        """BPTT + encoder backward into self.grads (zeroed first).  `comm(lo, hi)` is called as soon
+        as the gradient range [lo, hi) is final (data-parallel bucket all-reduce hook)."""
+        st = self._stream()
+        self.grads.zero_()
+        self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                _p(self.grads), st), "decoder_train_bwd")
+        if comm:
+            comm(*self.buckets[0])
+        self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
+                                          6, 5, st), "encoder_bwd")
+        if comm:
+            comm(*self.buckets[1])
+        self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
+                                          4, 1, st), "encoder_bwd")
+        if comm:
+            comm(*self.buckets[2])
+
+    def optimizer_step(self, lr, clip=-1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        st = self._stream()
+        self.adam_t += 1
+        lr_t = float(lr) * math.sqrt(1.0 - beta2 ** self.adam_t) / (1.0 - beta1 ** self.adam_t)
+        scale = None
+        if clip is not None and clip > 0:
+            self._ck(self.lib.lxo_global_norm_scale(self.n_params, _p(self.grads), ctypes.c_float(clip), _p(self.scale), st), "clip")
+            scale = self.scale
+        self._ck(self.lib.lxo_adam_step(self.n_params, _p(self.params), _p(self.grads), _p(self.adam_m), _p(self.adam_v),
+                                        ctypes.c_float(lr_t), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
+                                        _p(scale), st), "adam")
+        self.pack()
+
+    def train_step(self, img, formula, lengths, lr, clip=-1.0, dist=None, sync_loss=True):
+        """One optimisation step of img2seq.py:_run_train's body.  Returns the batch loss
+        (token mean over the global batch) or None when sync_loss is False."""
+        self.forward(img, formula)
+        n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
+        n_global = dist.sum_scalar(n_local) if dist is not None else n_local
+        stats = self.loss(lengths, 1.0 / float(n_global))
+        self.backward(comm=dist.reduce_range_fn(self.grads) if dist is not None else None)
+        if dist is not None:
+            dist.finish()
+        self.optimizer_step(lr, clip)
+        if not sync_loss:
+            return None
+        if dist is not None:
+            s = stats.clone()
+            dist.all_reduce(s)
+            s = s.cpu().numpy()
+        else:
+            s = stats.cpu().numpy()
+        return float(s[0]) / float(s[1])
+
+    def evaluate_batch(self, img, formula, lengths):
+        """(sum CE, n_words) of img2seq.py:74-75 for one batch (teacher forced)."""
+        self.forward(img, formula)
+        n = int(np.asarray(lengths).sum())
+        s = self.loss(lengths, 1.0 / max(n, 1)).cpu().numpy()
+        return float(s[0]), n
+
+    # --------------------------------------------------------------- decode --
+    def _encode_only(self, img, beam):
+        B, H, W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+        if beam != self.beam:
+            self.beam, self.ws = beam, None
+        if self.max_steps <= 0:
+            self.max_steps, self.ws = 152, None
+        self.ensure(B, H, W, 1)
+        self._img = self._to_dev(img, torch.uint8)
+        self._ck(self.lib.lxo_encoder_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), self._stream()),
+                 "encoder_fwd")
+        return B
+
+    def greedy_decode(self, img, id_end, max_iter=151):
+        """ids int32 [B, T'] as pred_test.ids of the greedy graph (decoder.py:64,70)."""
+        if self.max_steps < max_iter + 1:
+            self.max_steps, self.ws = max_iter + 1, None
+        B = self._encode_only(img, 1)
+        ids = torch.zeros(B, self.max_steps, dtype=torch.int32, device=self.device)
+        steps = ctypes.c_int(0)
+        self._ck(self.lib.lxo_greedy_decode(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(max_iter),
+                                            _p(ids), ctypes.byref(steps), self._stream()), "greedy_decode")
+        return ids[:, :steps.value].cpu().numpy()
+
+    def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False):
+        """ids int32 [B, T', k] as pred_test.ids of the beam graph before the transpose at img2seq.py:241."""
+        if self.max_steps < max_iter + 1:
+            self.max_steps, self.ws = max_iter + 1, None
+        B = self._encode_only(img, int(beam_size))
+        ids = torch.zeros(B, self.max_steps, beam_size, dtype=torch.int32, device=self.device)
+        par = torch.zeros(B, self.max_steps, beam_size, dtype=torch.int32, device=self.device)
+        steps = ctypes.c_int(0)
+        self._ck(self.lib.lxo_beam_decode(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(max_iter),
+                                          _p(ids), _p(par), ctypes.byref(steps), self._stream()), "beam_decode")
+        out = ids[:, :steps.value].cpu().numpy()
+        if return_parents:
+            return out, par[:, :steps.value].cpu().numpy()
+        return out

@@ -1,0 +1,86 @@
+"""-m gpu: the MFMA GEMM families on real gfx950 against float64 NumPy.  These pin the
+MFMA lane layouts that the CPU-side hipsim interpreter only assumes."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from latex_ocr_amd import _abi
+    return _abi.load()
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _bf(a):
+    return torch.from_numpy(a).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dt,a_f32,c_f32,small,M,N,K,act", [
+    (0, 1, 1, 0, 300, 200, 96, 1), (0, 1, 1, 1, 64, 160, 128, 2),
+    (1, 0, 0, 0, 257, 130, 160, 1), (1, 0, 1, 0, 129, 96, 64, 0),
+    (1, 1, 1, 0, 200, 500, 512, 0), (1, 1, 1, 1, 64, 2048, 1024, 2),
+])
+def test_gemm_nt(dt, a_f32, c_f32, small, M, N, K, act):
+    L = _lib()
+    rng = np.random.default_rng(M + N + K)
+    # asymmetric data: a transposed / permuted fragment cannot pass
+    A = (rng.standard_normal((M, K)) + np.arange(K)[None, :] * 0.01).astype(np.float32)
+    B = (rng.standard_normal((N, K)) + np.arange(N)[:, None] * 0.003).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    if dt == 1:
+        Bd = _bf(B).cuda(); Bref = Bd.float().cpu().numpy()
+        if a_f32:
+            Ad = _dev(A); Aref = _bf(A).float().numpy()
+        else:
+            Ad = _bf(A).cuda(); Aref = Ad.float().cpu().numpy()
+    else:
+        Ad, Bd, Aref, Bref = _dev(A), _dev(B), A, B
+    out_f32 = dt == 0 or c_f32
+    C = torch.zeros(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.lxo_gemm_nt(dt, a_f32, c_f32, small, _p(Ad), _p(Bd), _p(C), M, N, K, K, K, N, _p(_dev(bias)), act,
+                       ctypes.c_float(0.25), 0, st)
+    assert rc == 0, L.lxo_last_error()
+    torch.cuda.synchronize()
+    ref = 0.25 * (Aref.astype(np.float64) @ Bref.astype(np.float64).T) + bias
+    ref = np.maximum(ref, 0) if act == 1 else (np.tanh(ref) if act == 2 else ref)
+    err = np.abs(C.float().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+    tol = 2e-5 if out_f32 else 8e-3
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("dt,a_f32,b_f32,M,I,J,nsplit", [
+    (0, 1, 1, 500, 136, 200, 3), (1, 0, 0, 1000, 576, 128, 4), (1, 1, 0, 333, 512, 504, 2),
+    (1, 1, 1, 64, 1024, 2048, 1), (1, 0, 1, 640, 96, 2048, 2),
+])
+def test_gemm_tn(dt, a_f32, b_f32, M, I, J, nsplit):
+    L = _lib()
+    rng = np.random.default_rng(M + I + J)
+    A = (rng.standard_normal((M, I)) + np.arange(I)[None, :] * 0.002).astype(np.float32)
+    B = (rng.standard_normal((M, J)) + np.arange(M)[:, None] * 0.001).astype(np.float32)
+    if dt == 1:
+        Ad = _dev(A) if a_f32 else _bf(A).cuda()
+        Bd = _dev(B) if b_f32 else _bf(B).cuda()
+        Aref, Bref = _bf(A).float().numpy(), _bf(B).float().numpy()
+    else:
+        Ad, Bd, Aref, Bref = _dev(A), _dev(B), A, B
+    C0 = rng.standard_normal((I, J)).astype(np.float32)
+    C = _dev(C0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.lxo_gemm_tn(dt, a_f32, b_f32, _p(Ad), _p(Bd), _p(C), M, I, J, I, J, J, nsplit, 1, st)
+    assert rc == 0, L.lxo_last_error()
+    torch.cuda.synchronize()
+    ref = C0 + Aref.astype(np.float64).T @ Bref.astype(np.float64)
+    err = np.abs(C.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
