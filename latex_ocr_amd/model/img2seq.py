@@ -1,0 +1,140 @@
+"""Img2SeqModel: the reference's model facade over the MI355X-native engine.
+
+Mirrors `model/img2seq.py` of the reference method by method (cited); the single
+`sess.run` boundary (:169, :236, :263) becomes calls into liblxo.so through
+`latex_ocr_amd.engine.Engine`.  Inputs are the reference's: lists of variable-shape
+uint8 [H,W,1] arrays and lists of int lists; the facade owns padding.
+"""
+import numpy as np
+
+from .base import BaseModel
+from .evaluation.text import score_files, truncate_end, write_answers
+from .params import dims_from_config
+from .utils.general import Config, Progbar, minibatches
+from .utils.image import pad_batch_images
+from .utils.text import pad_batch_formulas
+
+
+class Img2SeqModel(BaseModel):
+    def __init__(self, config, dir_output, vocab):
+        """Reference: model/img2seq.py:23-32."""
+        super(Img2SeqModel, self).__init__(config, dir_output)
+        self._vocab = vocab
+
+    # ------------------------------------------------------------------ build --
+    def _build_engine(self):
+        from ..engine import Engine
+        cfg = self._config
+        if getattr(cfg, "encoder_cnn", "vanilla") != "vanilla":
+            raise NotImplementedError("encoder_cnn=%r: only the 'vanilla' encoder (encoder.py:46-52) is built" % cfg.encoder_cnn)
+        if not getattr(cfg, "positional_embeddings", True):
+            raise NotImplementedError("positional_embeddings=false is not built")
+        self.engine = Engine(self._vocab.n_tok, dims=dims_from_config(cfg),
+                             dtype=getattr(cfg, "compute_dtype", "bf16"),
+                             device=getattr(cfg, "device", "cuda:0") if str(getattr(cfg, "device", "")).startswith("cuda") else "cuda:0",
+                             seed=getattr(cfg, "seed", 0),
+                             beam=getattr(cfg, "beam_size", 1) if getattr(cfg, "decoding", "greedy") == "beam_search" else 1,
+                             max_steps=getattr(cfg, "max_length_formula", 150) + 2)
+
+    def build_train(self, config):
+        """Reference: model/img2seq.py:34-40."""
+        self.logger.info("Building model...")
+        self._build_engine()
+        self._lr_method = config.lr_method.lower()
+        if self._lr_method != "adam":
+            raise NotImplementedError("lr_method %r: the device optimizer implements Adam (img2seq.py:101); "
+                                      "adagrad/sgd/rmsprop (:102-107) are not built" % config.lr_method)
+        self._clip = getattr(config, "clip", -1)
+        self.init_session()
+        self.logger.info("- done.")
+
+    def build_pred(self):
+        """Reference: model/img2seq.py:42-46."""
+        self.logger.info("Building model...")
+        self._build_engine()
+        self.init_session()
+        self.logger.info("- done.")
+
+    # ------------------------------------------------------------------ feeds --
+    def _get_feed_dict(self, img, formula=None, lr=None, dropout=1):
+        """Reference: model/img2seq.py:125-142.  `dropout` is a KEEP probability (quirk C-5);
+        every value >= 1 is the identity, which is all the shipped configs use."""
+        if dropout < 1:
+            raise NotImplementedError("dropout keep-prob < 1 is not built (shipped configs use 1 / 127 = identity)")
+        fd = {"img": pad_batch_images(img), "dropout": dropout}
+        if formula is not None:
+            f, l = pad_batch_formulas(formula, self._vocab.id_pad, self._vocab.id_end)
+            fd["formula"], fd["formula_length"] = f, l
+        if lr is not None:
+            fd["lr"] = lr
+        return fd
+
+    # ------------------------------------------------------------------ train --
+    def _run_train(self, config, train_set, val_set, epoch, lr_schedule):
+        """Reference: model/img2seq.py:144-196."""
+        batch_size = config.batch_size
+        nbatches = (len(train_set) + batch_size - 1) // batch_size
+        prog = Progbar(nbatches)
+        for i, (img, formula) in enumerate(minibatches(train_set, batch_size)):
+            fd = self._get_feed_dict(img, formula=formula, lr=lr_schedule.lr, dropout=config.dropout)
+            loss_eval = self.engine.train_step(fd["img"], fd["formula"], fd["formula_length"], fd["lr"], clip=self._clip)
+            prog.update(i + 1, [("loss", loss_eval), ("perplexity", np.exp(loss_eval)), ("lr", lr_schedule.lr)])
+            lr_schedule.update(batch_no=epoch * nbatches + i)
+        self.logger.info("- Training: {}".format(prog.info))
+        config_eval = Config({"dir_answers": self._dir_output + "formulas_val/", "batch_size": config.batch_size})
+        scores = self.evaluate(config_eval, val_set)
+        score = scores["perplexity"]
+        lr_schedule.update(score=score)
+        return score
+
+    def _run_evaluate(self, config, test_set):
+        """Reference: model/img2seq.py:198-213."""
+        files, perp = self.write_prediction(config, test_set)
+        scores = score_files(files[0], files[1])
+        scores["perplexity"] = perp
+        return scores
+
+    def _decode(self, img):
+        """pred_test.ids of the decode graph (decoder.py:60-70), shaped [B, k, T'] as after
+        img2seq.py:238-241."""
+        cfg = self._config
+        max_iter = getattr(cfg, "max_length_formula", 150) + 1          # decoder.py:70
+        if getattr(cfg, "decoding", "greedy") == "beam_search":
+            ids = self.engine.beam_decode(img, self._vocab.id_end, cfg.beam_size, max_iter=max_iter)
+            return np.transpose(ids, [0, 2, 1])
+        ids = self.engine.greedy_decode(img, self._vocab.id_end, max_iter=max_iter)
+        return np.expand_dims(ids, axis=1)
+
+    def write_prediction(self, config, test_set):
+        """Reference: model/img2seq.py:215-254.  perplexity is NEGATED (quirk C-2)."""
+        k = self._config.beam_size if getattr(self._config, "decoding", "greedy") == "beam_search" else 1
+        refs, hyps = [], [[] for _ in range(k)]
+        n_words, ce_words = 0, 0.0
+        for img, formula in minibatches(test_set, config.batch_size):
+            fd = self._get_feed_dict(img, formula=formula, dropout=1)
+            ce, n = self.engine.evaluate_batch(fd["img"], fd["formula"], fd["formula_length"])
+            ids_eval = self._decode(fd["img"])
+            n_words += n
+            ce_words += ce
+            for form, preds in zip(formula, ids_eval):
+                refs.append(form)
+                for i, pred in enumerate(preds):
+                    hyps[i].append(pred)
+        files = write_answers(refs, hyps, self._vocab.id_to_tok, config.dir_answers, self._vocab.id_end)
+        perp = -np.exp(ce_words / float(n_words))
+        return files, perp
+
+    def predict_batch(self, images):
+        """Reference: model/img2seq.py:256-276."""
+        fd = self._get_feed_dict(images, dropout=1)
+        ids_eval = self._decode(fd["img"])
+        hyps = [[] for _ in range(ids_eval.shape[1])]
+        for preds in ids_eval:
+            for i, pred in enumerate(preds):
+                p = truncate_end(pred, self._vocab.id_end)
+                hyps[i].append(" ".join(self._vocab.id_to_tok[int(idx)] for idx in p))
+        return hyps
+
+    def predict(self, img):
+        """Reference: model/img2seq.py:278-285."""
+        return [hyp[0] for hyp in self.predict_batch([img])]
