@@ -8,11 +8,11 @@ int lxo_k_lstm_fwd(const float* z, const float* c_prev, float* gates, float* c_o
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, const float* dh1, int ld1, const float* dh2, int ld2,
                    float* dcc, float* dz, int B, int U, hipStream_t st);
 int lxo_k_tanh_bwd(const float* a, int lda, const float* b, int ldb, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st);
-int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* ctx, int ldctx,
-                   int nv, int R, int Rp, int E, int C, int beam, hipStream_t st);
+int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* part,
+                   float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st);
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
                    const float* dctx, int lddc, const float* ctx, int ldctx, float* de, float* datth,
-                   int nv, int R, int Rp, int E, int C, hipStream_t st);
+                   int nv, int R, int Rp, int E, int C, int nch, hipStream_t st);
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
                    int T, int B, int R, int Rp, int E, hipStream_t st);
 int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st);

@@ -6,7 +6,6 @@
 
 namespace {
 
-constexpr int MAXR = 10240;   // regions per sample held in LDS (Plan::validate)
 
 // 4 consecutive k of one row as floats
 LXO_DEV void load4(const float* p, float (&v)[4]) {
@@ -146,167 +145,264 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
     }
 }
 
-// ---- attention forward: one workgroup per (virtual) sample ----
-template <typename CT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
-                                                      const float* __restrict__ att_h, const float* __restrict__ beta,
-                                                      float* __restrict__ alpha, float* __restrict__ ctx, int ldctx,
-                                                      int R, int Rp, int E, int C, int beam) {
-    __shared__ float sc[MAXR];
-    __shared__ float redc[4][512];
-    __shared__ float red[8];
-    const int v = blockIdx.x, bi = v / beam;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const CT* ai = att_img + (long long)bi * R * E;
-    const CT* im = img + (long long)bi * R * C;
-    const int KC = (E + 255) >> 8;
-    float ah[4][4], bt[4][4];
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-        const int k0 = kc * 256 + lane * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = kc < KC && k0 + j < E;
-            ah[kc][j] = ok ? att_h[(long long)v * E + k0 + j] : 0.f;
-            bt[kc][j] = ok ? beta[k0 + j] : 0.f;
-        }
-    }
-    // scores e[r] = sum_k beta_k tanh(att_img[r][k] + att_h[k])       (attention_mechanism.py:83-91)
-    for (int r = wave; r < R; r += 4) {
-        float part = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const int k0 = kc * 256 + lane * 4;
-            if (kc < KC && k0 < E) {
-                float x[4];
-                load4(ai + (long long)r * E + k0, x);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) part = fmaf(tanhf(x[j] + ah[kc][j]), bt[kc][j], part);
-            }
-        }
-        part = wave_sum(part);
-        if (lane == 0) sc[r] = part;
-    }
-    __syncthreads();
-    // softmax over regions                                            (attention_mechanism.py:94)
-    float m = -3.0e38f;
-    for (int r = tid; r < R; r += 256) m = fmaxf(m, sc[r]);
-    m = wave_max(m);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float l = 0.f;
-    for (int r = tid; r < R; r += 256) { const float p = expf(sc[r] - m); sc[r] = p; l += p; }
-    l = wave_sum(l);
-    if (lane == 0) red[4 + wave] = l;
-    __syncthreads();
-    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-    for (int r = tid; r < R; r += 256) { const float a = sc[r] * inv; sc[r] = a; alpha[(long long)v * Rp + r] = a; }
-    __syncthreads();
-    // context = sum_r alpha[r] * img[r][:]                            (attention_mechanism.py:73-74)
-    const int c0 = lane * 8;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    if (c0 < C)
-        for (int r = wave; r < R; r += 4) {
-            float x[8];
-            load8(im + (long long)r * C + c0, x);
-            const float a = sc[r];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fmaf(a, x[e], acc[e]);
-        }
-    if (c0 < C) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e];
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256)
-        ctx[(long long)v * ldctx + c] = redc[0][c] + redc[1][c] + redc[2][c] + redc[3][c];
-}
+// ---- attention stream ----
+// The R regions of a sample are split into NCH chunks, one workgroup (8 waves) per
+// (chunk, sample), so that B*NCH >= ~2 workgroups per CU and every wave keeps 8 row
+// loads in flight (the stream is latency-bound otherwise: one 512-B row per wave per
+// round trip measured 5 GB/s per workgroup).  Each chunk produces flash-style partials
+// (max, sum, unnormalised context); attn_fwd_combine normalises.
+constexpr int ATT_ROWS = 1024;  // max rows per chunk (Plan::attn_chunks)
+constexpr int ATT_W = 8;        // waves per workgroup
+constexpr int ATT_U = 8;        // rows in flight per wave
 
-// ---- attention backward (per step): d_e and d_att_h; d_img / d_att_img are deferred ----
+template <typename CT> LXO_DEV float tanh_ct(float x);
+template <> LXO_DEV float tanh_ct<float>(float x) { return tanhf(x); }
+// bf16 mode: 1 - 2/(e^{2x}+1) on v_exp_f32 / v_rcp_f32 (abs error ~1e-7, far below bf16 resolution)
+template <> LXO_DEV float tanh_ct<bf16_t>(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
+
 template <typename CT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
-                                                      const float* __restrict__ att_h, const float* __restrict__ beta,
-                                                      const float* __restrict__ alpha, const float* __restrict__ dctx, int lddc,
-                                                      const float* __restrict__ ctx, int ldctx,
-                                                      float* __restrict__ de, float* __restrict__ datth,
-                                                      int R, int Rp, int E, int C) {
-    __shared__ float sc[MAXR];
-    __shared__ float rede[4][1024];
-    __shared__ float red[4];
-    const int v = blockIdx.x;
+__global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+                                                           const float* __restrict__ att_h, const float* __restrict__ beta,
+                                                           float* __restrict__ alpha, float* __restrict__ part,
+                                                           int R, int Rp, int E, int C, int beam, int nch, int rows_per) {
+    __shared__ float sc[ATT_ROWS];
+    __shared__ float redc[ATT_W][512];
+    __shared__ float red[2 * ATT_W];
+    const int ch = blockIdx.x, v = blockIdx.y, bi = v / beam;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const CT* ai = att_img + (long long)v * R * E;
-    const CT* im = img + (long long)v * R * C;
+    const int r0 = ch * rows_per;
+    const int n = min(R, r0 + rows_per) - r0;          // may be <= 0 for a trailing chunk
+    const CT* ai = att_img + ((long long)bi * R + r0) * E;
+    const CT* im = img + ((long long)bi * R + r0) * C;
+    float* pout = part + ((long long)v * nch + ch) * (C + 2);
     const int KC = (E + 255) >> 8;
-    // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r
-    float s = 0.f;
-    for (int c = tid; c < C; c += 256) s = fmaf(ctx[(long long)v * ldctx + c], dctx[(long long)v * lddc + c], s);
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    s = red[0] + red[1] + red[2] + red[3];
-    const int c0 = lane * 8;
-    float dc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dc[e] = (c0 + e < C) ? dctx[(long long)v * lddc + c0 + e] : 0.f;
-    for (int r = wave; r < R; r += 4) {
-        float part = 0.f;
-        if (c0 < C) {
-            float x[8];
-            load8(im + (long long)r * C + c0, x);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) part = fmaf(x[e], dc[e], part);
-        }
-        part = wave_sum(part);
-        if (lane == 0) {
-            const float d = alpha[(long long)v * Rp + r] * (part - s);   // softmax backward
-            sc[r] = d;
-            de[(long long)v * Rp + r] = d;
-        }
-    }
-    __syncthreads();
-    float ah[4][4], bt[4][4], acc[4][4];
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
+    // scores
+    for (int kc = 0; kc < KC; ++kc) {
         const int k0 = kc * 256 + lane * 4;
+        const bool kok = k0 < E;
+        float ah[4], bt[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = kc < KC && k0 + j < E;
-            ah[kc][j] = ok ? att_h[(long long)v * E + k0 + j] : 0.f;
-            bt[kc][j] = ok ? beta[k0 + j] : 0.f;
-            acc[kc][j] = 0.f;
-        }
-    }
-    for (int r = wave; r < R; r += 4) {
-        const float d = sc[r];
+        for (int j = 0; j < 4; ++j) { ah[j] = kok ? att_h[(long long)v * E + k0 + j] : 0.f; bt[j] = kok ? beta[k0 + j] : 0.f; }
+        for (int base = wave; base < n; base += ATT_W * ATT_U) {
+            float x[ATT_U][4];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const int k0 = kc * 256 + lane * 4;
-            if (kc < KC && k0 < E) {
-                float x[4];
-                load4(ai + (long long)r * E + k0, x);
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                if (kok && r < n) load4(ai + (long long)r * E + k0, x[u]);
+                else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
+            }
+            float pt[ATT_U];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float tau = tanhf(x[j] + ah[kc][j]);
-                    acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
+            for (int u = 0; u < ATT_U; ++u) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a = fmaf(tanh_ct<CT>(x[u][j] + ah[j]), bt[j], a);
+                pt[u] = a;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < ATT_U; ++u) {
+                    const int r = base + ATT_W * u;
+                    if (r < n) sc[r] = (kc == 0 ? 0.f : sc[r]) + pt[u];
                 }
             }
         }
     }
+    __syncthreads();
+    // chunk-local softmax statistics
+    float m = -3.0e38f;
+    for (int r = tid; r < n; r += 512) m = fmaxf(m, sc[r]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-        const int k0 = kc * 256 + lane * 4;
-        if (kc < KC && k0 < E) {
+    for (int w = 1; w < ATT_W; ++w) m = fmaxf(m, red[w]);
+    float l = 0.f;
+    for (int r = tid; r < n; r += 512) {
+        const float p = expf(sc[r] - m);
+        sc[r] = p; l += p;
+        alpha[(long long)v * Rp + r0 + r] = p;          // unnormalised; attn_fwd_combine rescales
+    }
+    l = wave_sum(l);
+    if (lane == 0) red[ATT_W + wave] = l;
+    __syncthreads();
+    if (tid == 0) {
+        float lt = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rede[wave][k0 + j] = acc[kc][j] * bt[kc][j];
+        for (int w = 0; w < ATT_W; ++w) lt += red[ATT_W + w];
+        pout[0] = m; pout[1] = lt;
+    }
+    // unnormalised context of the chunk
+    const int c0 = lane * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        for (int base = wave; base < n; base += ATT_W * ATT_U) {
+            float x[ATT_U][8];
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                if (r < n) load8(im + (long long)r * C + c0, x[u]);
+                else { for (int e = 0; e < 8; ++e) x[u][e] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                const float a = r < n ? sc[r] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(a, x[u][e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 512) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_W; ++w) t += redc[w][c];
+        pout[2 + c] = t;
+    }
+}
+
+// merge the chunk partials: alpha = p * exp(m_c - m) / l ; ctx = sum_c ctx_c exp(m_c - m) / l
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __restrict__ part, float* __restrict__ alpha,
+                                                              float* __restrict__ ctx, int ldctx, int R, int Rp, int C,
+                                                              int nch, int rows_per) {
+    __shared__ float scl[32];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const float* pv = part + (long long)v * nch * (C + 2);
+    if (tid == 0) {
+        float m = -3.0e38f;
+        for (int c = 0; c < nch; ++c) if (pv[(long long)c * (C + 2) + 1] > 0.f) m = fmaxf(m, pv[(long long)c * (C + 2)]);
+        float l = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            const float lc = pv[(long long)c * (C + 2) + 1];
+            const float s = lc > 0.f ? expf(pv[(long long)c * (C + 2)] - m) : 0.f;
+            scl[c] = s; l += lc * s;
+        }
+        const float inv = 1.0f / l;
+        for (int c = 0; c < nch; ++c) scl[c] *= inv;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float t = 0.f;
+        for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + c], scl[k], t);
+        ctx[(long long)v * ldctx + c] = t;
+    }
+    for (int r = tid; r < R; r += 256) alpha[(long long)v * Rp + r] *= scl[r / rows_per];
+}
+
+// ---- attention backward (per step): d_e and d_att_h; d_img / d_att_img are deferred ----
+template <typename CT>
+__global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+                                                           const float* __restrict__ att_h, const float* __restrict__ beta,
+                                                           const float* __restrict__ alpha, const float* __restrict__ dctx, int lddc,
+                                                           const float* __restrict__ ctx, int ldctx,
+                                                           float* __restrict__ de, float* __restrict__ datth,
+                                                           int R, int Rp, int E, int C, int rows_per) {
+    __shared__ float sc[ATT_ROWS];
+    __shared__ float rede[ATT_W][1024];
+    __shared__ float red[ATT_W];
+    const int ch = blockIdx.x, v = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = ch * rows_per;
+    const int n = min(R, r0 + rows_per) - r0;
+    if (n <= 0) return;                                  // block-uniform
+    const CT* ai = att_img + ((long long)v * R + r0) * E;
+    const CT* im = img + ((long long)v * R + r0) * C;
+    const int KC = (E + 255) >> 8;
+    // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r
+    float s = 0.f;
+    for (int c = tid; c < C; c += 512) s = fmaf(ctx[(long long)v * ldctx + c], dctx[(long long)v * lddc + c], s);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_W; ++w) s += red[w];
+    const int c0 = lane * 8;
+    float dc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dc[e] = (c0 + e < C) ? dctx[(long long)v * lddc + c0 + e] : 0.f;
+    for (int base = wave; base < n; base += ATT_W * ATT_U) {
+        float x[ATT_U][8];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int r = base + ATT_W * u;
+            if (c0 < C && r < n) load8(im + (long long)r * C + c0, x[u]);
+            else { for (int e = 0; e < 8; ++e) x[u][e] = 0.f; }
+        }
+        float pt[ATT_U];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(x[u][e], dc[e], a);
+            pt[u] = a;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                if (r < n) {
+                    const float d = alpha[(long long)v * Rp + r0 + r] * (pt[u] - s);   // softmax backward
+                    sc[r] = d;
+                    de[(long long)v * Rp + r0 + r] = d;
+                }
+            }
         }
     }
     __syncthreads();
-    for (int k = tid; k < E; k += 256)
-        datth[(long long)v * E + k] = rede[0][k] + rede[1][k] + rede[2][k] + rede[3][k];
+    for (int kc = 0; kc < KC; ++kc) {
+        const int k0 = kc * 256 + lane * 4;
+        const bool kok = k0 < E;
+        float ah[4], acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ah[j] = kok ? att_h[(long long)v * E + k0 + j] : 0.f; acc[j] = 0.f; }
+        for (int base = wave; base < n; base += ATT_W * ATT_U) {
+            float x[ATT_U][4];
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                if (kok && r < n) load4(ai + (long long)r * E + k0, x[u]);
+                else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                const float d = r < n ? sc[r] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float tau = tanh_ct<CT>(x[u][j] + ah[j]);
+                    acc[j] = fmaf(d, 1.f - tau * tau, acc[j]);
+                }
+            }
+        }
+        if (kok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rede[wave][k0 + j] = acc[j] * beta[k0 + j];
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < E; k += 512) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_W; ++w) t += rede[w][k];
+        atomicAdd(&datth[(long long)v * E + k], t);
+    }
 }
 
 // deferred: d_att_img[b][r][k] = beta_k sum_t de[t][b][r] (1 - tau^2),  d_beta_k += sum de * tau
@@ -663,19 +759,27 @@ int lxo_k_tanh_bwd(const float* a, int lda, const float* b, int ldb, const float
     LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols), a, lda, b, ldb, o, ldo, g, ldg, rows, cols);
     DONE;
 }
-int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* ctx, int ldctx,
-                   int nv, int R, int Rp, int E, int C, int beam, hipStream_t st) {
-    if (R > MAXR || E > 1024 || C > 512) return -2;
-    if (dt == LXO_BF16) LAUNCH((attn_fwd_kernel<bf16_t>), nv, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, ctx, ldctx, R, Rp, E, C, beam);
-    else LAUNCH((attn_fwd_kernel<float>), nv, (const float*)att_img, (const float*)img, att_h, beta, alpha, ctx, ldctx, R, Rp, E, C, beam);
+int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* part,
+                   float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st) {
+    if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
+    const int rows_per = cdiv(R, nch);
+    if (rows_per > ATT_ROWS) return -2;
+    dim3 grid(nch, nv);
+    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
+    else hipLaunchKernelGGL((attn_fwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
+    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
     DONE;
 }
+// datth must be zero on entry (chunks accumulate with atomics)
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
                    const float* dctx, int lddc, const float* ctx, int ldctx, float* de, float* datth,
-                   int nv, int R, int Rp, int E, int C, hipStream_t st) {
-    if (R > MAXR || E > 1024 || C > 512) return -2;
-    if (dt == LXO_BF16) LAUNCH((attn_bwd_kernel<bf16_t>), nv, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C);
-    else LAUNCH((attn_bwd_kernel<float>), nv, (const float*)att_img, (const float*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C);
+                   int nv, int R, int Rp, int E, int C, int nch, hipStream_t st) {
+    if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
+    const int rows_per = cdiv(R, nch);
+    if (rows_per > ATT_ROWS) return -2;
+    dim3 grid(nch, nv);
+    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
+    else hipLaunchKernelGGL((attn_bwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
     DONE;
 }
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,

@@ -58,13 +58,14 @@ LXO_DEV f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 // ------------------------------------------------------------------ NT ----
-template <typename CT, bool CONV, typename TA, typename OT, int BM, int BN>
+template <typename CT, bool CONV, typename TA, typename OT, int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     constexpr bool BF = is_bf16<CT>::value;
-    constexpr int BK = 32;
-    constexpr int PITCH = BF ? 40 : 33;
+    constexpr int PITCH = BF ? BK + 8 : BK + 1;
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave (2x2 waves)
-    constexpr int AC = BM / 64, BC = BN / 64;     // 8-element chunks per thread
+    constexpr int CPR = BK / 8;                   // 8-element chunks per tile row
+    constexpr int RPP = 256 / CPR;                // tile rows staged per pass of the 256 threads
+    constexpr int AC = BM / RPP, BC = BN / RPP;   // chunks per thread
     __shared__ __attribute__((aligned(16))) CT As[BM * PITCH];
     __shared__ __attribute__((aligned(16))) CT Bs[BN * PITCH];
 
@@ -74,12 +75,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     const TA* __restrict__ A = reinterpret_cast<const TA*>(p.A);
     const CT* __restrict__ Bp = reinterpret_cast<const CT*>(p.Bp);
 
-    const int srow = tid >> 2, skc = (tid & 3) * 8;
+    const int srow = tid / CPR, skc = (tid % CPR) * 8;
     // per-thread row descriptors
     bool a_ok[AC]; long long a_base[AC]; int a_oy[AC], a_ox[AC];
 #pragma unroll
     for (int j = 0; j < AC; ++j) {
-        const int m = m0 + srow + 64 * j;
+        const int m = m0 + srow + RPP * j;
         a_ok[j] = m < p.M;
         if constexpr (CONV) {
             const int mm = a_ok[j] ? m : 0;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     bool b_ok[BC]; long long b_base[BC];
 #pragma unroll
     for (int j = 0; j < BC; ++j) {
-        const int n = n0 + srow + 64 * j;
+        const int n = n0 + srow + RPP * j;
         b_ok[j] = n < p.N;
         b_base[j] = (long long)n * p.ldb;
     }
@@ -137,16 +138,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     };
 
     gload(0);
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
+    for (int k0 = 0; k0 < p.K; k0 += BK) {   // K % BK == 0 (checked by the launcher)
 #pragma unroll
-        for (int j = 0; j < AC; ++j) stage_store_rowmajor<CT>(&As[(srow + 64 * j) * PITCH + skc], ra[j]);
+        for (int j = 0; j < AC; ++j) stage_store_rowmajor<CT>(&As[(srow + RPP * j) * PITCH + skc], ra[j]);
 #pragma unroll
-        for (int j = 0; j < BC; ++j) stage_store_rowmajor<CT>(&Bs[(srow + 64 * j) * PITCH + skc], rb[j]);
+        for (int j = 0; j < BC; ++j) stage_store_rowmajor<CT>(&Bs[(srow + RPP * j) * PITCH + skc], rb[j]);
         __syncthreads();
         if (k0 + BK < p.K) gload(k0 + BK);
         if constexpr (BF) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 16; ++ks) {
                 u32x4 af[TM], bfr[TN];
                 const int kof = ks * 16 + (lane >> 5) * 8;
 #pragma unroll
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
             }
         } else {
 #pragma unroll 4
-            for (int ks = 0; ks < 16; ++ks) {
+            for (int ks = 0; ks < BK / 2; ++ks) {
                 float af[TM], bfr[TN];
                 const int kof = ks * 2 + (lane >> 5);
 #pragma unroll
@@ -215,6 +216,33 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
 }
 
 // ------------------------------------------------------------------ TN ----
+struct PixIt {                       // running (b, oy, ox) of an im2col row
+    int b, oy, ox;
+    LXO_DEV void init(int m, int Ho, int Wo) {
+        const int hw = Ho * Wo;
+        b = m / hw; const int rem = m - b * hw;
+        oy = rem / Wo; ox = rem - oy * Wo;
+    }
+    LXO_DEV void advance(int d, int Ho, int Wo) {
+        ox += d;
+        while (ox >= Wo) { ox -= Wo; ++oy; }
+        while (oy >= Ho) { oy -= Ho; ++b; }
+    }
+};
+
+// pair two rows of 8 values into 8 dwords {row0[e], row1[e]} (bf16x2), e = 0..7
+LXO_DEV void pack_rows(const u32x4& r0, const u32x4& r1, unsigned (&out)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = (r0[i] & 0xffffu) | (r1[i] << 16);
+        out[2 * i + 1] = (r0[i] >> 16) | (r1[i] & 0xffff0000u);
+    }
+}
+LXO_DEV void pack_rows(const float (&r0)[8], const float (&r1)[8], unsigned (&out)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = pack_bf2(r0[e], r1[e]);
+}
+
 template <typename CT, bool CONV, typename TA, typename TB>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     constexpr bool BF = is_bf16<CT>::value;
@@ -243,18 +271,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // staging geometry
-    //  bf16: one (row-pair, 8-column chunk) of A and of B per thread
+    //  bf16: one (row pair, 8-column chunk) of A and of B per thread, written as packed bf16x2 dwords
     //  f32 : two (row, 8-column chunk) of A and of B per thread
     constexpr int NQ = BF ? 1 : 2;
-    int s_r[NQ], s_c[NQ];           // row offset within the 32-row slab, chunk index (0..15)
+    constexpr int NR = BF ? 2 : 1;
+    int s_r[NQ], s_c[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if constexpr (BF) { s_r[q] = 2 * (lane & 15); s_c[q] = (lane >> 4) + 4 * wave; }
         else { const int c = tid + 256 * q; s_r[q] = c & 31; s_c[q] = c >> 5; }
     }
-    // conv: decode of the A column chunk (tap, channel) is loop invariant
     int c_kh[NQ], c_kw[NQ], c_ci[NQ];
     bool ai_ok[NQ], bj_ok[NQ];
+    PixIt pix[NQ][NR];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int i = i0 + s_c[q] * 8;
@@ -266,39 +295,62 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
             const int tap = ii / p.Cin;
             c_ci[q] = ii - tap * p.Cin;
             c_kh[q] = tap / 3; c_kw[q] = tap - 3 * c_kh[q];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) pix[q][rr].init(mbeg + s_r[q] + rr, p.Ho, p.Wo);
         }
     }
-    constexpr int NR = BF ? 2 : 1;   // rows per staged item
-    auto a_ptr = [&](int q, int m, bool& ok) -> const TA* {
-        ok = ai_ok[q] && m < mend;
-        if (!ok) return A;
-        if constexpr (CONV) {
-            const int hw = p.Ho * p.Wo;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const int iy = oy - p.pad + c_kh[q], ix = ox - p.pad + c_kw[q];
-            ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            if (!ok) return A;
-            return A + (((long long)b * p.H + iy) * p.W + ix) * p.Cin + c_ci[q];
-        } else {
-            return A + (long long)m * p.lda + i0 + s_c[q] * 8;
-        }
-    };
 
-    float va[NQ][NR][8], vb[NQ][NR][8];
+    // staged registers: packed pairs (bf16) or raw rows (f32)
+    unsigned pa[NQ][8], pb[NQ][8];
+    float fa[NQ][8], fb[NQ][8];
     auto gload = [&](int mb) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < NQ; ++q) {
+            const TA* ap[NR]; bool aok[NR]; const TB* bq[NR]; bool bok[NR];
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
                 const int m = mb + s_r[q] + rr;
-                bool ok; const TA* pa = a_ptr(q, m, ok);
-                if (ok) load8(pa, va[q][rr]);
-                else { for (int e = 0; e < 8; ++e) va[q][rr][e] = 0.f; }
-                const bool okb = bj_ok[q] && m < mend;
-                if (okb) load8(B + (long long)m * p.ldb + j0 + s_c[q] * 8, vb[q][rr]);
-                else { for (int e = 0; e < 8; ++e) vb[q][rr][e] = 0.f; }
+                aok[rr] = ai_ok[q] && m < mend;
+                ap[rr] = A;
+                if constexpr (CONV) {
+                    const int iy = pix[q][rr].oy - p.pad + c_kh[q], ix = pix[q][rr].ox - p.pad + c_kw[q];
+                    aok[rr] = aok[rr] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    if (aok[rr]) ap[rr] = A + (((long long)pix[q][rr].b * p.H + iy) * p.W + ix) * p.Cin + c_ci[q];
+                    pix[q][rr].advance(BR, p.Ho, p.Wo);
+                } else {
+                    if (aok[rr]) ap[rr] = A + (long long)m * p.lda + i0 + s_c[q] * 8;
+                }
+                bok[rr] = bj_ok[q] && m < mend;
+                bq[rr] = bok[rr] ? B + (long long)m * p.ldb + j0 + s_c[q] * 8 : B;
             }
+            if constexpr (BF) {
+                if constexpr (is_bf16<TA>::value) {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    const u32x4 r0 = aok[0] ? *reinterpret_cast<const u32x4*>(ap[0]) : z;
+                    const u32x4 r1 = aok[1] ? *reinterpret_cast<const u32x4*>(ap[1]) : z;
+                    pack_rows(r0, r1, pa[q]);
+                } else {
+                    float r0[8], r1[8];
+                    if (aok[0]) load8(ap[0], r0); else { for (int e = 0; e < 8; ++e) r0[e] = 0.f; }
+                    if (aok[1]) load8(ap[1], r1); else { for (int e = 0; e < 8; ++e) r1[e] = 0.f; }
+                    pack_rows(r0, r1, pa[q]);
+                }
+                if constexpr (is_bf16<TB>::value) {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    const u32x4 r0 = bok[0] ? *reinterpret_cast<const u32x4*>(bq[0]) : z;
+                    const u32x4 r1 = bok[1] ? *reinterpret_cast<const u32x4*>(bq[1]) : z;
+                    pack_rows(r0, r1, pb[q]);
+                } else {
+                    float r0[8], r1[8];
+                    if (bok[0]) load8(bq[0], r0); else { for (int e = 0; e < 8; ++e) r0[e] = 0.f; }
+                    if (bok[1]) load8(bq[1], r1); else { for (int e = 0; e < 8; ++e) r1[e] = 0.f; }
+                    pack_rows(r0, r1, pb[q]);
+                }
+            } else {
+                if (aok[0]) load8(reinterpret_cast<const float*>(ap[0]), fa[q]); else { for (int e = 0; e < 8; ++e) fa[q][e] = 0.f; }
+                if (bok[0]) load8(reinterpret_cast<const float*>(bq[0]), fb[q]); else { for (int e = 0; e < 8; ++e) fb[q][e] = 0.f; }
+            }
+        }
     };
 
     if (mbeg < mend) gload(mbeg);
@@ -308,11 +360,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if constexpr (BF) {
-                    *reinterpret_cast<unsigned*>(&As[(s_c[q] * 8 + e) * PITCH + s_r[q]]) = pack_bf2(va[q][0][e], va[q][1][e]);
-                    *reinterpret_cast<unsigned*>(&Bs[(s_c[q] * 8 + e) * PITCH + s_r[q]]) = pack_bf2(vb[q][0][e], vb[q][1][e]);
+                    *reinterpret_cast<unsigned*>(&As[(s_c[q] * 8 + e) * PITCH + s_r[q]]) = pa[q][e];
+                    *reinterpret_cast<unsigned*>(&Bs[(s_c[q] * 8 + e) * PITCH + s_r[q]]) = pb[q][e];
                 } else {
-                    As[(s_c[q] * 8 + e) * PITCH + s_r[q]] = va[q][0][e];
-                    Bs[(s_c[q] * 8 + e) * PITCH + s_r[q]] = vb[q][0][e];
+                    As[(s_c[q] * 8 + e) * PITCH + s_r[q]] = fa[q][e];
+                    Bs[(s_c[q] * 8 + e) * PITCH + s_r[q]] = fb[q][e];
                 }
             }
         }
@@ -325,11 +377,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
                 const int kof = ks * 16 + (lane >> 5) * 8;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const CT* pa = &As[(wi * 64 + i * 32 + (lane & 31)) * PITCH + kof];
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pa), hi = *reinterpret_cast<const u32x2*>(pa + 4);
+                    const CT* pa_ = &As[(wi * 64 + i * 32 + (lane & 31)) * PITCH + kof];
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pa_), hi = *reinterpret_cast<const u32x2*>(pa_ + 4);
                     af[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                    const CT* pb = &Bs[(wj * 64 + i * 32 + (lane & 31)) * PITCH + kof];
-                    const u32x2 lo2 = *reinterpret_cast<const u32x2*>(pb), hi2 = *reinterpret_cast<const u32x2*>(pb + 4);
+                    const CT* pb_ = &Bs[(wj * 64 + i * 32 + (lane & 31)) * PITCH + kof];
+                    const u32x2 lo2 = *reinterpret_cast<const u32x2*>(pb_), hi2 = *reinterpret_cast<const u32x2*>(pb_ + 4);
                     bfr[i] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
                 }
 #pragma unroll
@@ -374,10 +426,113 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
-template <typename CT, bool CONV, typename TA, typename OT, int BM, int BN>
+// ------------------------------------------------------------- skinny ----
+// C[M<=64 per block row][N] = act(alpha * A * Bp^T + bias) for the per-step recurrent GEMMs
+// (M = batch).  These are latency-bound: one workgroup per 32 output columns, the four
+// waves split K four ways, every operand fragment is loaded straight from global memory in
+// MFMA layout with 8 k-steps of loads in flight, and the four partial tiles meet in LDS.
+template <typename CT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmNT p) {
+    constexpr bool BF = is_bf16<CT>::value;
+    __shared__ float red[4][64][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
+    const int kq = p.K >> 2, kb = wave * kq;
+    const float* __restrict__ A = reinterpret_cast<const float*>(p.A);
+    const CT* __restrict__ Bp = reinterpret_cast<const CT*>(p.Bp);
+    const int row0 = m0 + (lane & 31), row1 = row0 + 32, col = n0 + (lane & 31);
+    const bool ok0 = row0 < p.M, ok1 = row1 < p.M, okb = col < p.N;
+    const float* a0 = A + (long long)(ok0 ? row0 : 0) * p.lda + kb;
+    const float* a1 = A + (long long)(ok1 ? row1 : 0) * p.lda + kb;
+    const CT* bp = Bp + (long long)(okb ? col : 0) * p.ldb + kb;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+        const int h8 = (lane >> 5) * 8;
+        for (int k = 0; k < kq; k += 128) {
+            f32x4 x0[8][2], x1[8][2]; u32x4 bb[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int kk = k + s * 16 + h8;
+                const bool in = kk < kq;
+                x0[s][0] = (ok0 && in) ? *reinterpret_cast<const f32x4*>(a0 + kk) : z4;
+                x0[s][1] = (ok0 && in) ? *reinterpret_cast<const f32x4*>(a0 + kk + 4) : z4;
+                x1[s][0] = (ok1 && in) ? *reinterpret_cast<const f32x4*>(a1 + kk) : z4;
+                x1[s][1] = (ok1 && in) ? *reinterpret_cast<const f32x4*>(a1 + kk + 4) : z4;
+                const u32x4 zb = {0u, 0u, 0u, 0u};
+                bb[s] = (okb && in) ? *reinterpret_cast<const u32x4*>(bp + kk) : zb;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const u32x4 f0 = {pack_bf2(x0[s][0][0], x0[s][0][1]), pack_bf2(x0[s][0][2], x0[s][0][3]),
+                                  pack_bf2(x0[s][1][0], x0[s][1][1]), pack_bf2(x0[s][1][2], x0[s][1][3])};
+                const u32x4 f1 = {pack_bf2(x1[s][0][0], x1[s][0][1]), pack_bf2(x1[s][0][2], x1[s][0][3]),
+                                  pack_bf2(x1[s][1][0], x1[s][1][1]), pack_bf2(x1[s][1][2], x1[s][1][3])};
+                acc0 = mfma_bf16(f0, bb[s], acc0);
+                acc1 = mfma_bf16(f1, bb[s], acc1);
+            }
+        }
+    } else {
+        // k permutation: half h of the wave owns k = 8j + 4h + e, used at k-step (j, e); A and B agree
+        const int h4 = (lane >> 5) * 4;
+        for (int k = 0; k < kq; k += 64) {
+            f32x4 x0[8], x1[8], bb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = k + j * 8 + h4;
+                const bool in = kk < kq;
+                x0[j] = (ok0 && in) ? *reinterpret_cast<const f32x4*>(a0 + kk) : z4;
+                x1[j] = (ok1 && in) ? *reinterpret_cast<const f32x4*>(a1 + kk) : z4;
+                bb[j] = (okb && in) ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(bp) + kk) : z4;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[j][e], bb[j][e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j][e], bb[j][e], acc1, 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        red[wave][rr][lane & 31] = acc0[r];
+        red[wave][rr + 32][lane & 31] = acc1[r];
+    }
+    __syncthreads();
+    const int orow = tid >> 2, oc0 = (tid & 3) * 8;
+    const int m = m0 + orow;
+    if (m < p.M) {
+        float* __restrict__ C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = n0 + oc0 + e;
+            if (n >= p.N) continue;
+            float v = red[0][orow][oc0 + e] + red[1][orow][oc0 + e] + red[2][orow][oc0 + e] + red[3][orow][oc0 + e];
+            v = p.alpha * v + (p.bias ? p.bias[n] : 0.f);
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            else if (p.act == 2) v = tanhf(v);
+            const long long o = (long long)m * p.ldc + n;
+            if (p.accumulate) v += C[o];
+            C[o] = v;
+        }
+    }
+}
+
+template <typename CT>
+int launch_skinny(const GemmNT& p, hipStream_t s) {
+    dim3 grid(cdiv(p.N, 32), cdiv(p.M, 64));
+    hipLaunchKernelGGL((gemm_skinny_kernel<CT>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+template <typename CT, bool CONV, typename TA, typename OT, int BM, int BN, int BK = 32>
 int launch_nt(const GemmNT& p, hipStream_t s) {
     dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM));
-    hipLaunchKernelGGL((gemm_nt_kernel<CT, CONV, TA, OT, BM, BN>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<CT, CONV, TA, OT, BM, BN, BK>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
 template <typename CT, bool CONV, typename TA, typename TB>
@@ -392,6 +547,10 @@ int launch_tn(const GemmTN& p, hipStream_t s) {
 int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K % 32 != 0 || p.K <= 0) return -2;
+    if (p.conv && p.Cin % 32) return -2;
+    const bool plain = !p.conv && !p.addend && !p.relu_ref && !p.out_pre && !p.colsum;
+    if (small && plain && p.K % 256 == 0 && (dt == LXO_F32 || (a_f32 && c_f32)) && p.lda % 4 == 0)
+        return dt == LXO_F32 ? launch_skinny<float>(p, s) : launch_skinny<bf16_t>(p, s);
     if (dt == LXO_F32) {
         if (p.conv) return launch_nt<float, true, float, float, 128, 128>(p, s);
         if (small) return launch_nt<float, false, float, float, 64, 64>(p, s);
@@ -399,15 +558,17 @@ int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p,
     }
     if (p.conv) {
         if (a_f32 || c_f32) return -3;
-        return launch_nt<bf16_t, true, bf16_t, bf16_t, 128, 128>(p, s);
+        if (p.Cin % 64) return -2;
+        return launch_nt<bf16_t, true, bf16_t, bf16_t, 128, 128, 64>(p, s);
     }
     if (small) {
         if (!(a_f32 && c_f32)) return -3;
         return launch_nt<bf16_t, false, float, float, 64, 64>(p, s);
     }
-    if (!a_f32 && !c_f32) return launch_nt<bf16_t, false, bf16_t, bf16_t, 128, 128>(p, s);
-    if (!a_f32 && c_f32) return launch_nt<bf16_t, false, bf16_t, float, 128, 128>(p, s);
-    if (a_f32 && c_f32) return launch_nt<bf16_t, false, float, float, 128, 128>(p, s);
+    const bool k64 = p.K % 64 == 0;
+    if (!a_f32 && !c_f32) return k64 ? launch_nt<bf16_t, false, bf16_t, bf16_t, 128, 128, 64>(p, s) : launch_nt<bf16_t, false, bf16_t, bf16_t, 128, 128>(p, s);
+    if (!a_f32 && c_f32) return k64 ? launch_nt<bf16_t, false, bf16_t, float, 128, 128, 64>(p, s) : launch_nt<bf16_t, false, bf16_t, float, 128, 128>(p, s);
+    if (a_f32 && c_f32) return k64 ? launch_nt<bf16_t, false, float, float, 128, 128, 64>(p, s) : launch_nt<bf16_t, false, float, float, 128, 128>(p, s);
     return -3;
 }
 

@@ -73,7 +73,7 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
     // att_h = h W                                 (attention_mechanism.py:79)
     RC(nt(P, true, true, true, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, atth_t, E, nv, E, U, nullptr, 0, false, st));
     RC(lxo_k_attn_fwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), atth_t, prm + P.poff[P_BETA], alpha_t,
-                      rec_cur + P.XH, P.REC, nv, P.R, P.Rp, E, C, beam, st));
+                      P.ws<float>(ws, W_APART), rec_cur + P.XH, P.REC, nv, P.R, P.Rp, E, C, beam, P.attn_chunks(nv), st));
     // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
     RC(nt(P, true, true, true, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, rec_cur, P.REC, nv, O, P.HC, nullptr, 2, false, st));
     return 0;
@@ -125,6 +125,8 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
 
     HIPRC(hipMemsetAsync(dxh, 0, (size_t)B * P.XH * 4, st));
     HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
+    HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));     // attention chunks accumulate d_att_h with atomics
+    const int nchb = P.attn_chunks(B);
     for (int t = T - 1; t >= 0; --t) {
         const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
         float* g_t = gall + (size_t)t * B * O;
@@ -135,7 +137,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(nt(P, true, true, true, g_t, O, P.pk(wp, K_OW), O, dhc_t, P.HC, B, P.HC, O, nullptr, 0, false, st));
         RC(lxo_k_attn_bwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), atth + (size_t)t * B * E, prm + P.poff[P_BETA],
                           alpha + (size_t)t * B * P.Rp, dhc_t + U, P.HC, rec_cur + P.XH, P.REC,
-                          de + (size_t)t * B * P.Rp, datth + (size_t)t * B * E, B, P.R, P.Rp, E, C, st));
+                          de + (size_t)t * B * P.Rp, datth + (size_t)t * B * E, B, P.R, P.Rp, E, C, nchb, st));
         // d_h carry += d_att_h W_att_h^T   (accumulates onto the carry written by the previous iteration)
         RC(nt(P, true, true, true, datth + (size_t)t * B * E, E, P.pk(wp, K_ATT_H), E, dxh + O, P.XH, B, U, E, nullptr, 0, true, st));
         RC(lxo_k_lstm_bwd(gates + (size_t)t * B * 4 * U, cs + (size_t)t * B * U, cs + (size_t)(t + 1) * B * U,

@@ -34,7 +34,7 @@ enum PackId {
 
 enum WsId {
     W_P1, W_Y2, W_P2, W_Y3, W_Y4, W_P4, W_Y5, W_P5, W_Y6, W_IMG, W_POS,
-    W_ATT_IMG, W_MEAN, W_EMB_IN, W_ZX, W_REC, W_CS, W_GATES, W_ATTH, W_ALPHA, W_LOGITS,
+    W_ATT_IMG, W_APART, W_MEAN, W_EMB_IN, W_ZX, W_REC, W_CS, W_GATES, W_ATTH, W_ALPHA, W_LOGITS,
     W_DLOGITS, W_LOSS, W_DOLOG, W_G, W_DHC, W_DE, W_DATTH, W_DZ, W_DXH, W_DCC, W_DIMG, W_DATTIMG,
     W_DEMB, W_DPRE0, W_DMEAN, W_G0, W_G1, W_GNORM,
     // decode-only
@@ -59,6 +59,8 @@ struct Plan {
 
     explicit Plan(const lxo_shape& sh, int beam = 1);
     int validate(char* msg, size_t n) const;
+    // chunks the R regions are split into for the attention stream, for nv decoder rows
+    int attn_chunks(int nv) const;
 
     template <class T> T* ws(void* base, WsId id) const { return reinterpret_cast<T*>(static_cast<char*>(base) + woff[id]); }
     const void* pk(const void* base, PackId id) const { return static_cast<const char*>(base) + koff[id]; }

@@ -23,7 +23,7 @@ const char* lxo_param_name(int id) { return (id >= 0 && id < P_COUNT) ? kParamNa
 
 static const char* kWsNames[W_COUNT] = {
     "p1", "y2", "p2", "y3", "y4", "p4", "y5", "p5", "y6", "img", "pos",
-    "att_img", "mean", "emb_in", "zx", "rec", "cs", "gates", "att_h", "alpha", "logits",
+    "att_img", "att_part", "mean", "emb_in", "zx", "rec", "cs", "gates", "att_h", "alpha", "logits",
     "dlogits", "loss", "do_log", "g", "dhc", "de", "datth", "dz", "dxh", "dcc", "d_img", "d_att_img",
     "d_emb", "dpre0", "dmean", "g0", "g1", "gnorm",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
@@ -91,6 +91,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)
     const size_t TB = (size_t)T * B;
     wb[W_ATT_IMG] = BL * R * E * esz;
+    wb[W_APART] = BK_ * 32 * (C + 2) * f4;
     wb[W_MEAN] = BL * C * f4;
     wb[W_EMB_IN] = TB * Dp * esz;
     wb[W_ZX] = TB * 4 * U * f4;
@@ -144,6 +145,16 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     for (int i = 0; i < W_COUNT; ++i) { wbytes[i] = wb[i]; woff[i] = wtotal; wtotal += al256(wb[i] + 256); }
 }
 
+int Plan::attn_chunks(int nv) const {
+    int nch = (512 + nv - 1) / nv;                 // ~2 workgroups per CU
+    if (nch > 16) nch = 16;
+    const int by_rows = R / 32 > 0 ? R / 32 : 1;   // keep >= 32 rows per chunk
+    if (nch > by_rows) nch = by_rows;
+    const int need = (R + 1023) / 1024;            // <= 1024 rows per chunk (LDS)
+    if (nch < need) nch = need;
+    return nch < 1 ? 1 : nch;
+}
+
 int Plan::validate(char* msg, size_t n) const {
 #define BAD(cond, text) if (cond) { snprintf(msg, n, "lxo_shape invalid: %s", text); return -10; }
     BAD(s.B <= 0 || s.H <= 0 || s.W <= 0, "B/H/W must be positive");
@@ -154,7 +165,7 @@ int Plan::validate(char* msg, size_t n) const {
     BAD(s.D % 8 || s.D <= 0, "D must be a positive multiple of 8");
     BAD(s.dtype != LXO_F32 && s.dtype != LXO_BF16, "dtype");
     BAD(s.E > 1024 || s.C > 512, "E <= 1024, C <= 512");
-    BAD(R > 10240, "more than 10240 regions");
+    BAD(R > 16384, "more than 16384 regions");
 #undef BAD
     return 0;
 }
