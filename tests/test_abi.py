@@ -1,0 +1,68 @@
+"""CPU: the gfx950 C-ABI library loads without a GPU and exports every symbol include/lxo.h
+declares; plan queries agree with the Python-side inventory; the product refuses to run
+without its HIP library / a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from latex_ocr_amd import _abi
+from latex_ocr_amd.model import params as PP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(_abi.LIB_PATH):
+        g.build()
+    return _abi.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "lxo.h")).read()
+    declared = sorted(set(re.findall(r"\b(lxo_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared and set(declared) == set(_abi.ENTRY_POINTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lxo_version() >= 1
+
+
+def test_param_table_matches_python(lib):
+    for V in (50, 500):
+        s = _abi.LxoShape(4, 32, 128, 10, V, 512, 256, 512, 512, 80, 1, 1, 0)
+        assert lib.lxo_param_total(ctypes.byref(s)) == PP.n_params(V)
+        off = 0
+        specs = PP.param_specs(V)
+        assert lib.lxo_param_num() == len(specs)
+        for i, (name, shp, _) in enumerate(specs):
+            o, c = ctypes.c_longlong(), ctypes.c_longlong()
+            assert lib.lxo_param_info(ctypes.byref(s), i, ctypes.byref(o), ctypes.byref(c)) == 0
+            assert lib.lxo_param_name(i).decode() == name
+            assert (o.value, c.value) == (off, int(np.prod(shp)))
+            off += int(np.prod(shp))
+
+
+def test_workspace_queries_and_validation(lib):
+    s = _abi.LxoShape(64, 128, 512, 101, 500, 512, 256, 512, 512, 80, 1, 1, 0)
+    ws = lib.lxo_workspace_bytes(ctypes.byref(s))
+    assert 1 << 30 < ws < 8 << 30
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.lxo_ws_region(ctypes.byref(s), b"img", ctypes.byref(off), ctypes.byref(nb)) == 0
+    assert nb.value == 64 * 14 * 62 * 512 * 2                       # [B, R=868, C] bf16
+    assert lib.lxo_ws_region(ctypes.byref(s), b"nope", None, None) != 0
+    bad = _abi.LxoShape(1, 8, 8, 4, 50, 512, 256, 512, 512, 80, 1, 1, 0)      # image too small for conv6 VALID
+    assert lib.lxo_encoder_fwd(ctypes.byref(bad), None, None, None, None, None) != 0
+    assert b"image too small" in lib.lxo_last_error()
+
+
+def test_no_cpu_fallback():
+    import torch
+    from latex_ocr_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        Engine(50, device="cpu")

@@ -1,0 +1,121 @@
+"""CPU: kernel LOGIC of the shipped HIP sources, executed by the hipsim SIMT interpreter
+(tests/hipsim: same .hip files compiled for the host; test infrastructure only).  Compared
+with the committed oracle golden vectors.  Real-hardware parity is in the -m gpu tests."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from simharness import Sim, lib, ptr
+from simlib import bf16_to_f32, f32_to_bf16
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_small.npz"))
+
+
+@pytest.mark.parametrize("dt,a_f32,c_f32,small,M,N,K", [(0, 1, 1, 0, 70, 40, 64), (1, 0, 0, 0, 130, 140, 128),
+                                                       (1, 1, 1, 1, 50, 70, 256), (0, 1, 1, 1, 64, 32, 256)])
+def test_gemm_nt(dt, a_f32, c_f32, small, M, N, K):
+    L = lib()
+    rng = np.random.default_rng(M * N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32); B = rng.standard_normal((N, K)).astype(np.float32)
+    if dt == 1:
+        Bd = f32_to_bf16(B); Bref = bf16_to_f32(Bd)
+        Ad = A if a_f32 else f32_to_bf16(A)
+        Aref = bf16_to_f32(f32_to_bf16(A))
+    else:
+        Ad, Bd, Aref, Bref = A, B, A, B
+    C = np.zeros((M, N), np.float32 if (dt == 0 or c_f32) else np.uint16)
+    assert L.lxo_gemm_nt(dt, a_f32, c_f32, small, ptr(Ad), ptr(Bd), ptr(C), M, N, K, K, K, N, None, 2, ctypes.c_float(0.1), 0, None) == 0
+    ref = np.tanh(0.1 * Aref.astype(np.float64) @ Bref.astype(np.float64).T)
+    out = C if C.dtype == np.float32 else bf16_to_f32(C)
+    assert np.abs(out - ref).max() < (1e-5 if C.dtype == np.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dt,a_f32,b_f32", [(0, 1, 1), (1, 0, 0), (1, 1, 0), (1, 0, 1)])
+def test_gemm_tn(dt, a_f32, b_f32):
+    L = lib()
+    M, I, J = 100, 72, 40
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((M, I)).astype(np.float32); B = rng.standard_normal((M, J)).astype(np.float32)
+    if dt == 1:
+        Ad = A if a_f32 else f32_to_bf16(A); Bd = B if b_f32 else f32_to_bf16(B)
+        Aref, Bref = bf16_to_f32(f32_to_bf16(A)), bf16_to_f32(f32_to_bf16(B))
+    else:
+        Ad, Bd, Aref, Bref = A, B, A, B
+    Ap = np.concatenate([Ad.reshape(-1), np.zeros(64, Ad.dtype)]); Bp = np.concatenate([Bd.reshape(-1), np.zeros(64, Bd.dtype)])
+    C0 = rng.standard_normal((I, J)).astype(np.float32); C = C0.copy()
+    assert L.lxo_gemm_tn(dt, a_f32, b_f32, ptr(Ap), ptr(Bp), ptr(C), M, I, J, I, J, J, 2, 1, None) == 0
+    ref = C0 + Aref.astype(np.float64).T @ Bref.astype(np.float64)
+    assert np.abs(C - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def _run(dtype):
+    img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
+    S = Sim(2, 32, 48, f.shape[1], 11, dtype=dtype, seed=0)
+    S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+    S.ck(S.L.lxo_decoder_train_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), None), "dec")
+    S.ck(S.L.lxo_ce_loss_fwd_bwd(S.sref(), ptr(S.ws), ptr(f), ptr(l), ctypes.c_float(1.0 / int(l.sum())), None), "loss")
+    return S, img, f, l
+
+
+def test_forward_backward_f32_vs_golden():
+    S, img, f, l = _run(0)
+    T = f.shape[1]
+    logits = S.region("logits", np.float32, (T, 2, 32))[:, :, :11].transpose(1, 0, 2)
+    assert np.abs(logits - GOLD["logits"]).max() < 2e-5
+    st = S.region("loss", np.float32)[:2]
+    assert abs(st[0] / st[1] - float(GOLD["loss"])) < 2e-6 and st[1] == int(GOLD["n_words"])
+    alpha = S.region("alpha", np.float32, (T, 2, 8))[:, :, :8].transpose(1, 0, 2)
+    assert np.abs(alpha - GOLD["alpha"]).max() < 1e-6
+    S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), None), "decbwd")
+    S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, None), "encbwd")
+    checked = 0
+    for k, _, _ in S.specs:
+        key = k.replace("/", "__")
+        if key in GOLD.files:
+            g, r = S.grad(k), GOLD[key]
+            assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1e-6) + 1e-9, k
+            checked += 1
+    assert checked >= 9
+
+
+def test_forward_bf16_within_loss_bar():
+    S, img, f, l = _run(1)
+    st = S.region("loss", np.float32)[:2]
+    assert abs(st[0] / st[1] - float(GOLD["loss"])) / float(GOLD["loss"]) < 1e-3       # north_star loss bar
+
+
+def test_greedy_and_beam_f32_vs_golden():
+    img = GOLD["img"]
+    S = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, max_steps=9)
+    S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+    ids = np.zeros((2, 9), np.int32); steps = ctypes.c_int(0)
+    S.ck(S.L.lxo_greedy_decode(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), 10, 8, ptr(ids), ctypes.byref(steps), None), "greedy")
+    assert steps.value == GOLD["greedy_ids"].shape[1]
+    assert np.array_equal(ids[:, :steps.value], GOLD["greedy_ids"])
+    S2 = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, beam=2, max_steps=9)
+    S2.ck(S2.L.lxo_encoder_fwd(S2.sref(), ptr(S2.params), ptr(S2.wpack), ptr(S2.ws), ptr(img), None), "enc")
+    bids = np.zeros((2, 9, 2), np.int32); bpar = np.zeros((2, 9, 2), np.int32)
+    S2.ck(S2.L.lxo_beam_decode(S2.sref(), ptr(S2.params), ptr(S2.wpack), ptr(S2.ws), 10, 8, ptr(bids), ptr(bpar), ctypes.byref(steps), None), "beam")
+    n = steps.value
+    assert n == GOLD["beam_ids"].shape[1]
+    assert np.array_equal(bids[:, :n], GOLD["beam_ids"]) and np.array_equal(bpar[:, :n], GOLD["beam_parents"])
+
+
+def test_adam_and_clip():
+    L = lib()
+    rng = np.random.default_rng(0)
+    n = 1000
+    p = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); sc = np.zeros(4, np.float32)
+    p0 = p.copy()
+    assert L.lxo_global_norm_scale(n, ptr(g), ctypes.c_float(5.0), ptr(sc), None) == 0
+    gn = np.sqrt((g.astype(np.float64) ** 2).sum())
+    assert abs(sc[1] - gn) / gn < 1e-6 and abs(sc[0] - 5.0 / max(gn, 5.0)) < 1e-6
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert L.lxo_adam_step(n, ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_float(lr_t), ctypes.c_float(0.9), ctypes.c_float(0.999),
+                           ctypes.c_float(1e-8), ptr(sc), None) == 0
+    gs = g * sc[0]
+    want = p0 - lr_t * (0.1 * gs) / (np.sqrt(0.001 * gs * gs) + 1e-8)
+    assert np.abs(p - want).max() < 1e-6

@@ -1,0 +1,83 @@
+"""CPU: the kept host surface (Config / Vocab / batching / LRSchedule) against golden vectors
+produced by the reference's own modules (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+
+from latex_ocr_amd.model.utils import general as G, text as T, image as I
+from latex_ocr_amd.model.utils.lr_schedule import LRSchedule
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_surface.json")))
+
+
+def test_minibatches():
+    data = [(i, [i, i + 1]) for i in range(11)]
+    for bs, want in GOLD["minibatches"].items():
+        got = [[list(x), list(y)] for x, y in G.minibatches(iter(data), int(bs))]
+        assert got == want
+    assert list(G.minibatches(iter([]), 4)) == []
+
+
+def test_pad_batch_formulas():
+    g = GOLD["pad_batch_formulas"]
+    f, l = T.pad_batch_formulas(g["in"], 48, 49)
+    assert f.tolist() == g["out"] and l.tolist() == g["len"] and str(f.dtype) == g["dtype"]
+
+
+def test_pad_batch_images_and_greyscale():
+    g = GOLD["pad_batch_images"]
+    out = I.pad_batch_images([np.asarray(a, np.uint8) for a in g["in"]])
+    assert out.tolist() == g["out"] and str(out.dtype) == g["dtype"]
+    g = GOLD["greyscale"]
+    assert I.greyscale(np.asarray(g["in"], np.uint8)).tolist() == g["out"]
+
+
+def test_vocab(tmp_path):
+    g = GOLD["vocab"]
+    vp = str(tmp_path / "vocab.txt")
+    T.write_vocab(g["tokens"], vp)
+    assert open(vp).read() == g["file"]
+    v = T.Vocab(G.Config({"unk": "_UNK", "pad": "_PAD", "end": "_END", "path_vocab": vp}))
+    assert v.tok_to_id == g["tok_to_id"] and v.n_tok == g["n_tok"]
+    assert (v.id_unk, v.id_pad, v.id_end) == (g["id_unk"], g["id_pad"], g["id_end"]) == (v.n_tok - 3, v.n_tok - 2, v.n_tok - 1)
+    assert v.form_prepro(g["prepro_in"]) == g["prepro_out"]
+
+
+def test_build_vocab():
+    ds = [(None, ["a", "b", "a"]), (None, ["b", "c", "a"])]
+    assert T.build_vocab([ds], min_count=2) == ["a", "b"]
+
+
+def test_lr_schedule_traces():
+    for tr in GOLD["lr_schedule"]:
+        s = LRSchedule(**tr["kw"])
+        lrs = [s.lr]
+        scores = [-3.0, -2.5, -2.6, -2.7, -2.4, -2.9] if tr["kw"].get("decay_rate") else None
+        for i in range(len(tr["lrs"]) - 1):
+            s.update(batch_no=i)
+            if scores is not None and i % 5 == 4:
+                s.update(score=scores[i // 5])
+            lrs.append(s.lr)
+        assert lrs == tr["lrs"]            # bit-for-bit (same float64 operation order)
+        assert bool(s.stop_training) == tr["stop"]
+
+
+def test_config_merge(tmp_path):
+    a, b = str(tmp_path / "a.json"), str(tmp_path / "b.json")
+    json.dump({"export_name": "a.json", "x": 1, "y": 2}, open(a, "w"))
+    json.dump({"export_name": "b.json", "y": 3, "z": {"k": 4}}, open(b, "w"))
+    c = G.Config([a, b])
+    assert {"x": c.x, "y": c.y, "z": c.z, "export_name": c.export_name} == GOLD["config_merge"]
+    c.save(str(tmp_path / "out") + "/")
+    assert sorted(os.listdir(str(tmp_path / "out"))) == ["a.json", "b.json"]
+
+
+def test_eval_text():
+    from latex_ocr_amd.model.evaluation import text as E
+    assert E.truncate_end([3, 4, 9, 5, 9], 9) == [3, 4]
+    assert E.levenshtein("kitten", "sitting") == 3
+    refs, hyps = [["a", "b", "c", "d", "e"], ["x", "y"]], [["a", "b", "c", "d", "e"], ["x", "z"]]
+    assert E.exact_match_score(refs, hyps) == 0.5
+    assert abs(E.edit_distance(refs, hyps) - (1 - 1 / 7.0)) < 1e-12
+    assert E.bleu_score([["a", "b", "c", "d", "e"]], [["a", "b", "c", "d", "e"]]) == 1.0

@@ -1,0 +1,106 @@
+"""CPU: the oracle itself.  PARITY UNPINNED against the reference (TF-1.12 graph cannot run,
+no golden vectors ship with it), so the oracle is held to: the geometry known-answers of
+SURVEY.md section 4, an independent float64 NumPy restatement, committed golden outputs
+(drift), and closed-form checks of the TF-specific semantics it encodes."""
+import os
+
+import numpy as np
+import torch
+
+from latex_ocr_amd.model import params as PP
+from oracle import np_micro as M
+from oracle import ref_model as R
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_small.npz"))
+
+
+def test_geometry_known_answers():
+    assert R.out_hw(128, 128) == (14, 14)          # dirty/test.ipynb cell 3
+    assert R.out_hw(40, 240) == (3, 28)            # visualize_attention.ipynb cells 10-11
+    assert R.out_hw(128, 512) == (14, 62) and R.out_hw(32, 128) == (2, 14)
+    assert PP.out_hw(128, 512) == (14, 62)
+    P = R.init_params(11, 0)
+    enc = R.encoder(P, torch.zeros(1, 40, 240, 1, dtype=torch.uint8))
+    assert tuple(enc.shape) == (1, 3, 28, 512)
+
+
+def test_param_inventory():
+    assert PP.n_params(500) == 8633488 and PP.n_params(50) == 8367088
+    a, b = R.init_params(13, 3), PP.init_params(13, 3)
+    assert list(a.keys()) == list(b.keys())
+    assert all(np.array_equal(a[k].numpy(), b[k]) for k in a)
+    emb = b["Decoder/embedding_table"]
+    assert np.allclose((emb ** 2).sum(-1), 1.0, atol=1e-6)                  # decoder.py:98-105
+
+
+def test_timing_signal_layout():
+    sig = R.timing_signal_2d(3, 5, 512).numpy()
+    inv = np.exp(-np.arange(128) * (np.log(1e4) / 127))
+    assert np.allclose(sig[2, 4, 0:128], np.sin(2 * inv), atol=1e-6)
+    assert np.allclose(sig[2, 4, 128:256], np.cos(2 * inv), atol=1e-6)
+    assert np.allclose(sig[2, 4, 256:384], np.sin(4 * inv), atol=1e-6)
+    assert np.allclose(sig[2, 4, 384:512], np.cos(4 * inv), atol=1e-6)
+
+
+def test_against_golden_and_float64_restatement():
+    P = R.init_params(11, 0)
+    img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
+    enc = R.encoder(P, torch.from_numpy(img))
+    logits, alpha = R.decoder_train(P, enc, torch.from_numpy(f), True)
+    loss, _, _ = R.loss_fn(logits, torch.from_numpy(f), torch.from_numpy(l))
+    assert np.allclose(enc.numpy(), GOLD["enc"], atol=1e-5)
+    assert np.allclose(logits.numpy(), GOLD["logits"], atol=1e-5)
+    assert abs(float(loss) - float(GOLD["loss"])) < 1e-6
+    e64 = M.encoder(P, img)
+    lg64, al64 = M.decoder_train(P, e64, f)
+    l64 = M.loss_fn(lg64, f, l)
+    assert np.abs(e64 - GOLD["enc"]).max() < 2e-6
+    assert np.abs(lg64 - GOLD["logits"]).max() < 5e-6
+    assert np.abs(al64 - GOLD["alpha"]).max() < 1e-6
+    assert abs(l64[0] - float(GOLD["loss"])) < 1e-6 and l64[2] == int(GOLD["n_words"])
+    assert np.allclose(alpha.sum(-1).numpy(), 1.0, atol=1e-5)
+
+
+def test_decode_golden_and_beam1_equals_greedy():
+    P = R.init_params(11, 0)
+    img = torch.from_numpy(GOLD["img"])
+    ids = R.greedy_decode(P, img, 10, max_iter=8)
+    assert np.array_equal(ids.numpy(), GOLD["greedy_ids"])
+    assert ids.shape[1] <= 9                                  # at most max_iter + 1 steps
+    b1, _ = R.beam_decode(P, img, 10, 1, max_iter=8)
+    assert np.array_equal(b1[:, :, 0].numpy(), ids.numpy())
+    b2, p2 = R.beam_decode(P, img, 10, 2, max_iter=8)
+    assert np.array_equal(b2.numpy(), GOLD["beam_ids"]) and np.array_equal(p2.numpy(), GOLD["beam_parents"])
+    assert (p2[:, 0] == 0).all()                              # time 0 expands beam 0 only
+
+
+def test_gradients_golden():
+    P = R.init_params(11, 0)
+    _, G, _, _ = R.train_grads(P, torch.from_numpy(GOLD["img"]), torch.from_numpy(GOLD["formula"]), torch.from_numpy(GOLD["lengths"]))
+    for k, g in G.items():
+        key = k.replace("/", "__")
+        if key in GOLD.files:
+            assert np.allclose(g.numpy(), GOLD[key], rtol=1e-4, atol=1e-7), k
+
+
+def test_adam_tf_epsilon_placement():
+    P = {"w": torch.tensor([1.0, -2.0])}
+    G = {"w": torch.tensor([0.5, 1e-9])}
+    opt = R.AdamTF(P)
+    opt.step(P, G, 0.1)
+    lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    m, v = 0.1 * np.array([0.5, 1e-9]), 0.001 * np.array([0.25, 1e-18])
+    want = np.array([1.0, -2.0]) - lr_t * m / (np.sqrt(v) + 1e-8)
+    assert np.allclose(P["w"].numpy(), want, rtol=1e-6)
+    # differs from torch.optim.Adam for tiny gradients (epsilon inside the bias correction there)
+    assert abs(want[1] - (-2.0 - 0.1 * 1e-9 / (1e-9 + 1e-8))) > 1e-4
+
+
+def test_loss_masks_padding():
+    logits = torch.randn(2, 4, 7)
+    f = torch.tensor([[1, 2, 6, 5], [3, 6, 5, 5]], dtype=torch.int32)
+    l = torch.tensor([3, 2], dtype=torch.int32)
+    loss, ce, nw = R.loss_fn(logits, f, l)
+    lp = torch.log_softmax(logits, -1)
+    want = -(lp[0, 0, 1] + lp[0, 1, 2] + lp[0, 2, 6] + lp[1, 0, 3] + lp[1, 1, 6])
+    assert abs(float(ce) - float(want)) < 1e-5 and int(nw) == 5 and abs(float(loss) - float(want) / 5) < 1e-6
