@@ -129,7 +129,24 @@ def main():
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel family: the implicit-GEMM conv (MFMA bound) ----
-        roof = eng.time_conv_gemms(img) if hasattr(eng, "time_conv_gemms") else None
+        flops, secs, per = eng.time_conv_gemms(B, H, W)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "conv_nt_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"kernel": "gemm_nt_kernel<bf16, implicit-im2col>: conv2..conv6 forward + dgrad, 10 launches per step",
+                "bound": "mfma", "achieved": round(flops / secs / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": round(flops / secs / MFMA_BF16_PEAK, 4), "traffic": traffic,
+                "flops_per_launch": flops / 10.0, "avg_launch_us": round(secs / 10.0 * 1e6, 1), "launches": per}
+        c8 = lambda n: -(-(-(-(-(-n // 2)) // 2)) // 2)
+        Rr = (c8(H) - 2) * (c8(W) - 2)
+        nbytes, asec = eng.time_attention(B, Rr)
+        roof_att = {"kernel": "attn_fwd_part_kernel + attn_fwd_combine_kernel (one decoder step, B samples)", "bound": "hbm",
+                    "achieved": round(nbytes / asec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / asec / 8e12, 4),
+                    "traffic": None, "bytes_per_launch": nbytes, "avg_launch_us": round(asec * 1e6, 2)}
         out = {
             "metric": "formula-images/sec training step (batch 64, 128x512)", "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -139,8 +156,8 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "conv_roofline_fraction_e2e": round(GF_TRAIN_PER_IMG * (H * W / (128.0 * 512.0)) * value / world / MFMA_BF16_PEAK, 4),
         }
-        if roof is not None:
-            out["roofline"] = roof
+        out["roofline"] = roof
+        out["roofline_attention"] = roof_att
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

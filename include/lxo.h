@@ -37,6 +37,22 @@ int lxo_gemm_nt(int dt, int a_f32, int c_f32, int small, const void* A, const vo
 int lxo_gemm_tn(int dt, int a_f32, int b_f32, const void* A, const void* B, float* C,
                 int M, int I, int J, int lda, int ldb, int ldc, int nsplit, int atomic, void* stream);
 
+/* 3x3 stride-1 convolution as an implicit GEMM on the MFMA units (the tf.layers.conv2d call
+ * sites model/encoder.py:37-59): out[B,Ho,Wo,Cout] = act(conv(in[B,H,W,Cin]) + bias), NHWC,
+ * in/out/wpk in the compute dtype, wpk = [Cout][9*Cin] (tap-major, channel-minor).
+ * pad 1 + Ho=H,Wo=W is SAME; pad 0 + Ho=H-2,Wo=W-2 is VALID; pad 2 + Ho=H+2,Wo=W+2 is the
+ * dgrad of a VALID layer.  Cin % 64 == 0 (bf16) / % 32 (f32). */
+int lxo_conv3x3(int dt, const void* in, const void* wpk, const float* bias, void* out, int B, int H, int W,
+                int Cin, int Ho, int Wo, int Cout, int pad, int relu, void* stream);
+
+/* AttentionMechanism.context (model/components/attention_mechanism.py:46-94) for nv decoder rows:
+ * alpha = softmax_r(sum_k beta_k tanh(att_img[r,k] + att_h[k])), ctx = sum_r alpha_r img[r,:].
+ * att_img [nimg,R,E], img [nimg,R,C] compute dtype; row v uses image v / beam; alpha f32 [nv,Rp],
+ * Rp = (R+7)/8*8; ctx f32 [nv, ldctx]; part = scratch of nv*32*(C+2) floats. */
+int lxo_attention_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta,
+                      float* alpha, float* part, float* ctx, int ldctx, int nv, int R, int E, int C, int beam,
+                      void* stream);
+
 /* ---- the hot path proper ---- */
 
 /* Shape of one call.  H, W are the batch-max image extents after white padding

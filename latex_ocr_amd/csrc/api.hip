@@ -121,3 +121,33 @@ extern "C" int lxo_beam_decode(const lxo_shape* s, const float* params, const vo
     CHECK_LAUNCH(lxo_impl_beam_decode(P, params, wpack, ws, id_end, max_iter, ids_out, parents_out, steps_out, (hipStream_t)stream), "lxo_beam_decode");
     return 0;
 }
+
+extern "C" int lxo_conv3x3(int dt, const void* in, const void* wpk, const float* bias, void* out, int B, int H, int W,
+                           int Cin, int Ho, int Wo, int Cout, int pad, int relu, void* stream) {
+    GemmNT g; memset(&g, 0, sizeof(g));
+    g.A = in; g.Bp = wpk; g.C = out; g.conv = 1; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.pad = pad;
+    g.M = B * Ho * Wo; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
+    g.bias = bias; g.act = relu ? 1 : 0; g.alpha = 1.f; g.addend_rows = 1;
+    CHECK_LAUNCH(lxo_launch_gemm_nt(dt, 0, 0, 0, g, (hipStream_t)stream), "lxo_conv3x3");
+    return 0;
+}
+extern "C" int lxo_attention_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta,
+                                 float* alpha, float* part, float* ctx, int ldctx, int nv, int R, int E, int C, int beam,
+                                 void* stream) {
+    int nch = (512 + nv - 1) / nv; if (nch > 16) nch = 16;
+    const int by_rows = R / 32 > 0 ? R / 32 : 1; if (nch > by_rows) nch = by_rows;
+    const int need = (R + 1023) / 1024; if (nch < need) nch = need;
+    Slabs none = {nullptr, 0, 0, 0};
+    CHECK_LAUNCH(lxo_k_attn_fwd(dt, att_img, img, att_h, none, nullptr, beta, alpha, part, ctx, ldctx, nv, R, (R + 7) / 8 * 8, E, C, beam < 1 ? 1 : beam,
+                                nch, (hipStream_t)stream), "lxo_attention_fwd");
+    return 0;
+}
+
+// test / micro-benchmark entry: split-K slab GEMM (see gemm.hip)
+extern "C" int lxo_gemm_slab(int dt, const void* A, const void* Bp, float* slab, int M, int N, int K, int lda, int ldb, int ldc,
+                             long long slab_stride, void* stream) {
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.Bp = Bp; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = 1.f; p.addend_rows = 1;
+    CHECK_LAUNCH(lxo_launch_gemm_slab(dt, p, slab, slab_stride, (hipStream_t)stream), "lxo_gemm_slab");
+    return 0;
+}

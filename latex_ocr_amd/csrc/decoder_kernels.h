@@ -1,17 +1,20 @@
 // Launchers of the non-GEMM decoder / loss / optimizer / decode kernels.
 #pragma once
 #include "lxo_common.h"
+// split-K partial products of gemm_slab_kernel: value(row, col) = sum_{s<n} p[s*stride + row*ld + col]
+struct Slabs { const float* p; int n; long long stride; int ld; };
 int lxo_k_rowmean(int dt, const void* img, float* mean, int B, int R, int C, hipStream_t st);
 int lxo_k_embed_gather(int dt, const float* table, const float* start, const int* formula, void* out, int B, int T, int D, int Dp, int V, hipStream_t st);
 int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* ids, void* out, int n, int D, int Dp, int V, hipStream_t st);
-int lxo_k_lstm_fwd(const float* z, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st);
-int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, const float* dh1, int ld1, const float* dh2, int ld2,
+int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st);
+int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                    float* dcc, float* dz, int B, int U, hipStream_t st);
-int lxo_k_tanh_bwd(const float* a, int lda, const float* b, int ldb, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st);
-int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* part,
+int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st);
+int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st);
+int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
                    float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st);
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
-                   const float* dctx, int lddc, const float* ctx, int ldctx, float* de, float* datth,
+                   Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
                    int nv, int R, int Rp, int E, int C, int nch, hipStream_t st);
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
                    int T, int B, int R, int Rp, int E, hipStream_t st);
@@ -20,7 +23,7 @@ int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* le
                   int B, int T, int V, int Vp, hipStream_t st);
 int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t st);
 int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st);
-int lxo_k_init_bwd(const float* dcc, const float* dxh, int ldx, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st);
+int lxo_k_init_bwd(const float* dcc, Slabs dxh, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st);
 int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids_step, int* ids_out, int max_steps, int step,
                  int* finished, int* n_unfinished, hipStream_t st);
 int lxo_k_beam_step(const float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float* logp, int* finished,

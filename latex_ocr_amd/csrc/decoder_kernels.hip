@@ -20,6 +20,14 @@ LXO_DEV void load4(const bf16_t* p, float (&v)[4]) {
 LXO_DEV void store4(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = a; }
 LXO_DEV void store4(bf16_t* p, const float (&v)[4]) { u32x2 a = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}; *reinterpret_cast<u32x2*>(p) = a; }
 
+// sum of the n split-K partial products written by gemm_slab_kernel: value(row, col) = sum_s p[s*stride + row*ld + col]
+LXO_DEV float slab_sum(const Slabs& sl, long long row, int col) {
+    float v = 0.f;
+    const float* q = sl.p + row * sl.ld + col;
+    for (int s = 0; s < sl.n; ++s) v += q[(long long)s * sl.stride];
+    return v;
+}
+
 // mean over regions: img [B][R][C] -> mean [B][C]   (attention_mechanism.py:148)
 template <typename CT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const CT* __restrict__ img, float* __restrict__ mean, int R, int C) {
@@ -90,15 +98,20 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
 }
 
 // TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71)
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ z, const float* __restrict__ c_prev,
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ z, Slabs zs, const float* __restrict__ c_prev,
                                                       float* __restrict__ gates, float* __restrict__ c_out,
                                                       float* __restrict__ h_out, int ldh, int B, int U) {
     const int total = B * U;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int b = i / U, u = i - b * U;
         const float* zr = z + (long long)b * 4 * U;
-        const float gi = sigmoidf_(zr[u]), gj = tanhf(zr[U + u]);
-        const float gf = sigmoidf_(zr[2 * U + u] + 1.0f), go = sigmoidf_(zr[3 * U + u]);
+        float z0 = zr[u], z1 = zr[U + u], z2 = zr[2 * U + u], z3 = zr[3 * U + u];
+        for (int sI = 0; sI < zs.n; ++sI) {
+            const float* q = zs.p + (long long)sI * zs.stride + (long long)b * zs.ld;
+            z0 += q[u]; z1 += q[U + u]; z2 += q[2 * U + u]; z3 += q[3 * U + u];
+        }
+        const float gi = sigmoidf_(z0), gj = tanhf(z1);
+        const float gf = sigmoidf_(z2 + 1.0f), go = sigmoidf_(z3);
         const float c = gf * c_prev[i] + gi * gj;
         const float h = go * tanhf(c);
         if (gates) {
@@ -111,15 +124,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
-                                                      const float* __restrict__ c_cur, const float* __restrict__ dh1, int ld1,
-                                                      const float* __restrict__ dh2, int ld2, float* __restrict__ dcc,
-                                                      float* __restrict__ dz, int B, int U) {
+                                                      const float* __restrict__ c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
+                                                      float* __restrict__ dcc, float* __restrict__ dz, int B, int U) {
     const int total = B * U;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int b = i / U, u = i - b * U;
         const float* gr = gates + (long long)b * 4 * U;
         const float gi = gr[u], gj = gr[U + u], gf = gr[2 * U + u], go = gr[3 * U + u];
-        const float dh = dh1[(long long)b * ld1 + u] + dh2[(long long)b * ld2 + u];
+        const float dh = slab_sum(s1, b, u) + slab_sum(s3, b, u) + slab_sum(s4, b, off4 + u);
         const float tc = tanhf(c_cur[i]);
         const float dc = dcc[i] + dh * go * (1.f - tc * tc);
         float* dr = dz + (long long)b * 4 * U;
@@ -131,17 +143,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
     }
 }
 
-// g = (a + b) * (1 - o^2)      (backward through o = tanh(.), attention_cell.py:82)
-__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+// g = (d_o from the logits + d_o carry) * (1 - o^2)      (backward through o = tanh(.), attention_cell.py:82)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ a, int lda, Slabs carry,
                                                       const float* __restrict__ o, int ldo, float* __restrict__ g, int ldg,
                                                       int rows, int cols) {
     const int total = rows * cols;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int r = i / cols, c = i - r * cols;
         const float ov = o[(long long)r * ldo + c];
-        float d = a ? a[(long long)r * lda + c] : 0.f;
-        if (b) d += b[(long long)r * ldb + c];
+        const float d = a[(long long)r * lda + c] + slab_sum(carry, r, c);
         g[(long long)r * ldg + c] = d * (1.f - ov * ov);
+    }
+}
+// o = tanh(sum of the K4 slabs) -> rec      (attention_cell.py:82)
+__global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __restrict__ o, int ldo, int rows, int cols) {
+    const int total = rows * cols;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / cols, c = i - r * cols;
+        o[(long long)r * ldo + c] = tanhf(slab_sum(sl, r, c));
     }
 }
 
@@ -162,7 +181,8 @@ template <> LXO_DEV float tanh_ct<bf16_t>(float x) { return 1.f - 2.f * __builti
 
 template <typename CT>
 __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
-                                                           const float* __restrict__ att_h, const float* __restrict__ beta,
+                                                           const float* __restrict__ att_h, Slabs ahs, float* __restrict__ att_h_out,
+                                                           const float* __restrict__ beta,
                                                            float* __restrict__ alpha, float* __restrict__ part,
                                                            int R, int Rp, int E, int C, int beam, int nch, int rows_per) {
     __shared__ float sc[ATT_ROWS];
@@ -182,7 +202,15 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
         const bool kok = k0 < E;
         float ah[4], bt[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ah[j] = kok ? att_h[(long long)v * E + k0 + j] : 0.f; bt[j] = kok ? beta[k0 + j] : 0.f; }
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+            if (kok) a = ahs.n > 0 ? slab_sum(ahs, v, k0 + j) : att_h[(long long)v * E + k0 + j];
+            ah[j] = a; bt[j] = kok ? beta[k0 + j] : 0.f;
+        }
+        if (ahs.n > 0 && att_h_out && ch == 0 && wave == 0 && kok) {      // materialise att_h for the backward pass
+#pragma unroll
+            for (int j = 0; j < 4; ++j) att_h_out[(long long)v * E + k0 + j] = ah[j];
+        }
         for (int base = wave; base < n; base += ATT_W * ATT_U) {
             float x[ATT_U][4];
 #pragma unroll
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
 template <typename CT>
 __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, const float* __restrict__ beta,
-                                                           const float* __restrict__ alpha, const float* __restrict__ dctx, int lddc,
+                                                           const float* __restrict__ alpha, Slabs dcs, int dcoff, float* __restrict__ dctx_out, int lddc,
                                                            const float* __restrict__ ctx, int ldctx,
                                                            float* __restrict__ de, float* __restrict__ datth,
                                                            int R, int Rp, int E, int C, int rows_per) {
@@ -321,7 +349,11 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
     const int KC = (E + 255) >> 8;
     // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r
     float s = 0.f;
-    for (int c = tid; c < C; c += 512) s = fmaf(ctx[(long long)v * ldctx + c], dctx[(long long)v * lddc + c], s);
+    for (int c = tid; c < C; c += 512) {
+        const float d = slab_sum(dcs, v, dcoff + c);
+        if (ch == 0) dctx_out[(long long)v * lddc + c] = d;          // summed d_ctx, kept for the deferred d_img GEMM
+        s = fmaf(ctx[(long long)v * ldctx + c], d, s);
+    }
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
@@ -331,7 +363,7 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
     const int c0 = lane * 8;
     float dc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dc[e] = (c0 + e < C) ? dctx[(long long)v * lddc + c0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) dc[e] = (c0 + e < C) ? slab_sum(dcs, v, dcoff + c0 + e) : 0.f;
     for (int base = wave; base < n; base += ATT_W * ATT_U) {
         float x[ATT_U][8];
 #pragma unroll
@@ -548,7 +580,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
 }
 
 // dpre = d_s0 * (1 - s0^2) for s in (c, h, o) -> [B][U+U+O]   (attention_mechanism.py:151 backward)
-__global__ __launch_bounds__(256) void init_bwd_kernel(const float* __restrict__ dcc, const float* __restrict__ dxh, int ldx,
+__global__ __launch_bounds__(256) void init_bwd_kernel(const float* __restrict__ dcc, Slabs dxh,
                                                       const float* __restrict__ c0, const float* __restrict__ rec0, int ldr,
                                                       float* __restrict__ dpre, int B, int U, int O) {
     const int W = 2 * U + O;
@@ -557,8 +589,8 @@ __global__ __launch_bounds__(256) void init_bwd_kernel(const float* __restrict__
         const int b = i / W, k = i - b * W;
         float d, s;
         if (k < U) { d = dcc[(long long)b * U + k]; s = c0[(long long)b * U + k]; }
-        else if (k < 2 * U) { d = dxh[(long long)b * ldx + O + (k - U)]; s = rec0[(long long)b * ldr + O + (k - U)]; }
-        else { d = dxh[(long long)b * ldx + (k - 2 * U)]; s = rec0[(long long)b * ldr + (k - 2 * U)]; }
+        else if (k < 2 * U) { d = slab_sum(dxh, b, O + (k - U)); s = rec0[(long long)b * ldr + O + (k - U)]; }
+        else { d = slab_sum(dxh, b, k - 2 * U); s = rec0[(long long)b * ldr + (k - 2 * U)]; }
         dpre[i] = d * (1.f - s * s);
     }
 }
@@ -746,40 +778,44 @@ int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* 
     else LAUNCH((embed_rows_kernel<float>), g, table, start, ids, (float*)out, n, D, Dp, V);
     DONE;
 }
-int lxo_k_lstm_fwd(const float* z, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U), z, c_prev, gates, c_out, h_out, ldh, B, U);
+int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st) {
+    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U), z, zs, c_prev, gates, c_out, h_out, ldh, B, U);
     DONE;
 }
-int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, const float* dh1, int ld1, const float* dh2, int ld2,
+int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                    float* dcc, float* dz, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U), gates, c_prev, c_cur, dh1, ld1, dh2, ld2, dcc, dz, B, U);
+    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, B, U);
     DONE;
 }
-int lxo_k_tanh_bwd(const float* a, int lda, const float* b, int ldb, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st) {
-    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols), a, lda, b, ldb, o, ldo, g, ldg, rows, cols);
+int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st) {
+    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols), a, lda, carry, o, ldo, g, ldg, rows, cols);
     DONE;
 }
-int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, float* alpha, float* part,
+int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st) {
+    LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols), sl, o, ldo, rows, cols);
+    DONE;
+}
+int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
                    float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
-    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
-    else hipLaunchKernelGGL((attn_fwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
+    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
+    else hipLaunchKernelGGL((attn_fwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
     DONE;
 }
 // datth must be zero on entry (chunks accumulate with atomics)
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
-                   const float* dctx, int lddc, const float* ctx, int ldctx, float* de, float* datth,
+                   Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
                    int nv, int R, int Rp, int E, int C, int nch, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
-    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
-    else hipLaunchKernelGGL((attn_bwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, beta, alpha, dctx, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
+    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
+    else hipLaunchKernelGGL((attn_bwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
     DONE;
 }
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
@@ -809,8 +845,8 @@ int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, fl
     LAUNCH(embed_scatter_kernel, grid1((long long)T * B * D), demb, formula, dtable, dstart, B, T, D, V);
     DONE;
 }
-int lxo_k_init_bwd(const float* dcc, const float* dxh, int ldx, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st) {
-    LAUNCH(init_bwd_kernel, grid1((long long)B * (2 * U + O)), dcc, dxh, ldx, c0, rec0, ldr, dpre, B, U, O);
+int lxo_k_init_bwd(const float* dcc, Slabs dxh, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st) {
+    LAUNCH(init_bwd_kernel, grid1((long long)B * (2 * U + O)), dcc, dxh, c0, rec0, ldr, dpre, B, U, O);
     DONE;
 }
 int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids_step, int* ids_out, int max_steps, int step,

@@ -41,3 +41,6 @@ struct GemmTN {
 // small != 0 selects the 64x64 tile (M <= 64 step GEMMs).
 int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p, hipStream_t s);
 int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_t s);
+
+// split-K partial products: slab[ks][M][ldc] = A[:, ks*128:(ks+1)*128] * Bp[:, same]^T, ks < K/128 (A float)
+int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s);

@@ -522,6 +522,99 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmNT p) {
     }
 }
 
+// --------------------------------------------------------------- slab ----
+// Split-K variant for the recurrent steps: grid (N/64, K/128, M/64).  Every workgroup
+// issues ALL its loads at once (A 64x128 f32 coalesced, B 64x128 compute dtype), converts
+// through LDS and writes one partial 64x64 tile to slab[ks] (plain stores, no atomics);
+// the consumer kernel adds the KS slabs.  One memory round trip per GEMM.
+template <typename CT>
+__global__ __launch_bounds__(256) void gemm_slab_kernel(GemmNT p, float* __restrict__ slab, long long slab_stride) {
+    constexpr bool BF = is_bf16<CT>::value;
+    constexpr int KQ = 128;
+    constexpr int PITCH = BF ? KQ + 8 : KQ + 1;
+    __shared__ __attribute__((aligned(16))) CT As[64 * PITCH];
+    __shared__ __attribute__((aligned(16))) CT Bs[64 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 64, ks = blockIdx.y, m0 = blockIdx.z * 64;
+    const int kb = ks * KQ;
+    const float* __restrict__ A = reinterpret_cast<const float*>(p.A);
+    const CT* __restrict__ Bp = reinterpret_cast<const CT*>(p.Bp);
+    // A: 64 rows x 128 floats = 2048 float4 -> 8 per thread (a wave reads 2 full rows per instruction)
+    f32x4 ra[8];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+        const int m = m0 + row;
+        ra[j] = m < p.M ? *reinterpret_cast<const f32x4*>(A + (long long)m * p.lda + kb + c4) : z4;
+    }
+    if constexpr (BF) {
+        u32x4 rb[4];
+        const u32x4 zb = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 4, c8 = (idx & 15) * 8;
+            const int n = n0 + row;
+            rb[j] = n < p.N ? *reinterpret_cast<const u32x4*>(Bp + (long long)n * p.ldb + kb + c8) : zb;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+            u32x2 v = {pack_bf2(ra[j][0], ra[j][1]), pack_bf2(ra[j][2], ra[j][3])};
+            *reinterpret_cast<u32x2*>(&As[row * PITCH + c4]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 4, c8 = (idx & 15) * 8;
+            *reinterpret_cast<u32x4*>(&Bs[row * PITCH + c8]) = rb[j];
+        }
+    } else {
+        f32x4 rb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+            const int n = n0 + row;
+            rb[j] = n < p.N ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Bp) + (long long)n * p.ldb + kb + c4) : z4;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { As[row * PITCH + c4 + e] = ra[j][e]; Bs[row * PITCH + c4 + e] = rb[j][e]; }
+        }
+    }
+    __syncthreads();
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (BF) {
+#pragma unroll
+        for (int s8 = 0; s8 < KQ / 16; ++s8) {
+            const int kof = s8 * 16 + (lane >> 5) * 8;
+            const u32x4 af = *reinterpret_cast<const u32x4*>(&As[(wm * 32 + (lane & 31)) * PITCH + kof]);
+            const u32x4 bfr = *reinterpret_cast<const u32x4*>(&Bs[(wn * 32 + (lane & 31)) * PITCH + kof]);
+            acc = mfma_bf16(af, bfr, acc);
+        }
+    } else {
+#pragma unroll 8
+        for (int s2 = 0; s2 < KQ / 2; ++s2) {
+            const int kof = s2 * 2 + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(wm * 32 + (lane & 31)) * PITCH + kof],
+                                                       Bs[(wn * 32 + (lane & 31)) * PITCH + kof], acc, 0, 0, 0);
+        }
+    }
+    float* __restrict__ out = slab + (long long)ks * slab_stride;
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n < p.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < p.M) out[(long long)m * p.ldc + n] = acc[r];
+        }
+    }
+}
+
 template <typename CT>
 int launch_skinny(const GemmNT& p, hipStream_t s) {
     dim3 grid(cdiv(p.N, 32), cdiv(p.M, 64));
@@ -587,4 +680,12 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
     if (a_f32 && !b_f32) return launch_tn<bf16_t, false, float, bf16_t>(p, s);
     if (a_f32 && b_f32) return launch_tn<bf16_t, false, float, float>(p, s);
     return launch_tn<bf16_t, false, bf16_t, float>(p, s);
+}
+
+int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s) {
+    if (p.K % 128 != 0 || p.lda % 4 != 0) return -2;
+    dim3 grid(cdiv(p.N, 64), p.K / 128, cdiv(p.M, 64));
+    if (dt == LXO_F32) hipLaunchKernelGGL((gemm_slab_kernel<float>), grid, dim3(256), 0, s, p, slab, slab_stride);
+    else hipLaunchKernelGGL((gemm_slab_kernel<bf16_t>), grid, dim3(256), 0, s, p, slab, slab_stride);
+    return (int)hipGetLastError();
 }

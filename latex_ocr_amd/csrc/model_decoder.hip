@@ -30,6 +30,14 @@ int tn(const Plan& P, bool a_f32, bool b_f32, const void* A, int lda, const void
     if (P.s.dtype == LXO_F32) { a_f32 = true; b_f32 = true; }
     return lxo_launch_gemm_tn(P.s.dtype, a_f32, b_f32, g, st);
 }
+// split-K partial products slab[ks] = A[:, ks*128:+128] * Bp^T  (one memory round trip; consumers add the slabs)
+int slab(const Plan& P, const float* A, int lda, const void* Bp, int ldb, float* out, int M, int N, int K, hipStream_t st) {
+    GemmNT g; memset(&g, 0, sizeof(g));
+    g.A = A; g.Bp = Bp; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N; g.alpha = 1.f; g.addend_rows = 1;
+    return lxo_launch_gemm_slab(P.s.dtype, g, out, (long long)M * N, st);
+}
+Slabs view(const float* p, int K, int M, int N) { Slabs s = {p, K / 128, (long long)M * N, N}; return s; }
+const Slabs kNoSlabs = {nullptr, 0, 0, 0};
 }  // namespace
 
 // att_img projection + initial states (attention_mechanism.py:19-43, 124-153; attention_cell.py:51-56)
@@ -62,20 +70,24 @@ static int attention_prepare(const Plan& P, const float* prm, const void* wp, vo
 }
 
 // One AttentionCell.step (attention_cell.py:58-89) for nv rows.  zx_t must already hold
-// emb_t * K[0:D] + b; rec_prev/cs_prev = state t-1, rec_cur/cs_cur receive state t.
+// emb_t * K[0:D] + b; rec_prev/cs_prev = state t-1 (o final), rec_cur/cs_cur receive state t.
+// Every GEMM is a split-K slab GEMM; the kernel that consumes a product adds its slabs.
 static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam,
-                     float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
+                     const float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
                      float* gates_t, float* atth_t, float* alpha_t, hipStream_t st) {
     const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
+    float* s1 = P.ws<float>(ws, W_S_K1); float* s2 = P.ws<float>(ws, W_S_K2); float* s4 = P.ws<float>(ws, W_S_K4);
     // z = zx + [o_prev, h_prev] K[D:]            (attention_cell.py:70-71)
-    RC(nt(P, true, true, true, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, zx_t, 4 * U, nv, 4 * U, P.XH, nullptr, 0, true, st));
-    RC(lxo_k_lstm_fwd(zx_t, cs_prev, gates_t, cs_cur, rec_cur + O, P.REC, nv, U, st));
+    RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, s1, nv, 4 * U, P.XH, st));
+    RC(lxo_k_lstm_fwd(zx_t, view(s1, P.XH, nv, 4 * U), cs_prev, gates_t, cs_cur, rec_cur + O, P.REC, nv, U, st));
     // att_h = h W                                 (attention_mechanism.py:79)
-    RC(nt(P, true, true, true, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, atth_t, E, nv, E, U, nullptr, 0, false, st));
-    RC(lxo_k_attn_fwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), atth_t, prm + P.poff[P_BETA], alpha_t,
-                      P.ws<float>(ws, W_APART), rec_cur + P.XH, P.REC, nv, P.R, P.Rp, E, C, beam, P.attn_chunks(nv), st));
+    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, s2, nv, E, U, st));
+    RC(lxo_k_attn_fwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), nullptr, view(s2, U, nv, E), atth_t,
+                      prm + P.poff[P_BETA], alpha_t, P.ws<float>(ws, W_APART), rec_cur + P.XH, P.REC, nv, P.R, P.Rp, E, C, beam,
+                      P.attn_chunks(nv), st));
     // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
-    RC(nt(P, true, true, true, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, rec_cur, P.REC, nv, O, P.HC, nullptr, 2, false, st));
+    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, s4, nv, O, P.HC, st));
+    RC(lxo_k_tanh_finalize(view(s4, P.HC, nv, O), rec_cur, P.REC, nv, O, st));
     return 0;
 }
 
@@ -115,7 +127,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     float* dolog = P.ws<float>(ws, W_DOLOG); float* gall = P.ws<float>(ws, W_G); float* dhc = P.ws<float>(ws, W_DHC);
     float* de = P.ws<float>(ws, W_DE); float* datth = P.ws<float>(ws, W_DATTH); float* dz = P.ws<float>(ws, W_DZ);
-    float* dxh = P.ws<float>(ws, W_DXH); float* dcc = P.ws<float>(ws, W_DCC);
+    float* dcc = P.ws<float>(ws, W_DCC);
     float* gates = P.ws<float>(ws, W_GATES); float* atth = P.ws<float>(ws, W_ATTH); float* alpha = P.ws<float>(ws, W_ALPHA);
     const void* dlog = P.ws<void>(ws, W_DLOGITS);
 
@@ -123,28 +135,30 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
     RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
 
-    HIPRC(hipMemsetAsync(dxh, 0, (size_t)B * P.XH * 4, st));
     HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
     HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));     // attention chunks accumulate d_att_h with atomics
     const int nchb = P.attn_chunks(B);
+    float* sb1 = P.ws<float>(ws, W_S_B1); float* sb3 = P.ws<float>(ws, W_S_B3); float* sb4 = P.ws<float>(ws, W_S_B4);
     for (int t = T - 1; t >= 0; --t) {
         const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
         float* g_t = gall + (size_t)t * B * O;
         float* dhc_t = dhc + (size_t)t * B * P.HC;
+        // carry [d_o | d_h] from step t+1 = the B4 slabs of the previous iteration (none at t = T-1)
+        const Slabs carry = (t == T - 1) ? kNoSlabs : view(sb4, 4 * U, B, P.XH);
         // g = (d_o_logits + d_o_carry) * (1 - o^2)
-        RC(lxo_k_tanh_bwd(dolog + (size_t)t * B * O, O, dxh, P.XH, rec_cur, P.REC, g_t, O, B, O, st));
+        RC(lxo_k_tanh_bwd(dolog + (size_t)t * B * O, O, carry, rec_cur, P.REC, g_t, O, B, O, st));
         // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
-        RC(nt(P, true, true, true, g_t, O, P.pk(wp, K_OW), O, dhc_t, P.HC, B, P.HC, O, nullptr, 0, false, st));
+        RC(slab(P, g_t, O, P.pk(wp, K_OW), O, sb1, B, P.HC, O, st));
         RC(lxo_k_attn_bwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), atth + (size_t)t * B * E, prm + P.poff[P_BETA],
-                          alpha + (size_t)t * B * P.Rp, dhc_t + U, P.HC, rec_cur + P.XH, P.REC,
+                          alpha + (size_t)t * B * P.Rp, view(sb1, O, B, P.HC), U, dhc_t + U, P.HC, rec_cur + P.XH, P.REC,
                           de + (size_t)t * B * P.Rp, datth + (size_t)t * B * E, B, P.R, P.Rp, E, C, nchb, st));
-        // d_h carry += d_att_h W_att_h^T   (accumulates onto the carry written by the previous iteration)
-        RC(nt(P, true, true, true, datth + (size_t)t * B * E, E, P.pk(wp, K_ATT_H), E, dxh + O, P.XH, B, U, E, nullptr, 0, true, st));
+        // d_h += d_att_h W_att_h^T
+        RC(slab(P, datth + (size_t)t * B * E, E, P.pk(wp, K_ATT_H), E, sb3, B, U, E, st));
         RC(lxo_k_lstm_bwd(gates + (size_t)t * B * 4 * U, cs + (size_t)t * B * U, cs + (size_t)(t + 1) * B * U,
-                          dhc_t, P.HC, dxh + O, P.XH, dcc, dz + (size_t)t * B * 4 * U, B, U, st));
+                          view(sb1, O, B, P.HC), view(sb3, E, B, U), carry, O, dcc, dz + (size_t)t * B * 4 * U, B, U, st));
         // [d_o carry | d_h carry] = d_z K[D:]^T
-        RC(nt(P, true, true, true, dz + (size_t)t * B * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
-              dxh, P.XH, B, P.XH, 4 * U, nullptr, 0, false, st));
+        RC(slab(P, dz + (size_t)t * B * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
+                sb4, B, P.XH, 4 * U, st));
     }
     // ---- deferred weight gradients over all steps ----
     RC(tn(P, true, true, rec + (size_t)B * P.REC + O, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));       // d[o_W_h; o_W_c]
@@ -159,7 +173,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     // ---- initial states ----
     float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
     const int W3 = 2 * U + O;
-    RC(lxo_k_init_bwd(dcc, dxh, P.XH, cs, rec, P.REC, dpre, B, U, O, st));
+    RC(lxo_k_init_bwd(dcc, view(sb4, 4 * U, B, P.XH), cs, rec, P.REC, dpre, B, U, O, st));
     RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, st));
     RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, st));
     RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, st));

@@ -26,6 +26,7 @@ static const char* kWsNames[W_COUNT] = {
     "att_img", "att_part", "mean", "emb_in", "zx", "rec", "cs", "gates", "att_h", "alpha", "logits",
     "dlogits", "loss", "do_log", "g", "dhc", "de", "datth", "dz", "dxh", "dcc", "d_img", "d_att_img",
     "d_emb", "dpre0", "dmean", "g0", "g1", "gnorm",
+    "s_k1", "s_k2", "s_k4", "s_b1", "s_b3", "s_b4",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
@@ -122,6 +123,12 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     for (size_t c : cand) if (c > gmax) gmax = c;
     wb[W_G0] = gmax; wb[W_G1] = gmax;
     wb[W_GNORM] = 64;
+    wb[W_S_K1] = (size_t)(XH / 128) * BK_ * 4 * U * f4;
+    wb[W_S_K2] = (size_t)(U / 128) * BK_ * E * f4;
+    wb[W_S_K4] = (size_t)(HC / 128) * BK_ * O * f4;
+    wb[W_S_B1] = (size_t)(O / 128) * BL * HC * f4;
+    wb[W_S_B3] = (size_t)(E / 128) * BL * U * f4;
+    wb[W_S_B4] = (size_t)(4 * U / 128) * BL * XH * f4;
     const int ms = s.max_steps > 0 ? s.max_steps : 0;
     if (ms > 0) {
         wb[W_DEC_IDS] = BK_ * ms * 4;
@@ -160,8 +167,8 @@ int Plan::validate(char* msg, size_t n) const {
     BAD(s.B <= 0 || s.H <= 0 || s.W <= 0, "B/H/W must be positive");
     BAD(Hp <= 0 || Wp <= 0, "image too small: need ceil(H/8) >= 3 and ceil(W/8) >= 3");
     BAD(s.V < 4, "V < 4");
-    BAD(s.C != 512 && s.C != 256 && s.C != 128 && s.C != 64, "C must be 64/128/256/512");
-    BAD(s.E % 64 || s.U % 64 || s.O % 64 || s.E <= 0 || s.U <= 0 || s.O <= 0, "E, U, O must be positive multiples of 64");
+    BAD(s.C != 512 && s.C != 256 && s.C != 128, "C must be 128/256/512");
+    BAD(s.E % 128 || s.U % 128 || s.O % 128 || s.E <= 0 || s.U <= 0 || s.O <= 0, "E, U, O must be positive multiples of 128");
     BAD(s.D % 8 || s.D <= 0, "D must be a positive multiple of 8");
     BAD(s.dtype != LXO_F32 && s.dtype != LXO_BF16, "dtype");
     BAD(s.E > 1024 || s.C > 512, "E <= 1024, C <= 512");

@@ -212,6 +212,70 @@ class Engine(object):
         s = self.loss(lengths, 1.0 / max(n, 1)).cpu().numpy()
         return float(s[0]), n
 
+    # ------------------------------------------------------ measurement aids --
+    def time_conv_gemms(self, B, H, W, reps=5):
+        """HIP-event timing (on the stream the kernels are launched on) of the implicit-GEMM conv
+        kernel for the ten launches one training step makes with it: conv2..conv6 forward and
+        dgrad.  Returns (sum of algorithmic FLOPs, sum of average launch seconds, per-launch list)."""
+        assert self.dtype == _abi.LXO_BF16
+        c = lambda n: -(-n // 2)
+        H1, W1 = c(H), c(W); H2, W2 = c(H1), c(W1); H4 = c(H2); W5 = c(W2)
+        C = self.dims["C"]
+        layers = [("conv2", H1, W1, 64, 128, 1), ("conv3", H2, W2, 128, 256, 1), ("conv4", H2, W2, 256, 256, 1),
+                  ("conv5", H4, W2, 256, C, 1), ("conv6", H4, W5, C, C, 0)]
+        bf = dict(dtype=torch.bfloat16, device=self.device)
+        st = self._stream()
+        out, flops_tot, t_tot = [], 0.0, 0.0
+        for name, h, w, ci, co, same in layers:
+            ho, wo = (h, w) if same else (h - 2, w - 2)
+            for kind in ("fwd", "dgrad"):
+                if kind == "fwd":
+                    x = torch.randn(B, h, w, ci, **bf); wp = torch.randn(co, 9 * ci, **bf) * 0.05
+                    y = torch.empty(B, ho, wo, co, **bf)
+                    args = (self.dtype, _p(x), _p(wp), None, _p(y), B, h, w, ci, ho, wo, co, 1 if same else 0, 1, st)
+                    flops = 2.0 * B * ho * wo * co * 9 * ci
+                else:
+                    x = torch.randn(B, ho, wo, co, **bf); wp = torch.randn(ci, 9 * co, **bf) * 0.05
+                    y = torch.empty(B, h, w, ci, **bf)
+                    args = (self.dtype, _p(x), _p(wp), None, _p(y), B, ho, wo, co, h, w, ci, 1 if same else 2, 0, st)
+                    flops = 2.0 * B * h * w * ci * 9 * co
+                for _ in range(2):
+                    self._ck(self.lib.lxo_conv3x3(*args), "conv3x3")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.device))
+                for _ in range(reps):
+                    self._ck(self.lib.lxo_conv3x3(*args), "conv3x3")
+                e1.record(torch.cuda.current_stream(self.device))
+                e1.synchronize()
+                sec = e0.elapsed_time(e1) * 1e-3 / reps
+                out.append({"launch": name + "_" + kind, "us": round(sec * 1e6, 1), "tflops": round(flops / sec / 1e12, 1)})
+                flops_tot += flops; t_tot += sec
+        return flops_tot, t_tot, out
+
+    def time_attention(self, B, R, reps=20):
+        """HIP-event timing of the attention stream (scores + softmax + context) for B samples."""
+        E, C = self.dims["E"], self.dims["C"]
+        ct = torch.bfloat16 if self.dtype == _abi.LXO_BF16 else torch.float32
+        att_img = torch.randn(B, R, E, dtype=ct, device=self.device)
+        img = torch.randn(B, R, C, dtype=ct, device=self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        att_h = torch.randn(B, E, **f32); beta = torch.randn(E, **f32) * 0.1
+        Rp = (R + 7) // 8 * 8
+        alpha = torch.empty(B, Rp, **f32); part = torch.empty(B * 32 * (C + 2), **f32); ctx = torch.empty(B, C, **f32)
+        st = self._stream()
+        args = (self.dtype, _p(att_img), _p(img), _p(att_h), _p(beta), _p(alpha), _p(part), _p(ctx), C, B, R, E, C, 1, st)
+        for _ in range(3):
+            self._ck(self.lib.lxo_attention_fwd(*args), "attention_fwd")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        for _ in range(reps):
+            self._ck(self.lib.lxo_attention_fwd(*args), "attention_fwd")
+        e1.record(torch.cuda.current_stream(self.device))
+        e1.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        nbytes = float(B) * R * (E + C) * att_img.element_size()
+        return nbytes, sec
+
     # --------------------------------------------------------------- decode --
     def _encode_only(self, img, beam):
         B, H, W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
