@@ -1,0 +1,179 @@
+// 3x3 convolution (forward and dgrad) as an implicit GEMM on the bf16 MFMA units, gfx950.
+//
+//   tile 256 (pixels) x 128 (output channels) x 64 (K), 8 waves as 4(M) x 2(N), each wave a
+//   2x2 grid of v_mfma_f32_32x32x16_bf16 tiles (64 accumulator registers);
+//   both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
+//   ds_write pass), two LDS stages, tile t+1 in flight under the MFMAs of tile t, one barrier
+//   per K-step;
+//   LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row & 7).  LDS-DMA
+//   writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address (each row's
+//   128-B line is still fetched whole) and again on the fragment read;
+//   im2col is implicit: a K-step of 64 lies inside one (kh, kw) tap because Cin % 64 == 0, so an
+//   A row chunk is 16 contiguous bytes of the NHWC input, or a zero line for padding taps;
+//   blockIdx -> tile remap keeps the tiles that share an A panel on one XCD (private L2s).
+#include "gemm.h"
+#include "api_util.h"
+
+namespace {
+
+__device__ unsigned lxo_zero_line[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+constexpr int CBM = 256, CBN = 128, CBK = 64, CTH = 512;
+constexpr int A_STAGE = CBM * CBK * 2, B_STAGE = CBN * CBK * 2, STAGE = A_STAGE + B_STAGE;
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+LXO_DEV void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)g, (lptr_t)(uintptr_t)l, 16, 0, 0);
+}
+
+}  // namespace
+
+HIP_DYNAMIC_SHARED(char, lxo_conv_lds)
+
+namespace {
+
+template <typename OT>
+__global__ __launch_bounds__(512) void conv_igemm_kernel(GemmNT p, int tiles_n) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware, bijective block -> tile map (blocks b, b+8, b+16.. share an XCD)
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    const int m0 = mt * CBM, n0 = nt * CBN;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
+    const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
+
+    // staging descriptors: A rows (tid>>3) + 64 j, LDS chunk tid&7, global chunk swizzled by row
+    const int srow = tid >> 3, sch = tid & 7;
+    int a_oy[4], a_ox[4]; long long a_base[4]; bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + srow + 64 * j;
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_oy[j] = oy - p.pad; a_ox[j] = ox - p.pad;
+        a_base[j] = (long long)b * p.H * p.W;
+    }
+    const bf16_t* b_ptr[2]; bool b_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + srow + 64 * j;
+        b_ok[j] = n < p.N;
+        b_ptr[j] = Bp + (long long)(b_ok[j] ? n : 0) * p.ldb + ((sch ^ (srow & 7)) << 3);
+    }
+    const int a_gch = (sch ^ (srow & 7)) << 3;          // element offset of the global chunk this lane fetches
+
+    auto issue = [&](int k0, int stage) {
+        char* as = lxo_conv_lds + stage * STAGE;
+        char* bs = as + A_STAGE;
+        const int tap = k0 / p.Cin;
+        const int ci0 = k0 - tap * p.Cin;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_oy[j] + kh, ix = a_ox[j] + kw;
+            const bool ok = a_ok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const void* src = ok ? (const void*)(A + (a_base[j] + (long long)iy * p.W + ix) * p.Cin + ci0 + a_gch) : (const void*)zline;
+            glds16(src, as + (wave * 64 + 512 * j) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const void* src = b_ok[j] ? (const void*)(b_ptr[j] + k0) : (const void*)zline;
+            glds16(src, bs + (wave * 64 + 512 * j) * 16);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = p.K / CBK;
+    issue(0, 0);
+    __syncthreads();                          // (the compiler drains the LDS-DMA queue before the barrier)
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) issue((t + 1) * CBK, (t + 1) & 1);
+        const char* as = lxo_conv_lds + (t & 1) * STAGE;
+        const char* bs = as + A_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = ks * 2 + (lane >> 5);
+            u32x4 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + (lane & 31);
+                af[i] = *reinterpret_cast<const u32x4*>(as + row * 128 + ((kc ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + (lane & 31);
+                bfr[j] = *reinterpret_cast<const u32x4*>(bs + row * 128 + ((kc ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (same contract as gemm_nt_kernel) ----
+    OT* __restrict__ C = reinterpret_cast<OT*>(p.C);
+    OT* __restrict__ Cpre = reinterpret_cast<OT*>(p.out_pre);
+    const bf16_t* __restrict__ ref = reinterpret_cast<const bf16_t*>(p.relu_ref);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        const bool n_ok = n < p.N;
+        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (!(n_ok && m < p.M)) continue;
+                float v = p.alpha * acc[i][j][e] + bias;
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                else if (p.act == 2) v = tanhf(v);
+                const long long o = (long long)m * p.ldc + n;
+                if (Cpre) Cpre[o] = from_f32<OT>(v);
+                if (p.addend) v += p.addend[(long long)(m % p.addend_rows) * p.N + n];
+                if (ref) v = (to_f32(ref[(long long)m * p.ldr + n]) > 0.f) ? v : 0.f;
+                csum += v;
+                if (p.accumulate) v += to_f32(C[o]);
+                C[o] = from_f32<OT>(v);
+            }
+        }
+        if (p.colsum) {
+            csum += __shfl_xor(csum, 32);
+            if (lane < 32 && n_ok) atomicAdd(&p.colsum[n], csum);
+        }
+    }
+}
+
+}  // namespace
+
+int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
+    if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+        attr_set = true;
+    }
+    const int tiles_n = cdiv(p.N, CBN), tiles_m = cdiv(p.M, CBM);
+    hipLaunchKernelGGL((conv_igemm_kernel<bf16_t>), dim3(tiles_m * tiles_n), dim3(CTH), 2 * STAGE, s, p, tiles_n);
+    return (int)hipGetLastError();
+}

@@ -44,3 +44,6 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
 
 // split-K partial products: slab[ks][M][ldc] = A[:, ks*128:(ks+1)*128] * Bp[:, same]^T, ks < K/128 (A float)
 int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s);
+
+// bf16 3x3 implicit-GEMM convolution, 256x128x64 tiles, LDS-DMA double buffering (conv_igemm.hip)
+int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s);

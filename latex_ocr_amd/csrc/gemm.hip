@@ -651,8 +651,8 @@ int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p,
     }
     if (p.conv) {
         if (a_f32 || c_f32) return -3;
-        if (p.Cin % 64) return -2;
-        return launch_nt<bf16_t, true, bf16_t, bf16_t, 128, 128, 64>(p, s);
+        if (p.Cin % 64 == 0) return lxo_launch_conv_igemm(p, s);
+        return launch_nt<bf16_t, true, bf16_t, bf16_t, 128, 128>(p, s);
     }
     if (small) {
         if (!(a_f32 && c_f32)) return -3;

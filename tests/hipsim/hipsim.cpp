@@ -33,6 +33,7 @@ hipsim_switch:
 
 namespace hipsim {
 Idx g_threadIdx, g_blockIdx;
+alignas(64) char g_dyn_lds[163840];
 dim3 g_blockDim, g_gridDim;
 
 enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };

@@ -41,6 +41,7 @@ struct Idx { unsigned x, y, z; };
 extern Idx g_threadIdx, g_blockIdx;
 extern dim3 g_blockDim, g_gridDim;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+extern char g_dyn_lds[163840];      // dynamic LDS of the workgroup being interpreted
 void syncthreads();
 void wave_sync();
 unsigned lane();                 // linear thread id % 64
@@ -57,6 +58,10 @@ template <class T> inline T exchange(T v, unsigned src) {
 }
 inline float bf2f(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
 }  // namespace hipsim
+
+#define HIP_DYNAMIC_SHARED(type, var) static type* var = reinterpret_cast<type*>(hipsim::g_dyn_lds);
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 
 #define threadIdx hipsim::g_threadIdx
 #define blockIdx hipsim::g_blockIdx
@@ -233,6 +238,12 @@ inline v4f mfma_16x16x4_f32(float a, float b, v4f c) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipsim::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipsim::mfma_32x32x2_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipsim::mfma_16x16x4_f32(a, b, c)
+
+// LDS-DMA: every lane copies `size` bytes from its own global pointer to (wave-uniform LDS base + lane*size)
+template <class G, class Lp> inline void hipsim_global_load_lds(G g, Lp l, unsigned size, int off, unsigned) {
+    memcpy(reinterpret_cast<char*>((uintptr_t)l) + off + hipsim::lane() * size, reinterpret_cast<const void*>((uintptr_t)g), size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipsim_global_load_lds(g, l, size, off, aux)
 
 // ---- host API subset used by the C-ABI layer ----
 inline hipError_t hipGetLastError() { return hipSuccess; }
