@@ -3,8 +3,8 @@
 //   tile 256 (pixels) x 128 (output channels) x 64 (K), 8 waves as 4(M) x 2(N), each wave a
 //   2x2 grid of v_mfma_f32_32x32x16_bf16 tiles (64 accumulator registers);
 //   both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
-//   ds_write pass), two LDS stages, tile t+1 in flight under the MFMAs of tile t, one barrier
-//   per K-step;
+//   ds_write pass), three LDS stages, tiles t+1 and t+2 in flight under the MFMAs of tile t,
+//   counted s_waitcnt vmcnt(6) + one raw s_barrier per K-step (never a full drain in the loop);
 //   LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row & 7).  LDS-DMA
 //   writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address (each row's
 //   128-B line is still fetched whole) and again on the fragment read;
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(GemmNT p, int tiles_n) 
     }
     const int a_gch = (sch ^ (srow & 7)) << 3;          // element offset of the global chunk this lane fetches
 
+    // 6 LDS-DMA instructions per thread per tile (the counted waits below rely on this number)
     auto issue = [&](int k0, int stage) {
         char* as = lxo_conv_lds + stage * STAGE;
         char* bs = as + A_STAGE;
@@ -98,12 +99,18 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(GemmNT p, int tiles_n) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // three LDS stages; tiles t+1 and t+2 are in flight while tile t is multiplied.  A wave waits
+    // only for ITS OWN loads of tile t (vmcnt(6) leaves the 6 newer ones outstanding), then the
+    // barrier makes every wave's part of tile t visible and frees stage (t-1)%3 for tile t+2.
     const int nk = p.K / CBK;
     issue(0, 0);
-    __syncthreads();                          // (the compiler drains the LDS-DMA queue before the barrier)
+    if (nk > 1) issue(CBK, 1);
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) issue((t + 1) * CBK, (t + 1) & 1);
-        const char* as = lxo_conv_lds + (t & 1) * STAGE;
+        if (t + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F76);     // vmcnt(6)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nk) issue((t + 2) * CBK, (t + 2) % 3);
+        const char* as = lxo_conv_lds + (t % 3) * STAGE;
         const char* bs = as + A_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -126,11 +133,42 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(GemmNT p, int tiles_n) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]),
                                                                         acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
 
-    // ---- epilogue (same contract as gemm_nt_kernel) ----
     OT* __restrict__ C = reinterpret_cast<OT*>(p.C);
+    const bool plain = !p.out_pre && !p.addend && !p.relu_ref && !p.colsum && !p.accumulate && p.ldc == p.N && (p.N & 7) == 0;
+    if (plain) {
+        // ---- fast epilogue: bias + activation in registers, transpose through LDS, 16-byte row stores ----
+        __syncthreads();                                  // every wave is done reading the stages
+        bf16_t* ot = reinterpret_cast<bf16_t*>(lxo_conv_lds);          // [256][128 + 8] bf16
+        constexpr int OP = CBN + 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nl = wn * 64 + j * 32 + (lane & 31);
+            const int n = n0 + nl;
+            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    float v = p.alpha * acc[i][j][e] + bias;
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    else if (p.act == 2) v = tanhf(v);
+                    ot[ml * OP + nl] = f2bf(v);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + 512 * it, row = idx >> 4, c8 = (idx & 15) * 8;
+            const int m = m0 + row, n = n0 + c8;
+            if (m < p.M && n < p.N)
+                *reinterpret_cast<u32x4*>(C + (long long)m * p.ldc + n) = *reinterpret_cast<const u32x4*>(ot + row * OP + c8);
+        }
+        return;
+    }
+    // ---- general epilogue (same contract as gemm_nt_kernel) ----
     OT* __restrict__ Cpre = reinterpret_cast<OT*>(p.out_pre);
     const bf16_t* __restrict__ ref = reinterpret_cast<const bf16_t*>(p.relu_ref);
 #pragma unroll
@@ -170,10 +208,10 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+        HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE));
         attr_set = true;
     }
     const int tiles_n = cdiv(p.N, CBN), tiles_m = cdiv(p.M, CBM);
-    hipLaunchKernelGGL((conv_igemm_kernel<bf16_t>), dim3(tiles_m * tiles_n), dim3(CTH), 2 * STAGE, s, p, tiles_n);
+    hipLaunchKernelGGL((conv_igemm_kernel<bf16_t>), dim3(tiles_m * tiles_n), dim3(CTH), 3 * STAGE, s, p, tiles_n);
     return (int)hipGetLastError();
 }

@@ -22,13 +22,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 LXO_DEV float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
 // round-to-nearest-even; NaN stays NaN (quiet)
-LXO_DEV bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// (v_cvt_pk_bf16_f32 on gfx950)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+LXO_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+LXO_DEV unsigned pack_bf2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-LXO_DEV unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
 template <class T> struct is_bf16 { static constexpr bool value = false; };
 template <> struct is_bf16<bf16_t> { static constexpr bool value = true; };

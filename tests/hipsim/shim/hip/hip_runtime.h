@@ -117,6 +117,7 @@ template <class T> inline T __builtin_amdgcn_readfirstlane_sim(T v) {
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipsim::syncthreads()
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(n) ((void)0)
 
 // ---- atomics (single host thread: plain read-modify-write) ----
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
