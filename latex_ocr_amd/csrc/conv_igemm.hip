@@ -5,7 +5,9 @@
 //   both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no
 //   ds_write pass), three LDS stages, tiles t+1 and t+2 in flight under the MFMAs of tile t,
 //   counted s_waitcnt vmcnt(6) + one raw s_barrier per K-step (never a full drain in the loop);
-//   LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row & 7).  LDS-DMA
+//   LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with ((row >> 1) & 7):
+//   two tile rows share a 256-B bank row, so (row & 1, (row >> 1) & 7) makes the 16 rows of a
+//   ds_read_b128 lane group hit 16 distinct 16-byte slots (conflict-free).  LDS-DMA
 //   writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address (each row's
 //   128-B line is still fetched whole) and again on the fragment read;
 //   im2col is implicit: a K-step of 64 lies inside one (kh, kw) tap because Cin % 64 == 0, so an
@@ -66,9 +68,9 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(GemmNT p, int tiles_n) 
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + srow + 64 * j;
         b_ok[j] = n < p.N;
-        b_ptr[j] = Bp + (long long)(b_ok[j] ? n : 0) * p.ldb + ((sch ^ (srow & 7)) << 3);
+        b_ptr[j] = Bp + (long long)(b_ok[j] ? n : 0) * p.ldb + ((sch ^ ((srow >> 1) & 7)) << 3);
     }
-    const int a_gch = (sch ^ (srow & 7)) << 3;          // element offset of the global chunk this lane fetches
+    const int a_gch = (sch ^ ((srow >> 1) & 7)) << 3;          // element offset of the global chunk this lane fetches
 
     // 6 LDS-DMA instructions per thread per tile (the counted waits below rely on this number)
     auto issue = [&](int k0, int stage) {
@@ -119,12 +121,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(GemmNT p, int tiles_n) 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32 + (lane & 31);
-                af[i] = *reinterpret_cast<const u32x4*>(as + row * 128 + ((kc ^ (row & 7)) << 4));
+                af[i] = *reinterpret_cast<const u32x4*>(as + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + (lane & 31);
-                bfr[j] = *reinterpret_cast<const u32x4*>(bs + row * 128 + ((kc ^ (row & 7)) << 4));
+                bfr[j] = *reinterpret_cast<const u32x4*>(bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
