@@ -83,7 +83,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LXO_FORCE_DIST") == "1":
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))

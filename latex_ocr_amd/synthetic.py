@@ -34,3 +34,25 @@ def config1(seed=1234):
 def config3_batch(B=64, H=128, W=512, n_tok=500, seed=1234):
     """One training batch of BASELINE.json configs[2]: lengths U{30..100}."""
     return make_set(B, H, W, n_tok, 30, 101, seed)
+
+
+def write_dataset(root, n_train=100, n_val=20, n_test=20, H=32, W=128, n_ord=47, seed=1234):
+    """Materialise a synthetic dataset in the reference's on-disk format (PNG images, a formulas
+    file of space-separated tokens, a matching file of "<img> <formula_idx>" lines, vocab.txt) so
+    that DataGenerator / Vocab / train.py can be driven end to end.  Tokens are "t0".."t<n_ord-1>"."""
+    import os
+    from PIL import Image
+    os.makedirs(root, exist_ok=True)
+    toks = ["t%d" % i for i in range(n_ord)]
+    with open(os.path.join(root, "vocab.txt"), "w") as f:
+        f.write("\n".join(toks))
+    for split, n, s in (("train", n_train, seed), ("val", n_val, seed + 1), ("test", n_test, seed + 2)):
+        imgs, forms = make_set(n, H, W, n_ord + 3, 5, 21, seed=s)
+        d = os.path.join(root, split)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(root, split + ".formulas.txt"), "w") as ff, open(os.path.join(root, split + ".matching.txt"), "w") as fm:
+            for i, (img, form) in enumerate(zip(imgs, forms)):
+                Image.fromarray(np.repeat(img, 3, axis=2)).save(os.path.join(d, "%d.png" % i))
+                ff.write(" ".join(toks[t] for t in form) + "\n")
+                fm.write("%d.png %d\n" % (i, i))
+    return root
