@@ -28,6 +28,14 @@ LXO_DEV float slab_sum(const Slabs& sl, long long row, int col) {
     return v;
 }
 
+// 4 consecutive columns (col % 4 == 0, ld % 4 == 0)
+LXO_DEV f32x4 slab_sum4(const Slabs& sl, long long row, int col) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* q = sl.p + row * sl.ld + col;
+    for (int s = 0; s < sl.n; ++s) v += *reinterpret_cast<const f32x4*>(q + (long long)s * sl.stride);
+    return v;
+}
+
 // mean over regions: img [B][R][C] -> mean [B][C]   (attention_mechanism.py:148)
 template <typename CT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const CT* __restrict__ img, float* __restrict__ mean, int R, int C) {
@@ -97,49 +105,64 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     }
 }
 
-// TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71)
+// TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71); 4 units per thread
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ z, Slabs zs, const float* __restrict__ c_prev,
                                                       float* __restrict__ gates, float* __restrict__ c_out,
                                                       float* __restrict__ h_out, int ldh, int B, int U) {
-    const int total = B * U;
+    const int total = B * (U >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int b = i / U, u = i - b * U;
-        const float* zr = z + (long long)b * 4 * U;
-        float z0 = zr[u], z1 = zr[U + u], z2 = zr[2 * U + u], z3 = zr[3 * U + u];
-        for (int sI = 0; sI < zs.n; ++sI) {
-            const float* q = zs.p + (long long)sI * zs.stride + (long long)b * zs.ld;
-            z0 += q[u]; z1 += q[U + u]; z2 += q[2 * U + u]; z3 += q[3 * U + u];
+        const int b = i / (U >> 2), u = (i - b * (U >> 2)) << 2;
+        const float* zr = z + (long long)b * 4 * U + u;
+        f32x4 zz[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zz[g] = *reinterpret_cast<const f32x4*>(zr + g * U) + slab_sum4(zs, b, g * U + u);
+        const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + (long long)b * U + u);
+        f32x4 gi, gj, gf, go, c, h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gi[e] = sigmoidf_(zz[0][e]); gj[e] = tanhf(zz[1][e]);
+            gf[e] = sigmoidf_(zz[2][e] + 1.0f); go[e] = sigmoidf_(zz[3][e]);
+            c[e] = gf[e] * cp[e] + gi[e] * gj[e];
+            h[e] = go[e] * tanhf(c[e]);
         }
-        const float gi = sigmoidf_(z0), gj = tanhf(z1);
-        const float gf = sigmoidf_(z2 + 1.0f), go = sigmoidf_(z3);
-        const float c = gf * c_prev[i] + gi * gj;
-        const float h = go * tanhf(c);
         if (gates) {
-            float* gr = gates + (long long)b * 4 * U;
-            gr[u] = gi; gr[U + u] = gj; gr[2 * U + u] = gf; gr[3 * U + u] = go;
+            float* gr = gates + (long long)b * 4 * U + u;
+            *reinterpret_cast<f32x4*>(gr) = gi; *reinterpret_cast<f32x4*>(gr + U) = gj;
+            *reinterpret_cast<f32x4*>(gr + 2 * U) = gf; *reinterpret_cast<f32x4*>(gr + 3 * U) = go;
         }
-        c_out[i] = c;
-        h_out[(long long)b * ldh + u] = h;
+        *reinterpret_cast<f32x4*>(c_out + (long long)b * U + u) = c;
+        *reinterpret_cast<f32x4*>(h_out + (long long)b * ldh + u) = h;
     }
 }
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                       const float* __restrict__ c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                                                       float* __restrict__ dcc, float* __restrict__ dz, int B, int U) {
-    const int total = B * U;
+    const int total = B * (U >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int b = i / U, u = i - b * U;
-        const float* gr = gates + (long long)b * 4 * U;
-        const float gi = gr[u], gj = gr[U + u], gf = gr[2 * U + u], go = gr[3 * U + u];
-        const float dh = slab_sum(s1, b, u) + slab_sum(s3, b, u) + slab_sum(s4, b, off4 + u);
-        const float tc = tanhf(c_cur[i]);
-        const float dc = dcc[i] + dh * go * (1.f - tc * tc);
-        float* dr = dz + (long long)b * 4 * U;
-        dr[u] = dc * gj * gi * (1.f - gi);
-        dr[U + u] = dc * gi * (1.f - gj * gj);
-        dr[2 * U + u] = dc * c_prev[i] * gf * (1.f - gf);
-        dr[3 * U + u] = dh * tc * go * (1.f - go);
-        dcc[i] = dc * gf;
+        const int b = i / (U >> 2), u = (i - b * (U >> 2)) << 2;
+        const float* gr = gates + (long long)b * 4 * U + u;
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(gr), gj = *reinterpret_cast<const f32x4*>(gr + U);
+        const f32x4 gf = *reinterpret_cast<const f32x4*>(gr + 2 * U), go = *reinterpret_cast<const f32x4*>(gr + 3 * U);
+        const f32x4 dh = slab_sum4(s1, b, u) + slab_sum4(s3, b, u) + slab_sum4(s4, b, off4 + u);
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(c_cur + (long long)b * U + u);
+        const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + (long long)b * U + u);
+        const f32x4 dci = *reinterpret_cast<const f32x4*>(dcc + (long long)b * U + u);
+        f32x4 di, dj, df, dg, dco;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float tc = tanhf(cc[e]);
+            const float dc = dci[e] + dh[e] * go[e] * (1.f - tc * tc);
+            di[e] = dc * gj[e] * gi[e] * (1.f - gi[e]);
+            dj[e] = dc * gi[e] * (1.f - gj[e] * gj[e]);
+            df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+            dg[e] = dh[e] * tc * go[e] * (1.f - go[e]);
+            dco[e] = dc * gf[e];
+        }
+        float* dr = dz + (long long)b * 4 * U + u;
+        *reinterpret_cast<f32x4*>(dr) = di; *reinterpret_cast<f32x4*>(dr + U) = dj;
+        *reinterpret_cast<f32x4*>(dr + 2 * U) = df; *reinterpret_cast<f32x4*>(dr + 3 * U) = dg;
+        *reinterpret_cast<f32x4*>(dcc + (long long)b * U + u) = dco;
     }
 }
 
@@ -147,20 +170,27 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ a, int lda, Slabs carry,
                                                       const float* __restrict__ o, int ldo, float* __restrict__ g, int ldg,
                                                       int rows, int cols) {
-    const int total = rows * cols;
+    const int total = rows * (cols >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int r = i / cols, c = i - r * cols;
-        const float ov = o[(long long)r * ldo + c];
-        const float d = a[(long long)r * lda + c] + slab_sum(carry, r, c);
-        g[(long long)r * ldg + c] = d * (1.f - ov * ov);
+        const int r = i / (cols >> 2), c = (i - r * (cols >> 2)) << 2;
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(o + (long long)r * ldo + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(a + (long long)r * lda + c) + slab_sum4(carry, r, c);
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = d[e] * (1.f - ov[e] * ov[e]);
+        *reinterpret_cast<f32x4*>(g + (long long)r * ldg + c) = out;
     }
 }
 // o = tanh(sum of the K4 slabs) -> rec      (attention_cell.py:82)
 __global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __restrict__ o, int ldo, int rows, int cols) {
-    const int total = rows * cols;
+    const int total = rows * (cols >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int r = i / cols, c = i - r * cols;
-        o[(long long)r * ldo + c] = tanhf(slab_sum(sl, r, c));
+        const int r = i / (cols >> 2), c = (i - r * (cols >> 2)) << 2;
+        const f32x4 v = slab_sum4(sl, r, c);
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = tanhf(v[e]);
+        *reinterpret_cast<f32x4*>(o + (long long)r * ldo + c) = out;
     }
 }
 
@@ -170,7 +200,7 @@ __global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __r
 // loads in flight (the stream is latency-bound otherwise: one 512-B row per wave per
 // round trip measured 5 GB/s per workgroup).  Each chunk produces flash-style partials
 // (max, sum, unnormalised context); attn_fwd_combine normalises.
-constexpr int ATT_ROWS = 1024;  // max rows per chunk (Plan::attn_chunks)
+constexpr int ATT_ROWS = 1 << 20;  // no per-chunk LDS row buffer any more
 constexpr int ATT_W = 8;        // waves per workgroup
 constexpr int ATT_U = 8;        // rows in flight per wave
 
@@ -179,13 +209,15 @@ template <> LXO_DEV float tanh_ct<float>(float x) { return tanhf(x); }
 // bf16 mode: 1 - 2/(e^{2x}+1) on v_exp_f32 / v_rcp_f32 (abs error ~1e-7, far below bf16 resolution)
 template <> LXO_DEV float tanh_ct<bf16_t>(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
-template <typename CT>
+// Forward: ONE pass over both streams with a per-wave online softmax (running max / sum / context),
+// so the att_img row and the img row of 8 regions are all in flight together; the raw scores go to
+// `alpha` and attn_fwd_combine turns them into normalised weights.
+template <typename CT, int KCT>
 __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, Slabs ahs, float* __restrict__ att_h_out,
                                                            const float* __restrict__ beta,
                                                            float* __restrict__ alpha, float* __restrict__ part,
                                                            int R, int Rp, int E, int C, int beam, int nch, int rows_per) {
-    __shared__ float sc[ATT_ROWS];
     __shared__ float redc[ATT_W][512];
     __shared__ float red[2 * ATT_W];
     const int ch = blockIdx.x, v = blockIdx.y, bi = v / beam;
@@ -195,103 +227,96 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
     const CT* ai = att_img + ((long long)bi * R + r0) * E;
     const CT* im = img + ((long long)bi * R + r0) * C;
     float* pout = part + ((long long)v * nch + ch) * (C + 2);
-    const int KC = (E + 255) >> 8;
-    // scores
-    for (int kc = 0; kc < KC; ++kc) {
+    constexpr int KC = KCT;
+    float ah[KCT][4], bt[KCT][4];
+#pragma unroll
+    for (int kc = 0; kc < KCT; ++kc) {
         const int k0 = kc * 256 + lane * 4;
-        const bool kok = k0 < E;
-        float ah[4], bt[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a = 0.f;
-            if (kok) a = ahs.n > 0 ? slab_sum(ahs, v, k0 + j) : att_h[(long long)v * E + k0 + j];
-            ah[j] = a; bt[j] = kok ? beta[k0 + j] : 0.f;
+        for (int j = 0; j < 4; ++j) { ah[kc][j] = 0.f; bt[kc][j] = 0.f; }
+        if (kc < KC && k0 < E) {
+            const f32x4 a4 = ahs.n > 0 ? slab_sum4(ahs, v, k0) : *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + k0);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ah[kc][j] = a4[j]; bt[kc][j] = b4[j]; }
+            if (ahs.n > 0 && att_h_out && ch == 0 && wave == 0) *reinterpret_cast<f32x4*>(att_h_out + (long long)v * E + k0) = a4;
         }
-        if (ahs.n > 0 && att_h_out && ch == 0 && wave == 0 && kok) {      // materialise att_h for the backward pass
+    }
+    const int c0 = lane * 8;
+    const bool cok = c0 < C;
+    float m = -3.0e38f, l = 0.f, acc[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) att_h_out[(long long)v * E + k0 + j] = ah[j];
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int base = wave; base < n; base += ATT_W * ATT_U) {
+        float xi[ATT_U][8], pt[ATT_U];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {                 // issue the img rows first: they are consumed last
+            const int r = base + ATT_W * u;
+            if (cok && r < n) load8(im + (long long)r * C + c0, xi[u]);
+            else { for (int e = 0; e < 8; ++e) xi[u][e] = 0.f; }
+            pt[u] = 0.f;
         }
-        for (int base = wave; base < n; base += ATT_W * ATT_U) {
-            float x[ATT_U][4];
 #pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                const int r = base + ATT_W * u;
-                if (kok && r < n) load4(ai + (long long)r * E + k0, x[u]);
-                else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
-            }
-            float pt[ATT_U];
-#pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                float a = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a = fmaf(tanh_ct<CT>(x[u][j] + ah[j]), bt[j], a);
-                pt[u] = a;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
-            }
-            if (lane == 0) {
+        for (int kc = 0; kc < KCT; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            if (kc < KC && k0 < E) {
+                float x[ATT_U][4];
 #pragma unroll
                 for (int u = 0; u < ATT_U; ++u) {
                     const int r = base + ATT_W * u;
-                    if (r < n) sc[r] = (kc == 0 ? 0.f : sc[r]) + pt[u];
+                    if (r < n) load4(ai + (long long)r * E + k0, x[u]);
+                    else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
                 }
+#pragma unroll
+                for (int u = 0; u < ATT_U; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pt[u] = fmaf(tanh_ct<CT>(x[u][j] + ah[kc][j]), bt[kc][j], pt[u]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+        }
+        float mn = m;
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) if (base + ATT_W * u < n) mn = fmaxf(mn, pt[u]);
+        const float sc = expf(m - mn);                    // wave-uniform rescale of the running sums
+        l *= sc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= sc;
+        m = mn;
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int r = base + ATT_W * u;
+            if (r < n) {
+                const float pw = expf(pt[u] - m);
+                l += pw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pw, xi[u][e], acc[e]);
+                if (lane == 0) alpha[(long long)v * Rp + r0 + r] = pt[u];       // raw score
             }
         }
     }
-    __syncthreads();
-    // chunk-local softmax statistics
-    float m = -3.0e38f;
-    for (int r = tid; r < n; r += 512) m = fmaxf(m, sc[r]);
-    m = wave_max(m);
+    // merge the 8 waves
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = red[0];
+    float mc = red[0];
 #pragma unroll
-    for (int w = 1; w < ATT_W; ++w) m = fmaxf(m, red[w]);
-    float l = 0.f;
-    for (int r = tid; r < n; r += 512) {
-        const float p = expf(sc[r] - m);
-        sc[r] = p; l += p;
-        alpha[(long long)v * Rp + r0 + r] = p;          // unnormalised; attn_fwd_combine rescales
+    for (int w = 1; w < ATT_W; ++w) mc = fmaxf(mc, red[w]);
+    const float sw = (l > 0.f) ? expf(m - mc) : 0.f;
+    if (lane == 0) red[ATT_W + wave] = l * sw;
+    if (cok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e] * sw;
     }
-    l = wave_sum(l);
-    if (lane == 0) red[ATT_W + wave] = l;
     __syncthreads();
     if (tid == 0) {
         float lt = 0.f;
 #pragma unroll
         for (int w = 0; w < ATT_W; ++w) lt += red[ATT_W + w];
-        pout[0] = m; pout[1] = lt;
+        pout[0] = mc; pout[1] = lt;
     }
-    // unnormalised context of the chunk
-    const int c0 = lane * 8;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    if (c0 < C) {
-        for (int base = wave; base < n; base += ATT_W * ATT_U) {
-            float x[ATT_U][8];
-#pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                const int r = base + ATT_W * u;
-                if (r < n) load8(im + (long long)r * C + c0, x[u]);
-                else { for (int e = 0; e < 8; ++e) x[u][e] = 0.f; }
-            }
-#pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                const int r = base + ATT_W * u;
-                const float a = r < n ? sc[r] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(a, x[u][e], acc[e]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e];
-    }
-    __syncthreads();
     for (int c = tid; c < C; c += 512) {
         float t = 0.f;
 #pragma unroll
@@ -300,11 +325,11 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
     }
 }
 
-// merge the chunk partials: alpha = p * exp(m_c - m) / l ; ctx = sum_c ctx_c exp(m_c - m) / l
+// merge the chunk partials: alpha = exp(e - m) / l ; ctx = sum_c ctx_c exp(m_c - m) / l
 __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __restrict__ part, float* __restrict__ alpha,
                                                               float* __restrict__ ctx, int ldctx, int R, int Rp, int C,
                                                               int nch, int rows_per) {
-    __shared__ float scl[32];
+    __shared__ float scl[34];
     const int v = blockIdx.x, tid = threadIdx.x;
     const float* pv = part + (long long)v * nch * (C + 2);
     if (tid == 0) {
@@ -318,6 +343,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
         }
         const float inv = 1.0f / l;
         for (int c = 0; c < nch; ++c) scl[c] *= inv;
+        scl[32] = m; scl[33] = inv;
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -325,18 +351,18 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
         for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + c], scl[k], t);
         ctx[(long long)v * ldctx + c] = t;
     }
-    for (int r = tid; r < R; r += 256) alpha[(long long)v * Rp + r] *= scl[r / rows_per];
+    const float m = scl[32], inv = scl[33];
+    for (int r = tid; r < R; r += 256) alpha[(long long)v * Rp + r] = expf(alpha[(long long)v * Rp + r] - m) * inv;
 }
 
-// ---- attention backward (per step): d_e and d_att_h; d_img / d_att_img are deferred ----
-template <typename CT>
+// ---- attention backward (per step): d_e and d_att_h in one pass; d_img / d_att_img are deferred ----
+template <typename CT, int KCT>
 __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, const float* __restrict__ beta,
                                                            const float* __restrict__ alpha, Slabs dcs, int dcoff, float* __restrict__ dctx_out, int lddc,
                                                            const float* __restrict__ ctx, int ldctx,
                                                            float* __restrict__ de, float* __restrict__ datth,
                                                            int R, int Rp, int E, int C, int rows_per) {
-    __shared__ float sc[ATT_ROWS];
     __shared__ float rede[ATT_W][1024];
     __shared__ float red[ATT_W];
     const int ch = blockIdx.x, v = blockIdx.y;
@@ -346,7 +372,7 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
     if (n <= 0) return;                                  // block-uniform
     const CT* ai = att_img + ((long long)v * R + r0) * E;
     const CT* im = img + ((long long)v * R + r0) * C;
-    const int KC = (E + 255) >> 8;
+    constexpr int KC = KCT;
     // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r
     float s = 0.f;
     for (int c = tid; c < C; c += 512) {
@@ -361,23 +387,52 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
 #pragma unroll
     for (int w = 0; w < ATT_W; ++w) s += red[w];
     const int c0 = lane * 8;
+    const bool cok = c0 < C;
     float dc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dc[e] = (c0 + e < C) ? slab_sum(dcs, v, dcoff + c0 + e) : 0.f;
+    for (int e = 0; e < 8; ++e) dc[e] = 0.f;
+    if (cok) {
+        const f32x4 d0 = slab_sum4(dcs, v, dcoff + c0), d1 = slab_sum4(dcs, v, dcoff + c0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dc[e] = d0[e]; dc[4 + e] = d1[e]; }
+    }
+    float ah[KCT][4], acc[KCT][4];
+#pragma unroll
+    for (int kc = 0; kc < KCT; ++kc) {
+        const int k0 = kc * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ah[kc][j] = 0.f; acc[kc][j] = 0.f; }
+        if (kc < KC && k0 < E) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ah[kc][j] = a4[j];
+        }
+    }
     for (int base = wave; base < n; base += ATT_W * ATT_U) {
-        float x[ATT_U][8];
+        float xi[ATT_U][8], pt[ATT_U], al[ATT_U];
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
             const int r = base + ATT_W * u;
-            if (c0 < C && r < n) load8(im + (long long)r * C + c0, x[u]);
-            else { for (int e = 0; e < 8; ++e) x[u][e] = 0.f; }
+            if (cok && r < n) load8(im + (long long)r * C + c0, xi[u]);
+            else { for (int e = 0; e < 8; ++e) xi[u][e] = 0.f; }
+            al[u] = r < n ? alpha[(long long)v * Rp + r0 + r] : 0.f;
         }
-        float pt[ATT_U];
+        float x[KCT][ATT_U][4];
+#pragma unroll
+        for (int kc = 0; kc < KCT; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                if (kc < KC && k0 < E && r < n) load4(ai + (long long)r * E + k0, x[kc][u]);
+                else { x[kc][u][0] = x[kc][u][1] = x[kc][u][2] = x[kc][u][3] = 0.f; }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
             float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a = fmaf(x[u][e], dc[e], a);
+            for (int e = 0; e < 8; ++e) a = fmaf(xi[u][e], dc[e], a);
             pt[u] = a;
         }
 #pragma unroll
@@ -385,47 +440,31 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
 #pragma unroll
             for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
         }
-        if (lane == 0) {
 #pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                const int r = base + ATT_W * u;
-                if (r < n) {
-                    const float d = alpha[(long long)v * Rp + r0 + r] * (pt[u] - s);   // softmax backward
-                    sc[r] = d;
-                    de[(long long)v * Rp + r0 + r] = d;
+        for (int u = 0; u < ATT_U; ++u) {
+            const int r = base + ATT_W * u;
+            const float d = al[u] * (pt[u] - s);                     // softmax backward (0 for r >= n)
+            if (lane == 0 && r < n) de[(long long)v * Rp + r0 + r] = d;
+#pragma unroll
+            for (int kc = 0; kc < KCT; ++kc) {
+                const int k0 = kc * 256 + lane * 4;
+                if (kc < KC && k0 < E) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float tau = tanh_ct<CT>(x[kc][u][j] + ah[kc][j]);
+                        acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
+                    }
                 }
             }
         }
     }
-    __syncthreads();
-    for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+    for (int kc = 0; kc < KCT; ++kc) {
         const int k0 = kc * 256 + lane * 4;
-        const bool kok = k0 < E;
-        float ah[4], acc[4];
+        if (kc < KC && k0 < E) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + k0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ah[j] = kok ? att_h[(long long)v * E + k0 + j] : 0.f; acc[j] = 0.f; }
-        for (int base = wave; base < n; base += ATT_W * ATT_U) {
-            float x[ATT_U][4];
-#pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                const int r = base + ATT_W * u;
-                if (kok && r < n) load4(ai + (long long)r * E + k0, x[u]);
-                else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
-            }
-#pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                const int r = base + ATT_W * u;
-                const float d = r < n ? sc[r] : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float tau = tanh_ct<CT>(x[u][j] + ah[j]);
-                    acc[j] = fmaf(d, 1.f - tau * tau, acc[j]);
-                }
-            }
-        }
-        if (kok) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rede[wave][k0 + j] = acc[j] * beta[k0 + j];
+            for (int j = 0; j < 4; ++j) rede[wave][k0 + j] = acc[kc][j] * b4[j];
         }
     }
     __syncthreads();
@@ -465,21 +504,26 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
             for (int j = 0; j < 4; ++j) { x[kc][j] = 0.f; acc[kc][j] = 0.f; }
             if (kc < KC && k0 < E) load4(att_img + ((long long)b * R + r) * E + k0, x[kc]);
         }
-        for (int t = 0; t < T; ++t) {
-            const float d = de[((long long)t * B + b) * Rp + r];
-            const float* ah = att_h + ((long long)t * B + b) * E;
+        for (int t0 = 0; t0 < T; t0 += 8) {
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 const int k0 = kc * 256 + lane * 4;
                 if (kc < KC && k0 < E) {
-                    float a[4];
-                    load4(ah + k0, a);
+                    float a[8][4], d[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float tau = tanhf(x[kc][j] + a[j]);
-                        acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
-                        db[kc][j] = fmaf(d, tau, db[kc][j]);
+                    for (int tt = 0; tt < 8; ++tt) {          // 8 time steps of loads in flight
+                        const int t = t0 + tt;
+                        if (t < T) { load4(att_h + ((long long)t * B + b) * E + k0, a[tt]); d[tt] = de[((long long)t * B + b) * Rp + r]; }
+                        else { a[tt][0] = a[tt][1] = a[tt][2] = a[tt][3] = 0.f; d[tt] = 0.f; }
                     }
+#pragma unroll
+                    for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float tau = tanh_ct<CT>(x[kc][j] + a[tt][j]);
+                            acc[kc][j] = fmaf(d[tt], 1.f - tau * tau, acc[kc][j]);
+                            db[kc][j] = fmaf(d[tt], tau, db[kc][j]);
+                        }
                 }
             }
         }
@@ -779,20 +823,20 @@ int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* 
     DONE;
 }
 int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U), z, zs, c_prev, gates, c_out, h_out, ldh, B, U);
+    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U / 4), z, zs, c_prev, gates, c_out, h_out, ldh, B, U);
     DONE;
 }
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                    float* dcc, float* dz, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, B, U);
+    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U / 4), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, B, U);
     DONE;
 }
 int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st) {
-    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols), a, lda, carry, o, ldo, g, ldg, rows, cols);
+    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, rows, cols);
     DONE;
 }
 int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st) {
-    LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols), sl, o, ldo, rows, cols);
+    LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, rows, cols);
     DONE;
 }
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
@@ -801,8 +845,15 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     const int rows_per = cdiv(R, nch);
     if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
-    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
-    else hipLaunchKernelGGL((attn_fwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per);
+#define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per
+    if (dt == LXO_BF16) {
+        if (E <= 256) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS);
+        else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS);
+    } else {
+        if (E <= 256) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS);
+        else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS);
+    }
+#undef AF_ARGS
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
     DONE;
 }
@@ -814,8 +865,15 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
     const int rows_per = cdiv(R, nch);
     if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
-    if (dt == LXO_BF16) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
-    else hipLaunchKernelGGL((attn_bwd_part_kernel<float>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per);
+#define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per
+    if (dt == LXO_BF16) {
+        if (E <= 256) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS);
+        else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS);
+    } else {
+        if (E <= 256) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS);
+        else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS);
+    }
+#undef AB_ARGS
     DONE;
 }
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
