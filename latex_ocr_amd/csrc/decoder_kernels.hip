@@ -3,6 +3,7 @@
 // and the context sum in ONE launch, att_img and img each read exactly once.
 #include "decoder_kernels.h"
 #include "api_util.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __r
 // (max, sum, unnormalised context); attn_fwd_combine normalises.
 constexpr int ATT_ROWS = 1 << 20;  // no per-chunk LDS row buffer any more
 constexpr int ATT_W = 8;        // waves per workgroup
-constexpr int ATT_U = 8;        // rows in flight per wave
 
 template <typename CT> LXO_DEV float tanh_ct(float x);
 template <> LXO_DEV float tanh_ct<float>(float x) { return tanhf(x); }
@@ -212,7 +212,7 @@ template <> LXO_DEV float tanh_ct<bf16_t>(float x) { return 1.f - 2.f * __builti
 // Forward: ONE pass over both streams with a per-wave online softmax (running max / sum / context),
 // so the att_img row and the img row of 8 regions are all in flight together; the raw scores go to
 // `alpha` and attn_fwd_combine turns them into normalised weights.
-template <typename CT, int KCT>
+template <typename CT, int KCT, int ATT_U>
 __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, Slabs ahs, float* __restrict__ att_h_out,
                                                            const float* __restrict__ beta,
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
 }
 
 // ---- attention backward (per step): d_e and d_att_h in one pass; d_img / d_att_img are deferred ----
-template <typename CT, int KCT>
+template <typename CT, int KCT, int ATT_U>
 __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, const float* __restrict__ beta,
                                                            const float* __restrict__ alpha, Slabs dcs, int dcoff, float* __restrict__ dctx_out, int lddc,
@@ -839,6 +839,11 @@ int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, int rows, int cols, hipStre
     LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, rows, cols);
     DONE;
 }
+static int att_u() {
+    static int u = -1;
+    if (u < 0) { const char* e = getenv("LXO_ATT_U"); u = (e && atoi(e) == 8) ? 8 : 4; }
+    return u;
+}
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
                    float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
@@ -847,11 +852,11 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     dim3 grid(nch, nv);
 #define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per
     if (dt == LXO_BF16) {
-        if (E <= 256) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS);
-        else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS);
+        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
+        else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
     } else {
-        if (E <= 256) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS);
-        else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS);
+        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
+        else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
     }
 #undef AF_ARGS
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
@@ -867,11 +872,11 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
     dim3 grid(nch, nv);
 #define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per
     if (dt == LXO_BF16) {
-        if (E <= 256) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS);
-        else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS);
+        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
+        else { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
     } else {
-        if (E <= 256) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS);
-        else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS);
+        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); }
+        else { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); }
     }
 #undef AB_ARGS
     DONE;

@@ -2,6 +2,7 @@
 #include "plan.h"
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 static const char* kParamNames[P_COUNT] = {
     "Encoder/convolutional_encoder/conv2d/kernel", "Encoder/convolutional_encoder/conv2d/bias",
@@ -153,7 +154,9 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
 }
 
 int Plan::attn_chunks(int nv) const {
-    int nch = (512 + nv - 1) / nv;                 // ~2 workgroups per CU
+    static int target = -1;                        // tuning knob: workgroups wanted for the attention stream
+    if (target < 0) { const char* e = getenv("LXO_ATT_WGS"); target = (e && atoi(e) > 0) ? atoi(e) : 512; }
+    int nch = (target + nv - 1) / nv;              // ~2 workgroups per CU by default
     if (nch > 16) nch = 16;
     const int by_rows = R / 32 > 0 ? R / 32 : 1;   // keep >= 32 rows per chunk
     if (nch > by_rows) nch = by_rows;
