@@ -15,6 +15,7 @@
 //   blockIdx -> tile remap keeps the tiles that share an A panel on one XCD (private L2s).
 #include "gemm.h"
 #include "api_util.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -204,10 +205,222 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(GemmNT p, int tiles_n) 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Halo-tiled variant: a workgroup owns a 4 x 64 block of output pixels (x 128 channels).  For
+// each 64-channel slice of the input it stages the (4+2) x (64+2) input patch ONCE and serves
+// all nine taps from it (an A fragment row is just the patch pixel shifted by the tap), so the
+// activation operand crosses L2->LDS 1.5x instead of 9x; only the weight tiles stream per
+// K-step.  LDS: two patch buffers (7 LDS-DMA slots of 16 B per thread each = 3584 slots) and
+// three weight stages.
+constexpr int HTH = 4, HTW = 64, HPW = HTW + 2, HPH = HTH + 2, HPROWS = HPH * HPW;   // 396 patch pixels
+constexpr int HPSLOTS = 7 * CTH;                                                       // 3584 >= 396 * 8
+constexpr int HPATCH = HPSLOTS * 16, HB_STAGE = CBN * CBK * 2;                         // 57344, 16384
+
+#define LXO_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+
+template <typename OT>
+__global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    const int tx_i = mt % tiles_x, ty_i = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+    const int oy0 = ty_i * HTH, ox0 = tx_i * HTW, n0 = nt * CBN;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
+    const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
+    char* patch0 = lxo_conv_lds;
+    char* bst0 = lxo_conv_lds + 2 * HPATCH;
+
+    // patch staging: slot s = tid + 512 j -> patch pixel prow = (tid >> 3) + 64 j, LDS chunk tid & 7
+    const int sch = tid & 7;
+    long long a_off[7];                      // element offset of the pixel in the input, < 0 = zero (padding / outside)
+    int a_gch[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int prow = (tid >> 3) + 64 * j;
+        const int py = prow / HPW, px = prow - py * HPW;
+        const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+        const bool ok = prow < HPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        a_off[j] = ok ? (((long long)b * p.H + iy) * p.W + ix) * p.Cin : -1;
+        a_gch[j] = (sch ^ ((prow >> 1) & 7)) << 3;
+    }
+    const int srow = tid >> 3;
+    const bf16_t* b_ptr[2]; bool b_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + srow + 64 * j;
+        b_ok[j] = n < p.N;
+        b_ptr[j] = Bp + (long long)(b_ok[j] ? n : 0) * p.ldb + ((sch ^ ((srow >> 1) & 7)) << 3);
+    }
+    auto issue_patch = [&](int c, int buf) {          // 7 LDS-DMA per thread
+        char* dst = patch0 + buf * HPATCH;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const void* src = a_off[j] >= 0 ? (const void*)(A + a_off[j] + c * CBK + a_gch[j]) : (const void*)zline;
+            glds16(src, dst + (wave * 64 + 512 * j) * 16);
+        }
+    };
+    auto issue_b = [&](int t, int stage) {             // 2 LDS-DMA per thread; K index of tile t = tap*Cin + c*64
+        const int c = t / 9, tap = t - 9 * c;
+        const int k0 = tap * p.Cin + c * CBK;
+        char* dst = bst0 + stage * HB_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const void* src = b_ok[j] ? (const void*)(b_ptr[j] + k0) : (const void*)zline;
+            glds16(src, dst + (wave * 64 + 512 * j) * 16);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // A-fragment geometry of this lane: tile pixel r -> (ty, tx); patch row for tap (kh,kw) = (ty+kh)*66 + tx + kw
+    int a_prow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = wm * 64 + i * 32 + (lane & 31);
+        a_prow[i] = (rr >> 6) * HPW + (rr & 63);
+    }
+    int b_row[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_row[j] = wn * 64 + j * 32 + (lane & 31);
+
+    const int nchunk = p.Cin / CBK, nk = nchunk * 9;
+    issue_patch(0, 0);
+    issue_b(0, 0);
+    if (nk > 1) issue_b(1, 1);
+    for (int t = 0; t < nk; ++t) {
+        // loads issued after B(t): B(t+1) [2] and the next patch [7] when it was issued at step t-2 or t-1
+        const int tm = t % 9;
+        const bool patch_after = (tm == 5 || tm == 6) && (t / 9 + 1 < nchunk);
+        const int nafter = ((t + 1 < nk) ? 2 : 0) + (patch_after ? 7 : 0);
+        if (nafter == 9) LXO_VMCNT(9);
+        else if (nafter == 7) LXO_VMCNT(7);
+        else if (nafter == 2) LXO_VMCNT(2);
+        else LXO_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nk) issue_b(t + 2, (t + 2) % 3);
+        if (tm == 4 && t / 9 + 1 < nchunk) issue_patch(t / 9 + 1, (t / 9 + 1) & 1);
+        const int c = t / 9, tap = t - 9 * c;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const char* ps = patch0 + (c & 1) * HPATCH;
+        const char* bs = bst0 + (t % 3) * HB_STAGE;
+        const int shift = kh * HPW + kw;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = ks * 2 + (lane >> 5);
+            u32x4 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int prow = a_prow[i] + shift;
+                af[i] = *reinterpret_cast<const u32x4*>(ps + prow * 128 + ((kc ^ ((prow >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = *reinterpret_cast<const u32x4*>(bs + b_row[j] * 128 + ((kc ^ ((b_row[j] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: tile pixel r -> output row ((b*Ho + oy0 + r/64) * Wo + ox0 + r%64) ----
+    OT* __restrict__ C = reinterpret_cast<OT*>(p.C);
+    const bool plain = !p.out_pre && !p.addend && !p.relu_ref && !p.colsum && !p.accumulate && p.ldc == p.N && (p.N & 7) == 0;
+    if (plain) {
+        __syncthreads();
+        bf16_t* ot = reinterpret_cast<bf16_t*>(lxo_conv_lds);
+        constexpr int OP = CBN + 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nl = wn * 64 + j * 32 + (lane & 31);
+            const int n = n0 + nl;
+            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    float v = p.alpha * acc[i][j][e] + bias;
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    else if (p.act == 2) v = tanhf(v);
+                    ot[ml * OP + nl] = f2bf(v);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + 512 * it, row = idx >> 4, c8 = (idx & 15) * 8;
+            const int oy = oy0 + (row >> 6), ox = ox0 + (row & 63), n = n0 + c8;
+            if (oy < p.Ho && ox < p.Wo && n < p.N)
+                *reinterpret_cast<u32x4*>(C + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.ldc + n) = *reinterpret_cast<const u32x4*>(ot + row * OP + c8);
+        }
+        return;
+    }
+    OT* __restrict__ Cpre = reinterpret_cast<OT*>(p.out_pre);
+    const bf16_t* __restrict__ ref = reinterpret_cast<const bf16_t*>(p.relu_ref);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        const bool n_ok = n < p.N;
+        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int oy = oy0 + (ml >> 6), ox = ox0 + (ml & 63);
+                if (!(n_ok && oy < p.Ho && ox < p.Wo)) continue;
+                const long long m = ((long long)b * p.Ho + oy) * p.Wo + ox;
+                float v = p.alpha * acc[i][j][e] + bias;
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                else if (p.act == 2) v = tanhf(v);
+                const long long o = m * p.ldc + n;
+                if (Cpre) Cpre[o] = from_f32<OT>(v);
+                if (p.addend) v += p.addend[(m % p.addend_rows) * p.N + n];
+                if (ref) v = (to_f32(ref[m * p.ldr + n]) > 0.f) ? v : 0.f;
+                csum += v;
+                if (p.accumulate) v += to_f32(C[o]);
+                C[o] = from_f32<OT>(v);
+            }
+        }
+        if (p.colsum) {
+            csum += __shfl_xor(csum, 32);
+            if (lane < 32 && n_ok) atomicAdd(&p.colsum[n], csum);
+        }
+    }
+}
+
 }  // namespace
 
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
+    static int use_halo = -1;
+    if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
+    if (use_halo) {
+        static bool halo_attr = false;
+        constexpr int LDSB = 2 * HPATCH + 3 * HB_STAGE;
+        if (!halo_attr) {
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+            halo_attr = true;
+        }
+        const int B = p.M / (p.Ho * p.Wo);
+        const int tiles_n = cdiv(p.N, CBN), tiles_x = cdiv(p.Wo, HTW), tiles_y = cdiv(p.Ho, HTH);
+        hipLaunchKernelGGL((conv_halo_kernel<bf16_t>), dim3(B * tiles_x * tiles_y * tiles_n), dim3(CTH), LDSB, s, p, tiles_n, tiles_x, tiles_y);
+        return (int)hipGetLastError();
+    }
     static bool attr_set = false;
     if (!attr_set) {
         HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE));

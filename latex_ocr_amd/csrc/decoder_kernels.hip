@@ -33,7 +33,16 @@ LXO_DEV float slab_sum(const Slabs& sl, long long row, int col) {
 LXO_DEV f32x4 slab_sum4(const Slabs& sl, long long row, int col) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float* q = sl.p + row * sl.ld + col;
-    for (int s = 0; s < sl.n; ++s) v += *reinterpret_cast<const f32x4*>(q + (long long)s * sl.stride);
+    for (int s0 = 0; s0 < sl.n; s0 += 8) {              // 8 slab loads in flight at a time
+        f32x4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            t[j] = (s0 + j < sl.n) ? *reinterpret_cast<const f32x4*>(q + (long long)(s0 + j) * sl.stride) : z;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
     return v;
 }
 
