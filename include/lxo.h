@@ -37,6 +37,11 @@ int lxo_gemm_nt(int dt, int a_f32, int c_f32, int small, const void* A, const vo
 int lxo_gemm_tn(int dt, int a_f32, int b_f32, const void* A, const void* B, float* C,
                 int M, int I, int J, int lda, int ldb, int ldc, int nsplit, int atomic, void* stream);
 
+/* split-K partial products of a skinny GEMM (the recurrent steps): slab[ks][M][ldc] = A[:, ks*128:+128] *
+ * Bp[:, same]^T for ks < K/128, A float [M][lda], Bp compute dtype [N][ldb]; the consumer adds the slabs. */
+int lxo_gemm_slab(int dt, const void* A, const void* Bp, float* slab, int M, int N, int K, int lda, int ldb, int ldc,
+                  long long slab_stride, void* stream);
+
 /* 3x3 stride-1 convolution as an implicit GEMM on the MFMA units (the tf.layers.conv2d call
  * sites model/encoder.py:37-59): out[B,Ho,Wo,Cout] = act(conv(in[B,H,W,Cin]) + bias), NHWC,
  * in/out/wpk in the compute dtype, wpk = [Cout][9*Cin] (tap-major, channel-minor).
@@ -44,6 +49,11 @@ int lxo_gemm_tn(int dt, int a_f32, int b_f32, const void* A, const void* B, floa
  * dgrad of a VALID layer.  Cin % 64 == 0 (bf16) / % 32 (f32). */
 int lxo_conv3x3(int dt, const void* in, const void* wpk, const float* bias, void* out, int B, int H, int W,
                 int Cin, int Ho, int Wo, int Cout, int pad, int relu, void* stream);
+
+/* weight gradient of lxo_conv3x3: dw[9*Cin][Cout] (f32, HWIO flattened) += sum_pixels in (x) dout.
+ * What TF autodiff derives for the tf.layers.conv2d kernels (model/img2seq.py:119-123). */
+int lxo_conv3x3_wgrad(int dt, const void* in, const void* dout, float* dw, int B, int H, int W,
+                      int Cin, int Ho, int Wo, int Cout, int pad, void* stream);
 
 /* AttentionMechanism.context (model/components/attention_mechanism.py:46-94) for nv decoder rows:
  * alpha = softmax_r(sum_k beta_k tanh(att_img[r,k] + att_h[k])), ctx = sum_r alpha_r img[r,:].

@@ -151,3 +151,15 @@ extern "C" int lxo_gemm_slab(int dt, const void* A, const void* Bp, float* slab,
     CHECK_LAUNCH(lxo_launch_gemm_slab(dt, p, slab, slab_stride, (hipStream_t)stream), "lxo_gemm_slab");
     return 0;
 }
+
+extern "C" int lxo_conv3x3_wgrad(int dt, const void* in, const void* dout, float* dw, int B, int H, int W,
+                                 int Cin, int Ho, int Wo, int Cout, int pad, void* stream) {
+    GemmTN g; memset(&g, 0, sizeof(g));
+    g.A = in; g.B = dout; g.C = dw; g.conv = 1; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.pad = pad;
+    g.M = B * Ho * Wo; g.I = 9 * Cin; g.J = Cout; g.lda = Cin; g.ldb = Cout; g.ldc = Cout;
+    const int tiles = cdiv(g.I, 128) * cdiv(g.J, 128);
+    int ns = cdiv(1024, tiles); const int maxs = g.M / 256 > 0 ? g.M / 256 : 1; if (ns > maxs) ns = maxs;
+    g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
+    CHECK_LAUNCH(lxo_launch_gemm_tn(dt, 0, 0, g, (hipStream_t)stream), "lxo_conv3x3_wgrad");
+    return 0;
+}

@@ -1,0 +1,173 @@
+// 3x3 convolution weight gradient on the bf16 MFMA units, gfx950:
+//     dW[tap][ci][co] += sum over pixels  in[pixel + tap][ci] * d_out[pixel][co]
+//
+// A workgroup owns a (64 ci) x (128 co) tile of ALL NINE taps (9 x 32x32 accumulator tiles per
+// wave = 144 registers) and walks a range of 2 x 64 pixel blocks.  Per block it stages, by
+// LDS-DMA and double buffered, the (2+2) x (64+2) input patch for its 64 channels and the 128
+// d_out pixels for its 128 channels -- each once, serving all nine taps (262 FLOP per staged
+// byte).  The contraction runs over PIXELS, which are the strided index of NHWC, so MFMA
+// operands are fetched with the transposing LDS read ds_read_b64_tr_b16 (4 consecutive pixels
+// of one channel per lane); the kw = 0/1/2 shifted operands of a patch row come from the same
+// three reads through v_alignbit.  Partial tiles are reduced with f32 atomics.
+#include "gemm.h"
+#include "api_util.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ unsigned lxo_wg_zero_line[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+constexpr int WTH = 2, WTW = 64, WPW = WTW + 2, WPH = WTH + 2, WPROWS = WPH * WPW;   // 264 patch pixels
+constexpr int WTHREADS = 512;
+constexpr int WPATCH = 5 * WTHREADS * 16;           // 40960 B: 2560 slots >= 264 * 8
+constexpr int WDY = WTH * WTW * 256;                // 32768 B: 128 pixels x 128 co
+constexpr int WSTAGE = WPATCH + WDY;
+constexpr int WCI = 64, WCO = 128;
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short v4s_t;
+typedef __attribute__((address_space(3))) v4s_t* ltr_t;
+LXO_DEV void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)g, (lptr_t)(uintptr_t)l, 16, 0, 0);
+}
+// 4 consecutive pixels (rows of the LDS image) of this lane's channel, as two dwords of bf16 pairs
+LXO_DEV u32x2 tr_read(const char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(uintptr_t)p));
+}
+
+}  // namespace
+
+HIP_DYNAMIC_SHARED(char, lxo_wgrad_lds)
+
+namespace {
+
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co, int tiles_x, int tiles_y, int nblocks, int per_split) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wci = wave >> 2, wco = wave & 3;            // 2 x 4 waves: 32 ci x 32 co each (x 9 taps)
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int ci0 = (tile / tiles_co) * WCI, co0 = (tile % tiles_co) * WCO;
+    const int Cout = p.J;
+    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(p.B);
+    const char* zline = reinterpret_cast<const char*>(lxo_wg_zero_line);
+    const int pb_beg = split * per_split, pb_end = min(nblocks, pb_beg + per_split);
+    if (pb_beg >= pb_end) return;
+
+    const int sch = tid & 7;                               // patch: 16-byte chunk (8 channels) of the 64-channel row
+    const int dch = tid & 15;                              // d_out: 16-byte chunk of the 128-channel row
+    auto issue = [&](int pb, int stage) {
+        char* ps = lxo_wgrad_lds + stage * WSTAGE;
+        char* ds = ps + WPATCH;
+        const int tx_i = pb % tiles_x, ty_i = (pb / tiles_x) % tiles_y, b = pb / (tiles_x * tiles_y);
+        const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {                      // 5 LDS-DMA: patch pixel prow = (tid >> 3) + 64 j
+            const int prow = (tid >> 3) + 64 * j;
+            const int py = prow / WPW, px = prow - py * WPW;
+            const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+            const bool ok = prow < WPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int gch = (sch ^ ((prow >> 1) & 7)) << 3;
+            const void* src = ok ? (const void*)(X + (((long long)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + gch) : (const void*)zline;
+            glds16(src, ps + (wave * 64 + 512 * j) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                      // 4 LDS-DMA: block pixel k = (tid >> 4) + 32 j
+            const int k = (tid >> 4) + 32 * j;
+            const int oy = oy0 + (k >> 6), ox = ox0 + (k & 63);
+            const bool ok = oy < p.Ho && ox < p.Wo && (co0 + (dch << 3)) < Cout;
+            const int gch = (dch ^ (k & 15)) << 3;
+            const void* src = ok ? (const void*)(DY + (((long long)b * p.Ho + oy) * p.Wo + ox) * Cout + co0 + gch) : (const void*)zline;
+            glds16(src, ds + (wave * 64 + 512 * j) * 16);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // lane geometry of the transposing reads: group g = (lane>>4)&1 (16 channels), q = lane&15 -> (j = q>>2: pixel, c = q&3: 4 channels)
+    const int h = lane >> 5, g = (lane >> 4) & 1, qj = (lane & 15) >> 2, qc = lane & 3;
+    const int a_ch = wci * 32 + 16 * g + 4 * qc;           // channel (within the 64) this lane addresses
+    const int a_chunk = a_ch >> 3, a_sub = (a_ch & 7) * 2;  // 16-byte chunk, byte offset inside it
+    const int b_ch = wco * 32 + 16 * g + 4 * qc;           // channel (within the 128)
+    const int b_chunk = b_ch >> 3, b_sub = (b_ch & 7) * 2;
+
+    issue(pb_beg, 0);
+    for (int pb = pb_beg; pb < pb_end; ++pb) {
+        const int stage = (pb - pb_beg) & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): only this block's loads are outstanding here
+        __builtin_amdgcn_s_barrier();
+        if (pb + 1 < pb_end) issue(pb + 1, stage ^ 1);
+        const char* ps = lxo_wgrad_lds + stage * WSTAGE;
+        const char* ds = ps + WPATCH;
+#pragma unroll 1
+        for (int ks = 0; ks < 8; ++ks) {                   // 16 pixels per K-step: row ty = ks>>2, x = (ks&3)*16 + 8h ..
+            const int ty = ks >> 2, xk = (ks & 3) * 16 + 8 * h;
+            // B operand: d_out pixels k0..k0+7 of this lane's channel
+            u32x4 bfr;
+            {
+                const int k0 = ty * 64 + xk;
+                const int ka = k0 + qj, kb = k0 + 4 + qj;
+                const u32x2 lo = tr_read(ds + ka * 256 + ((b_chunk ^ (ka & 15)) << 4) + b_sub);
+                const u32x2 hi = tr_read(ds + kb * 256 + ((b_chunk ^ (kb & 15)) << 4) + b_sub);
+                bfr = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                // patch row ty + kh, pixels xk .. xk+11 -> three reads, six dwords of pixel pairs
+                const int pr0 = (ty + kh) * WPW + xk;
+                unsigned d[6];
+#pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3) {
+                    const int prow = pr0 + 4 * q3 + qj;
+                    const u32x2 v = tr_read(ps + prow * 128 + ((a_chunk ^ ((prow >> 1) & 7)) << 4) + a_sub);
+                    d[2 * q3] = v[0]; d[2 * q3 + 1] = v[1];
+                }
+                const u32x4 a0 = {d[0], d[1], d[2], d[3]};
+                const u32x4 a1 = {__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
+                                  __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16)};
+                const u32x4 a2 = {d[1], d[2], d[3], d[4]};
+                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 0], 0, 0, 0);
+                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 1], 0, 0, 0);
+                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 2], 0, 0, 0);
+            }
+        }
+    }
+    // reduce into dW[(tap*Cin + ci)][co]
+    const int co = co0 + wco * 32 + (lane & 31);
+    if (co < Cout) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = ci0 + wci * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (ci < p.Cin) atomicAdd(&p.C[((long long)t * p.Cin + ci) * p.ldc + co], acc[t][e]);
+            }
+    }
+}
+
+}  // namespace
+
+// bf16 only; Cin % 64 == 0, Cout % 8 == 0
+int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
+    if (!p.conv || p.Cin % 64 || p.J % 8) return -2;
+    static bool attr = false;
+    if (!attr) {
+        HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE));
+        attr = true;
+    }
+    const int B = p.M / (p.Ho * p.Wo);
+    const int tiles_ci = p.Cin / WCI, tiles_co = cdiv(p.J, WCO);
+    const int tiles_x = cdiv(p.Wo, WTW), tiles_y = cdiv(p.Ho, WTH);
+    const int nblocks = B * tiles_x * tiles_y;
+    const int tiles = tiles_ci * tiles_co;
+    int nsplit = cdiv(256, tiles);
+    if (nsplit > nblocks) nsplit = nblocks;
+    const int per_split = cdiv(nblocks, nsplit);
+    nsplit = cdiv(nblocks, per_split);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, nsplit), dim3(WTHREADS), 2 * WSTAGE, s, p, tiles_co, tiles_x, tiles_y, nblocks, per_split);
+    return (int)hipGetLastError();
+}

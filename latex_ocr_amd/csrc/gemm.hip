@@ -14,6 +14,7 @@
 // bf16 mode uses v_mfma_f32_32x32x16_bf16 (f32 accumulate); f32 mode (parity
 // mode) uses v_mfma_f32_32x32x2_f32, which is an exact fmaf chain.
 #include "gemm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -674,6 +675,9 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
     }
     if (p.conv) {
         if (a_f32 || b_f32) return -3;
+        static int use_halo = -1;
+        if (use_halo < 0) { const char* e = getenv("LXO_WGRAD_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
+        if (use_halo && p.Cin % 64 == 0 && p.J % 8 == 0 && p.atomic && p.nbatch == 1) return lxo_launch_conv_wgrad(p, s);
         return launch_tn<bf16_t, true, bf16_t, bf16_t>(p, s);
     }
     if (!a_f32 && !b_f32) return launch_tn<bf16_t, false, bf16_t, bf16_t>(p, s);

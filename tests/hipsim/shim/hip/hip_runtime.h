@@ -240,6 +240,28 @@ inline v4f mfma_16x16x4_f32(float a, float b, v4f c) {
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipsim::mfma_32x32x2_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipsim::mfma_16x16x4_f32(a, b, c)
 
+// ds_read_b64_tr_b16 (semantics measured on gfx950): within each group of 16 lanes let chunk[q] be the
+// four b16 at lane q's address; lane i receives result[j] = chunk[4*j + (i >> 2)][i & 3], j = 0..3.
+typedef __attribute__((ext_vector_type(4))) short hipsim_v4s;
+template <class Lp> inline hipsim_v4s hipsim_ds_read_tr16_b64(Lp p) {
+    unsigned l = hipsim::lane();
+    uintptr_t a = (uintptr_t)p;
+    memcpy(hipsim::slot(l), &a, sizeof(a));
+    hipsim::wave_sync();
+    hipsim_v4s r;
+    const unsigned g = l & ~15u, i = l & 15u;
+    for (int j = 0; j < 4; ++j) {
+        uintptr_t qa; memcpy(&qa, hipsim::slot(g + 4 * j + (i >> 2)), sizeof(qa));
+        short v; memcpy(&v, reinterpret_cast<const char*>(qa) + 2 * (i & 3), 2);
+        r[j] = v;
+    }
+    hipsim::wave_sync();
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipsim_ds_read_tr16_b64(p)
+inline unsigned hipsim_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
+#define __builtin_amdgcn_alignbit(hi, lo, sh) hipsim_alignbit(hi, lo, sh)
+
 // LDS-DMA: every lane copies `size` bytes from its own global pointer to (wave-uniform LDS base + lane*size)
 template <class G, class Lp> inline void hipsim_global_load_lds(G g, Lp l, unsigned size, int off, unsigned) {
     memcpy(reinterpret_cast<char*>((uintptr_t)l) + off + hipsim::lane() * size, reinterpret_cast<const void*>((uintptr_t)g), size);
