@@ -84,3 +84,37 @@ def test_gemm_tn(dt, a_f32, b_f32, M, I, J, nsplit):
     ref = C0 + Aref.astype(np.float64).T @ Bref.astype(np.float64)
     err = np.abs(C.cpu().numpy() - ref).max() / np.abs(ref).max()
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,valid", [(3, 10, 70, 64, 128, 0), (2, 16, 64, 128, 256, 1), (2, 7, 130, 256, 64, 0), (1, 32, 128, 64, 128, 0)])
+def test_conv3x3_fwd_and_wgrad_bf16(B, H, W, Cin, Cout, valid):
+    """implicit-GEMM conv (halo tiles, LDS-DMA) and the tap-reuse weight gradient (transposing LDS reads)
+    against torch conv2d on the same bf16-rounded operands."""
+    import torch.nn.functional as F
+    L = _lib()
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(3, 3, Cin, Cout, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(Cout, generator=g)
+    Ho, Wo = (H - 2, W - 2) if valid else (H, W)
+    pad = 0 if valid else 1
+    wpk = w.reshape(9 * Cin, Cout).t().contiguous()                       # [Cout][9*Cin]
+    xd, wd, bd = x.cuda(), wpk.cuda(), bias.cuda()
+    y = torch.zeros(B, Ho, Wo, Cout, dtype=torch.bfloat16, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.lxo_conv3x3(1, _p(xd), _p(wd), _p(bd), _p(y), B, H, W, Cin, Ho, Wo, Cout, pad, 1, st) == 0, L.lxo_last_error()
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.float().permute(3, 2, 0, 1).double(), bias.double(), padding=pad))
+    ref = ref.permute(0, 2, 3, 1).float()
+    torch.cuda.synchronize()
+    err = (y.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 6e-3, err
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g).to(torch.bfloat16)
+    dw = torch.zeros(9 * Cin, Cout, device="cuda")
+    assert L.lxo_conv3x3_wgrad(1, _p(xd), _p(dy.cuda()), _p(dw), B, H, W, Cin, Ho, Wo, Cout, pad, st) == 0, L.lxo_last_error()
+    wr = w.float().permute(3, 2, 0, 1).double().requires_grad_(True)
+    out = F.conv2d(x.float().permute(0, 3, 1, 2).double(), wr, None, padding=pad)
+    (out * dy.float().permute(0, 3, 1, 2).double()).sum().backward()
+    refw = wr.grad.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).float()       # HWIO flattened
+    torch.cuda.synchronize()
+    errw = (dw.cpu() - refw).abs().max().item() / refw.abs().max().item()
+    assert errw < 2e-5, errw
