@@ -105,6 +105,12 @@ int lxo_encoder_fwd(const lxo_shape* s, const float* params, const void* wpack, 
 int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                     const uint8_t* img, float* grads, int last_layer, int first_layer, void* stream);
 
+/* Optional second HIP stream for the calling host thread (NULL disables).  When set, the recurrent
+ * loops of lxo_decoder_train_fwd / _bwd run the two halves of the batch on `stream` and on this side
+ * stream (fork/join by events), so the launch- and latency-bound step kernels of one half overlap the
+ * other half's.  The only per-thread state the library keeps. */
+int lxo_set_side_stream(void* stream);
+
 /* Decoder.__call__ training branch (model/decoder.py:41-57): AttentionMechanism
  * set-up (attention_mechanism.py:19-43,124-153), T steps of AttentionCell.step
  * (attention_cell.py:58-89) under teacher forcing, logits for every step. */

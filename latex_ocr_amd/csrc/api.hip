@@ -163,3 +163,8 @@ extern "C" int lxo_conv3x3_wgrad(int dt, const void* in, const void* dout, float
     CHECK_LAUNCH(lxo_launch_gemm_tn(dt, 0, 0, g, (hipStream_t)stream), "lxo_conv3x3_wgrad");
     return 0;
 }
+
+extern "C" int lxo_set_side_stream(void* stream) {
+    CHECK_LAUNCH(lxo_impl_set_side_stream((hipStream_t)stream), "lxo_set_side_stream");
+    return 0;
+}

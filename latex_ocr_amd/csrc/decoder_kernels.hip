@@ -844,6 +844,17 @@ int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo
     LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, rows, cols);
     DONE;
 }
+__global__ __launch_bounds__(256) static void slab_reduce_kernel(Slabs sl, float* __restrict__ o, int ldo, int rows, int cols) {
+    const int total = rows * (cols >> 2);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / (cols >> 2), c = (i - r * (cols >> 2)) << 2;
+        *reinterpret_cast<f32x4*>(o + (long long)r * ldo + c) = slab_sum4(sl, r, c);
+    }
+}
+int lxo_k_slab_reduce(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st) {
+    LAUNCH(slab_reduce_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, rows, cols);
+    DONE;
+}
 int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st) {
     LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, rows, cols);
     DONE;

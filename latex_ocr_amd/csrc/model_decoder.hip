@@ -69,25 +69,52 @@ static int attention_prepare(const Plan& P, const float* prm, const void* wp, vo
     return 0;
 }
 
-// One AttentionCell.step (attention_cell.py:58-89) for nv rows.  zx_t must already hold
-// emb_t * K[0:D] + b; rec_prev/cs_prev = state t-1 (o final), rec_cur/cs_cur receive state t.
-// Every GEMM is a split-K slab GEMM; the kernel that consumes a product adds its slabs.
-static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam,
+// Side stream for the half-batch interleave of the recurrent loop (set per host thread through
+// lxo_set_side_stream; null = single stream).  The recurrence is a chain of ~13 short, latency-bound
+// launches per step pair; the two halves of the batch are independent, so running them on two HIP
+// streams lets one half's launch/latency gaps be filled by the other half's kernels.
+static thread_local hipStream_t g_side = nullptr;
+static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+int lxo_impl_set_side_stream(hipStream_t s) {
+    g_side = s;
+    if (s && !g_ev_fork) {
+        HIPRC(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
+        HIPRC(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
+    }
+    return 0;
+}
+static int fork_side(hipStream_t st) { HIPRC(hipEventRecord(g_ev_fork, st)); HIPRC(hipStreamWaitEvent(g_side, g_ev_fork, 0)); return 0; }
+static int join_side(hipStream_t st) { HIPRC(hipEventRecord(g_ev_join, g_side)); HIPRC(hipStreamWaitEvent(st, g_ev_join, 0)); return 0; }
+
+// One AttentionCell.step (attention_cell.py:58-89) for rows [r0, r0+nr) of nv decoder rows.  The step
+// pointers address row 0; zx_t must already hold emb_t * K[0:D] + b; rec_prev/cs_prev = state t-1
+// (o final), rec_cur/cs_cur receive state t.  Every GEMM is a split-K slab GEMM; the kernel that
+// consumes a product adds its slabs.
+static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int r0, int nr, int beam,
                      const float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
                      float* gates_t, float* atth_t, float* alpha_t, hipStream_t st) {
     const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
-    float* s1 = P.ws<float>(ws, W_S_K1); float* s2 = P.ws<float>(ws, W_S_K2); float* s4 = P.ws<float>(ws, W_S_K4);
+    const size_t r = (size_t)r0;
+    float* s1 = P.ws<float>(ws, W_S_K1) + r * (P.XH / 128) * 4 * U;
+    float* s2 = P.ws<float>(ws, W_S_K2) + r * (U / 128) * E;
+    float* s4 = P.ws<float>(ws, W_S_K4) + r * (P.HC / 128) * O;
+    zx_t += r * 4 * U; rec_prev += r * P.REC; cs_prev += r * U; rec_cur += r * P.REC; cs_cur += r * U;
+    if (gates_t) gates_t += r * 4 * U;
+    atth_t += r * E; alpha_t += r * P.Rp;
+    const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG) + (r / beam) * P.R * E * P.esz;
+    const char* img = (const char*)P.ws<void>(ws, W_IMG) + (r / beam) * P.R * C * P.esz;
+    float* part = P.ws<float>(ws, W_APART) + r * 32 * (C + 2);
     // z = zx + [o_prev, h_prev] K[D:]            (attention_cell.py:70-71)
-    RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, s1, nv, 4 * U, P.XH, st));
-    RC(lxo_k_lstm_fwd(zx_t, view(s1, P.XH, nv, 4 * U), cs_prev, gates_t, cs_cur, rec_cur + O, P.REC, nv, U, st));
+    RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, s1, nr, 4 * U, P.XH, st));
+    RC(lxo_k_lstm_fwd(zx_t, view(s1, P.XH, nr, 4 * U), cs_prev, gates_t, cs_cur, rec_cur + O, P.REC, nr, U, st));
     // att_h = h W                                 (attention_mechanism.py:79)
-    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, s2, nv, E, U, st));
-    RC(lxo_k_attn_fwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), nullptr, view(s2, U, nv, E), atth_t,
-                      prm + P.poff[P_BETA], alpha_t, P.ws<float>(ws, W_APART), rec_cur + P.XH, P.REC, nv, P.R, P.Rp, E, C, beam,
-                      P.attn_chunks(nv), st));
+    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, s2, nr, E, U, st));
+    RC(lxo_k_attn_fwd(P.s.dtype, att_img, img, nullptr, view(s2, U, nr, E), atth_t,
+                      prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.XH, P.REC, nr, P.R, P.Rp, E, C, beam,
+                      P.attn_chunks(nr), st));
     // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
-    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, s4, nv, O, P.HC, st));
-    RC(lxo_k_tanh_finalize(view(s4, P.HC, nv, O), rec_cur, P.REC, nv, O, st));
+    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, s4, nr, O, P.HC, st));
+    RC(lxo_k_tanh_finalize(view(s4, P.HC, nr, O), rec_cur, P.REC, nr, O, st));
     return 0;
 }
 
@@ -99,14 +126,18 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     RC(nt(P, false, true, false, P.ws<void>(ws, W_EMB_IN), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, T * B, 4 * U, P.Dp,
           prm + P.poff[P_LSTM_B], 0, false, st));
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
-    for (int t = 0; t < T; ++t) {
-        RC(cell_step(P, prm, wp, ws, B, 1, zx + (size_t)t * B * 4 * U,
-                     rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
-                     rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
-                     P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
-                     P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
-                     P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, st));
-    }
+    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
+    const int nh = dual ? 2 : 1, hb = B / nh;
+    if (dual) RC(fork_side(st));
+    for (int t = 0; t < T; ++t)
+        for (int h = 0; h < nh; ++h)
+            RC(cell_step(P, prm, wp, ws, h * hb, hb, 1, zx + (size_t)t * B * 4 * U,
+                         rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
+                         rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
+                         P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
+                         P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
+                         P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, h ? g_side : st));
+    if (dual) RC(join_side(st));
     // logits_t = o_t y_W_o for every step at once  (attention_cell.py:84)
     RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
           T * B, V, O, nullptr, 0, false, st));
@@ -137,28 +168,47 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
 
     HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
     HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));     // attention chunks accumulate d_att_h with atomics
-    const int nchb = P.attn_chunks(B);
-    float* sb1 = P.ws<float>(ws, W_S_B1); float* sb3 = P.ws<float>(ws, W_S_B3); float* sb4 = P.ws<float>(ws, W_S_B4);
+    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
+    const int nh = dual ? 2 : 1, hb = B / nh;
+    const int nchb = P.attn_chunks(hb);
+    if (dual) RC(fork_side(st));
     for (int t = T - 1; t >= 0; --t) {
-        const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
-        float* g_t = gall + (size_t)t * B * O;
-        float* dhc_t = dhc + (size_t)t * B * P.HC;
-        // carry [d_o | d_h] from step t+1 = the B4 slabs of the previous iteration (none at t = T-1)
-        const Slabs carry = (t == T - 1) ? kNoSlabs : view(sb4, 4 * U, B, P.XH);
-        // g = (d_o_logits + d_o_carry) * (1 - o^2)
-        RC(lxo_k_tanh_bwd(dolog + (size_t)t * B * O, O, carry, rec_cur, P.REC, g_t, O, B, O, st));
-        // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
-        RC(slab(P, g_t, O, P.pk(wp, K_OW), O, sb1, B, P.HC, O, st));
-        RC(lxo_k_attn_bwd(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_IMG), atth + (size_t)t * B * E, prm + P.poff[P_BETA],
-                          alpha + (size_t)t * B * P.Rp, view(sb1, O, B, P.HC), U, dhc_t + U, P.HC, rec_cur + P.XH, P.REC,
-                          de + (size_t)t * B * P.Rp, datth + (size_t)t * B * E, B, P.R, P.Rp, E, C, nchb, st));
-        // d_h += d_att_h W_att_h^T
-        RC(slab(P, datth + (size_t)t * B * E, E, P.pk(wp, K_ATT_H), E, sb3, B, U, E, st));
-        RC(lxo_k_lstm_bwd(gates + (size_t)t * B * 4 * U, cs + (size_t)t * B * U, cs + (size_t)(t + 1) * B * U,
-                          view(sb1, O, B, P.HC), view(sb3, E, B, U), carry, O, dcc, dz + (size_t)t * B * 4 * U, B, U, st));
-        // [d_o carry | d_h carry] = d_z K[D:]^T
-        RC(slab(P, dz + (size_t)t * B * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
-                sb4, B, P.XH, 4 * U, st));
+        for (int h = 0; h < nh; ++h) {
+            hipStream_t sh = h ? g_side : st;
+            const size_t r0 = (size_t)h * hb;
+            float* sb1 = P.ws<float>(ws, W_S_B1) + r0 * (O / 128) * P.HC;
+            float* sb3 = P.ws<float>(ws, W_S_B3) + r0 * (E / 128) * U;
+            float* sb4 = P.ws<float>(ws, W_S_B4) + r0 * (4 * U / 128) * P.XH;
+            const float* rec_cur = rec + ((size_t)(t + 1) * B + r0) * P.REC;
+            float* g_t = gall + ((size_t)t * B + r0) * O;
+            float* dhc_t = dhc + ((size_t)t * B + r0) * P.HC;
+            const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG) + r0 * P.R * E * P.esz;
+            const char* img = (const char*)P.ws<void>(ws, W_IMG) + r0 * P.R * C * P.esz;
+            // carry [d_o | d_h] from step t+1 = the B4 slabs of the previous iteration (none at t = T-1)
+            const Slabs carry = (t == T - 1) ? kNoSlabs : view(sb4, 4 * U, hb, P.XH);
+            // g = (d_o_logits + d_o_carry) * (1 - o^2)
+            RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, hb, O, sh));
+            // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
+            RC(slab(P, g_t, O, P.pk(wp, K_OW), O, sb1, hb, P.HC, O, sh));
+            RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + ((size_t)t * B + r0) * E, prm + P.poff[P_BETA],
+                              alpha + ((size_t)t * B + r0) * P.Rp, view(sb1, O, hb, P.HC), U, dhc_t + U, P.HC, rec_cur + P.XH, P.REC,
+                              de + ((size_t)t * B + r0) * P.Rp, datth + ((size_t)t * B + r0) * E, hb, P.R, P.Rp, E, C, nchb, sh));
+            // d_h += d_att_h W_att_h^T
+            RC(slab(P, datth + ((size_t)t * B + r0) * E, E, P.pk(wp, K_ATT_H), E, sb3, hb, U, E, sh));
+            RC(lxo_k_lstm_bwd(gates + ((size_t)t * B + r0) * 4 * U, cs + ((size_t)t * B + r0) * U, cs + ((size_t)(t + 1) * B + r0) * U,
+                              view(sb1, O, hb, P.HC), view(sb3, E, hb, U), carry, O, dcc + r0 * U, dz + ((size_t)t * B + r0) * 4 * U, hb, U, sh));
+            // [d_o carry | d_h carry] = d_z K[D:]^T
+            RC(slab(P, dz + ((size_t)t * B + r0) * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
+                    sb4, hb, P.XH, 4 * U, sh));
+        }
+    }
+    if (dual) RC(join_side(st));
+    // the final carries of the two halves are separate slab sets; gather them into one [B][XH] buffer
+    float* dxh = P.ws<float>(ws, W_DXH);
+    for (int h = 0; h < nh; ++h) {
+        const size_t r0 = (size_t)h * hb;
+        float* sb4 = P.ws<float>(ws, W_S_B4) + r0 * (4 * U / 128) * P.XH;
+        RC(lxo_k_slab_reduce(view(sb4, 4 * U, hb, P.XH), dxh + r0 * P.XH, P.XH, hb, P.XH, st));
     }
     // ---- deferred weight gradients over all steps ----
     RC(tn(P, true, true, rec + (size_t)B * P.REC + O, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));       // d[o_W_h; o_W_c]
@@ -173,7 +223,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     // ---- initial states ----
     float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
     const int W3 = 2 * U + O;
-    RC(lxo_k_init_bwd(dcc, view(sb4, 4 * U, B, P.XH), cs, rec, P.REC, dpre, B, U, O, st));
+    { const Slabs one = {dxh, 1, 0, P.XH}; RC(lxo_k_init_bwd(dcc, one, cs, rec, P.REC, dpre, B, U, O, st)); }
     RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, st));
     RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, st));
     RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, st));
@@ -211,7 +261,7 @@ static int decode_common_step(const Plan& P, const float* prm, const void* wp, v
     RC(nt(P, false, true, false, P.ws<void>(ws, W_DEC_EMB), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, nv, 4 * U, P.Dp,
           prm + P.poff[P_LSTM_B], 0, false, st));
     const int prev = cur ^ 1;
-    RC(cell_step(P, prm, wp, ws, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
+    RC(cell_step(P, prm, wp, ws, 0, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
                  rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U, nullptr,
                  P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), st));
     RC(nt(P, true, true, nv <= 64, rec + (size_t)cur * nv * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_DEC_LOGITS), P.Vp,

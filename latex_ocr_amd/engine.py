@@ -7,6 +7,7 @@ there is no eager/PyTorch compute path and no CPU fallback here.
 """
 import ctypes
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -55,6 +56,10 @@ class Engine(object):
         first_dec = self._offsets["Decoder/embedding_table"][0]
         c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]
         self.buckets = [(first_dec, self.n_params), (c5, first_dec), (0, c5)]
+        # second stream for the half-batch interleave of the recurrent loop
+        self.side_stream = None
+        if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "1") != "0":
+            self.side_stream = torch.cuda.Stream(self.device)
         self.load_params(PP.init_params(self.n_tok, seed, self.dims))
 
     # ------------------------------------------------------------ plumbing --
@@ -143,9 +148,14 @@ class Engine(object):
         self._img = self._to_dev(img, torch.uint8)
         self._formula = self._to_dev(formula, torch.int32)
         st = self._stream()
+        self._bind_side()
         self._ck(self.lib.lxo_encoder_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), st), "encoder_fwd")
         self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
                  "decoder_train_fwd")
+
+    def _bind_side(self):
+        side = ctypes.c_void_p(self.side_stream.cuda_stream) if self.side_stream is not None else ctypes.c_void_p(0)
+        self._ck(self.lib.lxo_set_side_stream(side), "set_side_stream")
 
     def loss(self, lengths, inv_ntok):
         self._lengths = self._to_dev(lengths, torch.int32)
@@ -157,6 +167,7 @@ class Engine(object):
         """BPTT + encoder backward into self.grads (zeroed first).  `comm(lo, hi)` is called as soon
         as the gradient range [lo, hi) is final (data-parallel bucket all-reduce hook)."""
         st = self._stream()
+        self._bind_side()
         self.grads.zero_()
         self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
                                                 _p(self.grads), st), "decoder_train_bwd")

@@ -59,7 +59,17 @@ def _run(dtype):
     return S, img, f, l
 
 
-def test_forward_backward_f32_vs_golden():
+@pytest.mark.parametrize("dual", [0, 1])
+def test_forward_backward_f32_vs_golden(dual):
+    # dual = 1: the half-batch / side-stream code path of the recurrent loops (streams are no-ops under hipsim)
+    lib().lxo_set_side_stream(ctypes.c_void_p(1 if dual else 0))
+    try:
+        _check_fwd_bwd()
+    finally:
+        lib().lxo_set_side_stream(ctypes.c_void_p(0))
+
+
+def _check_fwd_bwd():
     S, img, f, l = _run(0)
     T = f.shape[1]
     logits = S.region("logits", np.float32, (T, 2, 32))[:, :, :11].transpose(1, 0, 2)
