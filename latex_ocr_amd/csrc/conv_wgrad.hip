@@ -75,8 +75,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
         for (int j = 0; j < 4; ++j) {                      // 4 LDS-DMA: block pixel k = (tid >> 4) + 32 j
             const int k = (tid >> 4) + 32 * j;
             const int oy = oy0 + (k >> 6), ox = ox0 + (k & 63);
-            const bool ok = oy < p.Ho && ox < p.Wo && (co0 + (dch << 3)) < Cout;
-            const int gch = (dch ^ (k & 15)) << 3;
+            const int gch = (dch ^ (k & 15)) << 3;            // the GLOBAL chunk this lane fetches (LDS slot dch holds it)
+            const bool ok = oy < p.Ho && ox < p.Wo && (co0 + gch) < Cout;
             const void* src = ok ? (const void*)(DY + (((long long)b * p.Ho + oy) * p.Wo + ox) * Cout + co0 + gch) : (const void*)zline;
             glds16(src, ds + (wave * 64 + 512 * j) * 16);
         }

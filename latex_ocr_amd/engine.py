@@ -56,9 +56,11 @@ class Engine(object):
         first_dec = self._offsets["Decoder/embedding_table"][0]
         c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]
         self.buckets = [(first_dec, self.n_params), (c5, first_dec), (0, c5)]
-        # second stream for the half-batch interleave of the recurrent loop
+        # optional second stream for the half-batch interleave of the recurrent loop (LXO_DUAL_STREAM=1).
+        # Measured slower than one stream in round 1 (18.8 vs 17.3 ms/step: twice the launches make the
+        # eager host loop the bottleneck), so it is off by default until the loop is graph-captured.
         self.side_stream = None
-        if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "1") != "0":
+        if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "0") == "1":
             self.side_stream = torch.cuda.Stream(self.device)
         self.load_params(PP.init_params(self.n_tok, seed, self.dims))
 
