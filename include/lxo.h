@@ -133,6 +133,12 @@ int lxo_global_norm_scale(long long n, const float* grads, float clip, float* sc
 int lxo_adam_step(long long n, float* params, const float* grads, float* m, float* v,
                   float lr_t, float beta1, float beta2, float eps, const float* scale_dev, void* stream);
 
+/* the non-Adam branches of add_optimizer (img2seq.py:102-107), TF-1.12 defaults:
+ * method 1 GradientDescentOptimizer, 2 AdagradOptimizer (slot = accumulator, caller initialises to 0.1),
+ * 3 RMSPropOptimizer (slot = rms, caller initialises to 1; decay 0.9, momentum 0, epsilon 1e-10). */
+int lxo_optimizer_step(int method, long long n, float* params, const float* grads, float* slot, float lr,
+                       const float* scale_dev, void* stream);
+
 /* dynamic_decode + GreedyDecoderCell (dynamic_decode.py:17-74, greedy_decoder_cell.py:40-66):
  * runs on the encoder output already in ws; ids_out int32 [B, max_steps] (device),
  * *steps_out = number of steps executed (<= max_iter + 1).  Host-synchronising. */

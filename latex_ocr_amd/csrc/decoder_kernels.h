@@ -33,3 +33,4 @@ int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* 
 int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k, int cols, hipStream_t st);
 int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sumsq_tmp, float* out, hipStream_t st);
 int lxo_k_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps, const float* scale, hipStream_t st);
+int lxo_k_simple_opt(float* p, const float* g, float* slot, long long n, float lr, int mode, const float* scale, hipStream_t st);

@@ -804,6 +804,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// the other optimizers of img2seq.py:102-107 with TF-1.12 defaults:
+//  mode 1 GradientDescent : theta -= lr g
+//  mode 2 Adagrad         : acc (init 0.1) += g^2 ; theta -= lr g / sqrt(acc)
+//  mode 3 RMSProp         : ms (init 1) = 0.9 ms + 0.1 g^2 ; theta -= lr g / sqrt(ms + 1e-10)
+__global__ __launch_bounds__(256) void simple_opt_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ slot,
+                                                        long long n, float lr, int mode, const float* __restrict__ scale) {
+    const float sc = scale ? scale[0] : 1.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * sc;
+        if (mode == 1) p[i] -= lr * gi;
+        else if (mode == 2) { const float a = slot[i] + gi * gi; slot[i] = a; p[i] -= lr * gi / sqrtf(a); }
+        else { const float ms = 0.9f * slot[i] + 0.1f * gi * gi; slot[i] = ms; p[i] -= lr * gi / sqrtf(ms + 1e-10f); }
+    }
+}
+
 inline int grid1(long long items, int per_block = 256, int cap = 2048) {
     long long g = (items + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -956,6 +971,11 @@ int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sums
     HIPRC(hipMemsetAsync(sumsq_tmp, 0, sizeof(float), st));
     LAUNCH(sumsq_kernel, grid1(n, 256 * 8, 1024), g, n, sumsq_tmp);
     hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq_tmp, clip, out);
+    DONE;
+}
+int lxo_k_simple_opt(float* p, const float* g, float* slot, long long n, float lr, int mode, const float* scale, hipStream_t st) {
+    if (mode < 1 || mode > 3 || (mode > 1 && !slot)) return -2;
+    LAUNCH(simple_opt_kernel, grid1(n, 256 * 4, 4096), p, g, slot, n, lr, mode, scale);
     DONE;
 }
 int lxo_k_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps, const float* scale, hipStream_t st) {

@@ -184,8 +184,30 @@ class Engine(object):
         if comm:
             comm(*self.buckets[2])
 
+    METHODS = {"adam": 0, "sgd": 1, "adagrad": 2, "rmsprop": 3}
+
+    def set_optimizer(self, lr_method):
+        """img2seq.py:95-109: 'adam' | 'adagrad' | 'sgd' | 'rmsprop' (TF-1.12 default hyper-parameters)."""
+        m = lr_method.lower()
+        if m not in self.METHODS:
+            raise NotImplementedError("Unknown method {}".format(lr_method))
+        self.method = self.METHODS[m]
+        if self.method == 2:
+            self.adam_v.fill_(0.1)        # Adagrad initial_accumulator_value
+        elif self.method == 3:
+            self.adam_v.fill_(1.0)        # RMSProp rms slot starts at ones
+
     def optimizer_step(self, lr, clip=-1.0, beta1=0.9, beta2=0.999, eps=1e-8):
         st = self._stream()
+        if getattr(self, "method", 0) != 0:
+            scale = None
+            if clip is not None and clip > 0:
+                self._ck(self.lib.lxo_global_norm_scale(self.n_params, _p(self.grads), ctypes.c_float(clip), _p(self.scale), st), "clip")
+                scale = self.scale
+            self._ck(self.lib.lxo_optimizer_step(self.method, self.n_params, _p(self.params), _p(self.grads), _p(self.adam_v),
+                                                 ctypes.c_float(float(lr)), _p(scale), st), "optimizer_step")
+            self.pack()
+            return
         self.adam_t += 1
         lr_t = float(lr) * math.sqrt(1.0 - beta2 ** self.adam_t) / (1.0 - beta1 ** self.adam_t)
         scale = None

@@ -41,9 +41,7 @@ class Img2SeqModel(BaseModel):
         self.logger.info("Building model...")
         self._build_engine()
         self._lr_method = config.lr_method.lower()
-        if self._lr_method != "adam":
-            raise NotImplementedError("lr_method %r: the device optimizer implements Adam (img2seq.py:101); "
-                                      "adagrad/sgd/rmsprop (:102-107) are not built" % config.lr_method)
+        self.engine.set_optimizer(self._lr_method)               # img2seq.py:95-109
         self._clip = getattr(config, "clip", -1)
         self.init_session()
         self.logger.info("- done.")

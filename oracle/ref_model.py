@@ -364,3 +364,27 @@ def out_hw(H, W):
     """Encoder output geometry (SURVEY.md section 4 known-answers)."""
     c = lambda n: -(-n // 2)
     return c(c(c(H))) - 2, c(c(c(W))) - 2
+
+
+class SimpleOptTF(object):
+    """+TF the non-Adam branches of add_optimizer (img2seq.py:102-107) with TF-1.12 defaults:
+    GradientDescent; Adagrad (initial_accumulator_value 0.1); RMSProp (decay .9, momentum 0, eps 1e-10,
+    rms slot initialised to ones)."""
+
+    def __init__(self, P, method):
+        self.method = method.lower()
+        init = {"sgd": 0.0, "adagrad": 0.1, "rmsprop": 1.0}[self.method]
+        self.slot = OrderedDict((k, torch.full_like(v, init)) for k, v in P.items())
+
+    def step(self, P, G, lr):
+        lr = np.float32(lr)
+        for k in P:
+            g = G[k]
+            if self.method == "sgd":
+                P[k].sub_(lr * g)
+            elif self.method == "adagrad":
+                self.slot[k].add_(g * g)
+                P[k].sub_(lr * g / self.slot[k].sqrt())
+            else:
+                self.slot[k].mul_(0.9).add_(0.1 * g * g)
+                P[k].sub_(lr * g / (self.slot[k] + 1e-10).sqrt())

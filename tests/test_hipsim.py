@@ -129,3 +129,20 @@ def test_adam_and_clip():
     gs = g * sc[0]
     want = p0 - lr_t * (0.1 * gs) / (np.sqrt(0.001 * gs * gs) + 1e-8)
     assert np.abs(p - want).max() < 1e-6
+
+
+@pytest.mark.parametrize("method,mode,init", [("sgd", 1, 0.0), ("adagrad", 2, 0.1), ("rmsprop", 3, 1.0)])
+def test_other_optimizers(method, mode, init):
+    import torch
+    from oracle import ref_model as R
+    L = lib()
+    rng = np.random.default_rng(mode)
+    n = 777
+    p = rng.standard_normal(n).astype(np.float32); slot = np.full(n, init, np.float32)
+    P = {"w": torch.from_numpy(p.copy())}
+    opt = R.SimpleOptTF(P, method)
+    for it in range(3):
+        g = rng.standard_normal(n).astype(np.float32)
+        assert L.lxo_optimizer_step(mode, n, ptr(p), ptr(g), ptr(slot), ctypes.c_float(0.01), None, None) == 0
+        opt.step(P, {"w": torch.from_numpy(g)}, 0.01)
+    assert np.abs(p - P["w"].numpy()).max() < 1e-6
