@@ -62,10 +62,6 @@ class Engine(object):
         self.side_stream = None
         if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "0") == "1":
             self.side_stream = torch.cuda.Stream(self.device)
-        # hipGraph replay of the recurrent loops needs a capturable (non-default) stream
-        self.main_stream = None
-        if self.side_stream is not None and os.environ.get("LXO_GRAPH", "0") == "1":
-            self.main_stream = torch.cuda.Stream(self.device)
         self.load_params(PP.init_params(self.n_tok, seed, self.dims))
 
     # ------------------------------------------------------------ plumbing --
@@ -226,13 +222,6 @@ class Engine(object):
     def train_step(self, img, formula, lengths, lr, clip=-1.0, dist=None, sync_loss=True):
         """One optimisation step of img2seq.py:_run_train's body.  Returns the batch loss
         (token mean over the global batch) or None when sync_loss is False."""
-        if self.main_stream is not None and torch.cuda.current_stream(self.device) != self.main_stream:
-            cur = torch.cuda.current_stream(self.device)
-            self.main_stream.wait_stream(cur)
-            with torch.cuda.stream(self.main_stream):
-                out = self.train_step(img, formula, lengths, lr, clip, dist, sync_loss)
-            cur.wait_stream(self.main_stream)
-            return out
         self.forward(img, formula)
         n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
         n_global = dist.sum_scalar(n_local) if dist is not None else n_local
