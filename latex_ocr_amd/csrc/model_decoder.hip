@@ -6,7 +6,6 @@
 #include "gemm.h"
 #include "decoder_kernels.h"
 #include "api_util.h"
-#include <stdlib.h>
 
 namespace {
 // dense C = act(A * Bp^T + bias) on the compute dtype `dt`
@@ -87,47 +86,6 @@ int lxo_impl_set_side_stream(hipStream_t s) {
 static int fork_side(hipStream_t st) { HIPRC(hipEventRecord(g_ev_fork, st)); HIPRC(hipStreamWaitEvent(g_side, g_ev_fork, 0)); return 0; }
 static int join_side(hipStream_t st) { HIPRC(hipEventRecord(g_ev_join, g_side)); HIPRC(hipStreamWaitEvent(st, g_ev_join, 0)); return 0; }
 
-// ---- hipGraph capture of the recurrent loops (LXO_GRAPH=1, needs the side stream) ----
-// With two streams the eager host loop (~2800 launches per step at ~3.5 us) becomes the bottleneck, so the
-// forked loop is captured once per (direction, shape, buffers) and replayed.  Small per-thread LRU cache.
-struct GraphKey { int dir; lxo_shape s; const void* a; const void* b; const void* c; const void* d; const void* e; };
-struct GraphEnt { GraphKey k; hipGraphExec_t exec; unsigned long long stamp; bool used; };
-static thread_local GraphEnt g_graphs[16];
-static thread_local unsigned long long g_stamp = 0;
-static bool graph_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("LXO_GRAPH"); on = (e && e[0] == '1') ? 1 : 0; }
-    return on == 1 && g_side != nullptr;
-}
-static GraphEnt* graph_find(const GraphKey& k) {
-    for (auto& g : g_graphs) if (g.used && memcmp(&g.k, &k, sizeof(k)) == 0) { g.stamp = ++g_stamp; return &g; }
-    return nullptr;
-}
-static GraphEnt* graph_slot() {
-    GraphEnt* best = &g_graphs[0];
-    for (auto& g : g_graphs) { if (!g.used) return &g; if (g.stamp < best->stamp) best = &g; }
-    if (best->used) { (void)hipGraphExecDestroy(best->exec); best->used = false; }
-    return best;
-}
-// runs body() either eagerly or as a captured + cached graph on st
-template <class F>
-static int run_loop(const GraphKey& key, hipStream_t st, F body) {
-    if (!graph_enabled()) return body();
-    if (GraphEnt* g = graph_find(key)) { HIPRC(hipGraphLaunch(g->exec, st)); return 0; }
-    hipGraph_t graph = nullptr;
-    HIPRC(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = body();
-    const hipError_t ec = hipStreamEndCapture(st, &graph);
-    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ec != hipSuccess) return -100 - (int)ec;
-    GraphEnt* slot = graph_slot();
-    HIPRC(hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    slot->k = key; slot->used = true; slot->stamp = ++g_stamp;
-    HIPRC(hipGraphLaunch(slot->exec, st));
-    return 0;
-}
-
 // One AttentionCell.step (attention_cell.py:58-89) for rows [r0, r0+nr) of nv decoder rows.  The step
 // pointers address row 0; zx_t must already hold emb_t * K[0:D] + b; rec_prev/cs_prev = state t-1
 // (o final), rec_cur/cs_cur receive state t.  Every GEMM is a split-K slab GEMM; the kernel that
@@ -170,21 +128,16 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
     const int nh = dual ? 2 : 1, hb = B / nh;
-    GraphKey key; memset(&key, 0, sizeof(key));
-    key.dir = 1; key.s = P.s; key.a = prm; key.b = wp; key.c = ws;
-    RC(run_loop(key, st, [&]() -> int {
-        if (dual) RC(fork_side(st));
-        for (int t = 0; t < T; ++t)
-            for (int h = 0; h < nh; ++h)
-                RC(cell_step(P, prm, wp, ws, h * hb, hb, 1, zx + (size_t)t * B * 4 * U,
-                             rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
-                             rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
-                             P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
-                             P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
-                             P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, h ? g_side : st));
-        if (dual) RC(join_side(st));
-        return 0;
-    }));
+    if (dual) RC(fork_side(st));
+    for (int t = 0; t < T; ++t)
+        for (int h = 0; h < nh; ++h)
+            RC(cell_step(P, prm, wp, ws, h * hb, hb, 1, zx + (size_t)t * B * 4 * U,
+                         rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
+                         rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
+                         P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
+                         P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
+                         P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, h ? g_side : st));
+    if (dual) RC(join_side(st));
     // logits_t = o_t y_W_o for every step at once  (attention_cell.py:84)
     RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
           T * B, V, O, nullptr, 0, false, st));
@@ -218,9 +171,6 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
     const int nh = dual ? 2 : 1, hb = B / nh;
     const int nchb = P.attn_chunks(hb);
-    GraphKey key; memset(&key, 0, sizeof(key));
-    key.dir = 2; key.s = P.s; key.a = prm; key.b = wp; key.c = ws;
-    RC(run_loop(key, st, [&]() -> int {
     if (dual) RC(fork_side(st));
     for (int t = T - 1; t >= 0; --t) {
         for (int h = 0; h < nh; ++h) {
@@ -253,8 +203,6 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         }
     }
     if (dual) RC(join_side(st));
-    return 0;
-    }));
     // the final carries of the two halves are separate slab sets; gather them into one [B][XH] buffer
     float* dxh = P.ws<float>(ws, W_DXH);
     for (int h = 0; h < nh; ++h) {

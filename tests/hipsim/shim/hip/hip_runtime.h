@@ -275,14 +275,6 @@ inline const char* hipGetErrorString(hipError_t) { return "hipsim"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-typedef void* hipGraph_t; typedef void* hipGraphExec_t;
-enum { hipStreamCaptureModeThreadLocal = 1 };
-inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipSuccess; }
-inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = (void*)1; return hipSuccess; }
-inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, void*, void*, size_t) { *e = (void*)1; return hipSuccess; }
-inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
-inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 typedef void* hipEvent_t;
 enum { hipEventDisableTiming = 2 };
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
