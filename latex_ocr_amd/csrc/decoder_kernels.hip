@@ -204,33 +204,6 @@ __global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __r
     }
 }
 
-struct I0 { static constexpr int value = 0; };
-struct I1 { static constexpr int value = 1; };
-// raw (unconverted) row pieces, so that a prefetched register set costs 16 B / 8 B per lane in bf16 mode
-template <typename CT> struct Raw8;
-template <> struct Raw8<bf16_t> { u32x4 v; };
-template <> struct Raw8<float> { f32x4 lo, hi; };
-template <typename CT> struct Raw4;
-template <> struct Raw4<bf16_t> { u32x2 v; };
-template <> struct Raw4<float> { f32x4 v; };
-LXO_DEV Raw8<bf16_t> ld_raw8(const bf16_t* p, bool ok) { Raw8<bf16_t> r; const u32x4 z = {0u, 0u, 0u, 0u}; r.v = ok ? *reinterpret_cast<const u32x4*>(p) : z; return r; }
-LXO_DEV Raw8<float> ld_raw8(const float* p, bool ok) { Raw8<float> r; const f32x4 z = {0.f, 0.f, 0.f, 0.f}; r.lo = ok ? *reinterpret_cast<const f32x4*>(p) : z; r.hi = ok ? *reinterpret_cast<const f32x4*>(p + 4) : z; return r; }
-LXO_DEV Raw4<bf16_t> ld_raw4(const bf16_t* p, bool ok) { Raw4<bf16_t> r; const u32x2 z = {0u, 0u}; r.v = ok ? *reinterpret_cast<const u32x2*>(p) : z; return r; }
-LXO_DEV Raw4<float> ld_raw4(const float* p, bool ok) { Raw4<float> r; const f32x4 z = {0.f, 0.f, 0.f, 0.f}; r.v = ok ? *reinterpret_cast<const f32x4*>(p) : z; return r; }
-LXO_DEV void unpack(const Raw8<bf16_t>& r, float (&v)[8]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r.v[i] << 16); v[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u); }
-}
-LXO_DEV void unpack(const Raw8<float>& r, float (&v)[8]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = r.lo[i]; v[4 + i] = r.hi[i]; }
-}
-LXO_DEV void unpack(const Raw4<bf16_t>& r, float (&v)[4]) {
-    v[0] = __uint_as_float(r.v[0] << 16); v[1] = __uint_as_float(r.v[0] & 0xffff0000u);
-    v[2] = __uint_as_float(r.v[1] << 16); v[3] = __uint_as_float(r.v[1] & 0xffff0000u);
-}
-LXO_DEV void unpack(const Raw4<float>& r, float (&v)[4]) { v[0] = r.v[0]; v[1] = r.v[1]; v[2] = r.v[2]; v[3] = r.v[3]; }
-
 // ---- attention stream ----
 // The R regions of a sample are split into NCH chunks, one workgroup (8 waves) per
 // (chunk, sample), so that B*NCH >= ~2 workgroups per CU and every wave keeps 8 row
@@ -249,7 +222,7 @@ template <> LXO_DEV float tanh_ct<bf16_t>(float x) { return 1.f - 2.f * __builti
 // so the att_img row and the img row of 8 regions are all in flight together; the raw scores go to
 // `alpha` and attn_fwd_combine turns them into normalised weights.
 template <typename CT, int KCT, int ATT_U>
-__global__ __launch_bounds__(512, 4) void attn_fwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+__global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, Slabs ahs, float* __restrict__ att_h_out,
                                                            const float* __restrict__ beta,
                                                            float* __restrict__ alpha, float* __restrict__ part,
@@ -283,36 +256,31 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_part_kernel(const CT* __restr
     float m = -3.0e38f, l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    // two register sets: the rows of iteration i+1 are in flight while iteration i is reduced
-    Raw8<CT> ri[2][ATT_U]; Raw4<CT> ra[2][KCT][ATT_U];
-    auto fetch = [&](auto SET, int base) {
-        constexpr int S = decltype(SET)::value;
+    for (int base = wave; base < n; base += ATT_W * ATT_U) {
+        float xi[ATT_U][8], pt[ATT_U];
 #pragma unroll
-        for (int u = 0; u < ATT_U; ++u) {
+        for (int u = 0; u < ATT_U; ++u) {                 // issue the img rows first: they are consumed last
             const int r = base + ATT_W * u;
-            ri[S][u] = ld_raw8(im + (long long)(r < n ? r : 0) * C + (cok ? c0 : 0), cok && r < n);
-#pragma unroll
-            for (int kc = 0; kc < KCT; ++kc) {
-                const int k0 = kc * 256 + lane * 4;
-                const bool ok = k0 < E && r < n;
-                ra[S][kc][u] = ld_raw4(ai + (long long)(ok ? r : 0) * E + (ok ? k0 : 0), ok);
-            }
+            if (cok && r < n) load8(im + (long long)r * C + c0, xi[u]);
+            else { for (int e = 0; e < 8; ++e) xi[u][e] = 0.f; }
+            pt[u] = 0.f;
         }
-    };
-    auto reduce = [&](auto SET, int base) {
-        constexpr int S = decltype(SET)::value;
-        float pt[ATT_U];
 #pragma unroll
-        for (int u = 0; u < ATT_U; ++u) {
-            float a = 0.f;
+        for (int kc = 0; kc < KCT; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            if (kc < KC && k0 < E) {
+                float x[ATT_U][4];
 #pragma unroll
-            for (int kc = 0; kc < KCT; ++kc) {
-                float x[4];
-                unpack(ra[S][kc][u], x);
+                for (int u = 0; u < ATT_U; ++u) {
+                    const int r = base + ATT_W * u;
+                    if (r < n) load4(ai + (long long)r * E + k0, x[u]);
+                    else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a = fmaf(tanh_ct<CT>(x[j] + ah[kc][j]), bt[kc][j], a);
+                for (int u = 0; u < ATT_U; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pt[u] = fmaf(tanh_ct<CT>(x[u][j] + ah[kc][j]), bt[kc][j], pt[u]);
             }
-            pt[u] = a;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -333,22 +301,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_part_kernel(const CT* __restr
             if (r < n) {
                 const float pw = expf(pt[u] - m);
                 l += pw;
-                float xi[8];
-                unpack(ri[S][u], xi);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pw, xi[e], acc[e]);
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pw, xi[u][e], acc[e]);
                 if (lane == 0) alpha[(long long)v * Rp + r0 + r] = pt[u];       // raw score
             }
-        }
-    };
-    constexpr int STEP = ATT_W * ATT_U;
-    if (wave < n) fetch(I0{}, wave);
-    for (int base = wave; base < n; base += 2 * STEP) {
-        if (base + STEP < n) fetch(I1{}, base + STEP);
-        reduce(I0{}, base);
-        if (base + STEP < n) {
-            if (base + 2 * STEP < n) fetch(I0{}, base + 2 * STEP);
-            reduce(I1{}, base + STEP);
         }
     }
     // merge the 8 waves
@@ -410,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
 
 // ---- attention backward (per step): d_e and d_att_h in one pass; d_img / d_att_img are deferred ----
 template <typename CT, int KCT, int ATT_U>
-__global__ __launch_bounds__(512, 4) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+__global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, const float* __restrict__ beta,
                                                            const float* __restrict__ alpha, Slabs dcs, int dcoff, float* __restrict__ dctx_out, int lddc,
                                                            const float* __restrict__ ctx, int ldctx,
@@ -461,32 +417,31 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_part_kernel(const CT* __restr
             for (int j = 0; j < 4; ++j) ah[kc][j] = a4[j];
         }
     }
-    Raw8<CT> ri[2][ATT_U]; Raw4<CT> ra[2][KCT][ATT_U]; float al[2][ATT_U];
-    auto fetch = [&](auto SET, int base) {
-        constexpr int S = decltype(SET)::value;
+    for (int base = wave; base < n; base += ATT_W * ATT_U) {
+        float xi[ATT_U][8], pt[ATT_U], al[ATT_U];
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
             const int r = base + ATT_W * u;
-            ri[S][u] = ld_raw8(im + (long long)(r < n ? r : 0) * C + (cok ? c0 : 0), cok && r < n);
-            al[S][u] = r < n ? alpha[(long long)v * Rp + r0 + r] : 0.f;
+            if (cok && r < n) load8(im + (long long)r * C + c0, xi[u]);
+            else { for (int e = 0; e < 8; ++e) xi[u][e] = 0.f; }
+            al[u] = r < n ? alpha[(long long)v * Rp + r0 + r] : 0.f;
+        }
+        float x[KCT][ATT_U][4];
 #pragma unroll
-            for (int kc = 0; kc < KCT; ++kc) {
-                const int k0 = kc * 256 + lane * 4;
-                const bool ok = k0 < E && r < n;
-                ra[S][kc][u] = ld_raw4(ai + (long long)(ok ? r : 0) * E + (ok ? k0 : 0), ok);
+        for (int kc = 0; kc < KCT; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                if (kc < KC && k0 < E && r < n) load4(ai + (long long)r * E + k0, x[kc][u]);
+                else { x[kc][u][0] = x[kc][u][1] = x[kc][u][2] = x[kc][u][3] = 0.f; }
             }
         }
-    };
-    auto reduce = [&](auto SET, int base) {
-        constexpr int S = decltype(SET)::value;
-        float pt[ATT_U];
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
-            float xi[8];
-            unpack(ri[S][u], xi);
             float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a = fmaf(xi[e], dc[e], a);
+            for (int e = 0; e < 8; ++e) a = fmaf(xi[u][e], dc[e], a);
             pt[u] = a;
         }
 #pragma unroll
@@ -497,28 +452,19 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_part_kernel(const CT* __restr
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
             const int r = base + ATT_W * u;
-            const float d = al[S][u] * (pt[u] - s);                  // softmax backward (0 for r >= n)
+            const float d = al[u] * (pt[u] - s);                     // softmax backward (0 for r >= n)
             if (lane == 0 && r < n) de[(long long)v * Rp + r0 + r] = d;
 #pragma unroll
             for (int kc = 0; kc < KCT; ++kc) {
-                float x[4];
-                unpack(ra[S][kc][u], x);
+                const int k0 = kc * 256 + lane * 4;
+                if (kc < KC && k0 < E) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float tau = tanh_ct<CT>(x[j] + ah[kc][j]);
-                    acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const float tau = tanh_ct<CT>(x[kc][u][j] + ah[kc][j]);
+                        acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
+                    }
                 }
             }
-        }
-    };
-    constexpr int STEP = ATT_W * ATT_U;
-    if (wave < n) fetch(I0{}, wave);
-    for (int base = wave; base < n; base += 2 * STEP) {
-        if (base + STEP < n) fetch(I1{}, base + STEP);
-        reduce(I0{}, base);
-        if (base + STEP < n) {
-            if (base + 2 * STEP < n) fetch(I0{}, base + 2 * STEP);
-            reduce(I1{}, base + STEP);
         }
     }
 #pragma unroll
