@@ -148,7 +148,7 @@ extern "C" int lxo_gemm_slab(int dt, const void* A, const void* Bp, float* slab,
                              long long slab_stride, void* stream) {
     GemmNT p; memset(&p, 0, sizeof(p));
     p.A = A; p.Bp = Bp; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = 1.f; p.addend_rows = 1;
-    CHECK_LAUNCH(lxo_launch_gemm_slab(dt, p, slab, slab_stride, (hipStream_t)stream, nullptr), "lxo_gemm_slab");
+    CHECK_LAUNCH(lxo_launch_gemm_slab(dt, p, slab, slab_stride, (hipStream_t)stream), "lxo_gemm_slab");
     return 0;
 }
 

@@ -43,10 +43,7 @@ int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p,
 int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_t s);
 
 // split-K partial products: slab[ks][M][ldc] = A[:, ks*128:(ks+1)*128] * Bp[:, same]^T, ks < K/128 (A float)
-// optional A-operand prologue: columns [0, cols) of A = tanh(sum_{s<n} slabs[s*stride + m*ld + k]) (finished values are also
-// written to store[m*store_ld + k]); lets the o_t = tanh(.) of one step be finalised inside the next step's first GEMM
-struct SlabPre { const float* slabs; int n; long long stride; int ld; int cols; float* store; int store_ld; };
-int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s, const SlabPre* pre = nullptr);
+int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s);
 
 // bf16 3x3 implicit-GEMM convolution, 256x128x64 tiles, LDS-DMA double buffering (conv_igemm.hip)
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s);

@@ -15,7 +15,6 @@
 // mode) uses v_mfma_f32_32x32x2_f32, which is an exact fmaf chain.
 #include "gemm.h"
 #include <stdlib.h>
-#include <string.h>
 
 namespace {
 
@@ -530,7 +529,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmNT p) {
 // through LDS and writes one partial 64x64 tile to slab[ks] (plain stores, no atomics);
 // the consumer kernel adds the KS slabs.  One memory round trip per GEMM.
 template <typename CT>
-__global__ __launch_bounds__(256) void gemm_slab_kernel(GemmNT p, float* __restrict__ slab, long long slab_stride, SlabPre pre) {
+__global__ __launch_bounds__(256) void gemm_slab_kernel(GemmNT p, float* __restrict__ slab, long long slab_stride) {
     constexpr bool BF = is_bf16<CT>::value;
     constexpr int KQ = 128;
     constexpr int PITCH = BF ? KQ + 8 : KQ + 1;
@@ -544,40 +543,11 @@ __global__ __launch_bounds__(256) void gemm_slab_kernel(GemmNT p, float* __restr
     // A: 64 rows x 128 floats = 2048 float4 -> 8 per thread (a wave reads 2 full rows per instruction)
     f32x4 ra[8];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    if (pre.n > 0 && kb < pre.cols) {
-        // A columns [0, pre.cols) are still pending as split-K slabs of the previous GEMM: A = tanh(sum of slabs)
-        // (the o_t of attention_cell.py:82); the first column tile also writes the finished values back.
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ra[j] = z4;
-        for (int s0 = 0; s0 < pre.n; s0 += 4) {
-            f32x4 t[8][4];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
-                const int m = m0 + row;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-                    t[j][q4] = (m < p.M && s0 + q4 < pre.n)
-                        ? *reinterpret_cast<const f32x4*>(pre.slabs + (long long)(s0 + q4) * pre.stride + (long long)m * pre.ld + kb + c4) : z4;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ra[j] += (t[j][0] + t[j][1]) + (t[j][2] + t[j][3]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
-            const int m = m0 + row;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ra[j][e] = tanhf(ra[j][e]);
-            if (blockIdx.x == 0 && m < p.M) *reinterpret_cast<f32x4*>(pre.store + (long long)m * pre.store_ld + kb + c4) = ra[j];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
-            const int m = m0 + row;
-            ra[j] = m < p.M ? *reinterpret_cast<const f32x4*>(A + (long long)m * p.lda + kb + c4) : z4;
-        }
+    for (int j = 0; j < 8; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+        const int m = m0 + row;
+        ra[j] = m < p.M ? *reinterpret_cast<const f32x4*>(A + (long long)m * p.lda + kb + c4) : z4;
     }
     if constexpr (BF) {
         u32x4 rb[4];
@@ -716,13 +686,10 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
     return launch_tn<bf16_t, false, bf16_t, float>(p, s);
 }
 
-int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s, const SlabPre* pre) {
+int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s) {
     if (p.K % 128 != 0 || p.lda % 4 != 0) return -2;
-    SlabPre none; memset(&none, 0, sizeof(none));
-    const SlabPre pp = pre ? *pre : none;
-    if (pp.n > 0 && (pp.cols % 128 != 0 || pp.ld % 4 != 0 || pp.store_ld % 4 != 0)) return -2;
     dim3 grid(cdiv(p.N, 64), p.K / 128, cdiv(p.M, 64));
-    if (dt == LXO_F32) hipLaunchKernelGGL((gemm_slab_kernel<float>), grid, dim3(256), 0, s, p, slab, slab_stride, pp);
-    else hipLaunchKernelGGL((gemm_slab_kernel<bf16_t>), grid, dim3(256), 0, s, p, slab, slab_stride, pp);
+    if (dt == LXO_F32) hipLaunchKernelGGL((gemm_slab_kernel<float>), grid, dim3(256), 0, s, p, slab, slab_stride);
+    else hipLaunchKernelGGL((gemm_slab_kernel<bf16_t>), grid, dim3(256), 0, s, p, slab, slab_stride);
     return (int)hipGetLastError();
 }

@@ -31,11 +31,10 @@ int tn(const Plan& P, bool a_f32, bool b_f32, const void* A, int lda, const void
     return lxo_launch_gemm_tn(P.s.dtype, a_f32, b_f32, g, st);
 }
 // split-K partial products slab[ks] = A[:, ks*128:+128] * Bp^T  (one memory round trip; consumers add the slabs)
-int slab(const Plan& P, const float* A, int lda, const void* Bp, int ldb, float* out, int M, int N, int K, hipStream_t st,
-         const SlabPre* pre = nullptr) {
+int slab(const Plan& P, const float* A, int lda, const void* Bp, int ldb, float* out, int M, int N, int K, hipStream_t st) {
     GemmNT g; memset(&g, 0, sizeof(g));
     g.A = A; g.Bp = Bp; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N; g.alpha = 1.f; g.addend_rows = 1;
-    return lxo_launch_gemm_slab(P.s.dtype, g, out, (long long)M * N, st, pre);
+    return lxo_launch_gemm_slab(P.s.dtype, g, out, (long long)M * N, st);
 }
 Slabs view(const float* p, int K, int M, int N) { Slabs s = {p, K / 128, (long long)M * N, N}; return s; }
 const Slabs kNoSlabs = {nullptr, 0, 0, 0};
@@ -91,11 +90,9 @@ static int join_side(hipStream_t st) { HIPRC(hipEventRecord(g_ev_join, g_side));
 // pointers address row 0; zx_t must already hold emb_t * K[0:D] + b; rec_prev/cs_prev = state t-1
 // (o final), rec_cur/cs_cur receive state t.  Every GEMM is a split-K slab GEMM; the kernel that
 // consumes a product adds its slabs.
-// o_pending: the o of rec_prev has not been finalised yet (its K4 slabs are still in W_S_K4) -> the first GEMM does it;
-// finalize_o: finish this step's o with its own kernel (decode, last training step) or leave it pending for the next step.
 static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int r0, int nr, int beam,
-                     const float* zx_t, float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
-                     float* gates_t, float* atth_t, float* alpha_t, hipStream_t st, bool o_pending = false, bool finalize_o = true) {
+                     const float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
+                     float* gates_t, float* atth_t, float* alpha_t, hipStream_t st) {
     const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
     const size_t r = (size_t)r0;
     float* s1 = P.ws<float>(ws, W_S_K1) + r * (P.XH / 128) * 4 * U;
@@ -108,9 +105,7 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
     const char* img = (const char*)P.ws<void>(ws, W_IMG) + (r / beam) * P.R * C * P.esz;
     float* part = P.ws<float>(ws, W_APART) + r * 32 * (C + 2);
     // z = zx + [o_prev, h_prev] K[D:]            (attention_cell.py:70-71)
-    SlabPre pre; memset(&pre, 0, sizeof(pre));
-    if (o_pending) { pre.slabs = s4; pre.n = P.HC / 128; pre.stride = (long long)nr * O; pre.ld = O; pre.cols = O; pre.store = rec_prev; pre.store_ld = P.REC; }
-    RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, s1, nr, 4 * U, P.XH, st, o_pending ? &pre : nullptr));
+    RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, s1, nr, 4 * U, P.XH, st));
     RC(lxo_k_lstm_fwd(zx_t, view(s1, P.XH, nr, 4 * U), cs_prev, gates_t, cs_cur, rec_cur + O, P.REC, nr, U, st));
     // att_h = h W                                 (attention_mechanism.py:79)
     RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, s2, nr, E, U, st));
@@ -119,7 +114,7 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
                       P.attn_chunks(nr), st));
     // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
     RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, s4, nr, O, P.HC, st));
-    if (finalize_o) RC(lxo_k_tanh_finalize(view(s4, P.HC, nr, O), rec_cur, P.REC, nr, O, st));
+    RC(lxo_k_tanh_finalize(view(s4, P.HC, nr, O), rec_cur, P.REC, nr, O, st));
     return 0;
 }
 
@@ -141,8 +136,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
                          rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
                          P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
                          P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
-                         P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, h ? g_side : st,
-                         /*o_pending=*/t > 0, /*finalize_o=*/t == T - 1));
+                         P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, h ? g_side : st));
     if (dual) RC(join_side(st));
     // logits_t = o_t y_W_o for every step at once  (attention_cell.py:84)
     RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
