@@ -334,34 +334,35 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
     }
 }
 
-// merge the chunk partials: alpha = exp(e - m) / l ; ctx = sum_c ctx_c exp(m_c - m) / l
+// merge the chunk partials: alpha = exp(e - m) / l ; ctx = sum_c ctx_c exp(m_c - m) / l.
+// grid (4, nv): every workgroup recomputes the (tiny) chunk scales in registers, then handles a
+// quarter of the channels and a quarter of the regions -- no serial phase, no barrier.
 __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __restrict__ part, float* __restrict__ alpha,
                                                               float* __restrict__ ctx, int ldctx, int R, int Rp, int C,
                                                               int nch, int rows_per) {
-    __shared__ float scl[34];
-    const int v = blockIdx.x, tid = threadIdx.x;
+    const int v = blockIdx.y, qd = blockIdx.x, tid = threadIdx.x;
     const float* pv = part + (long long)v * nch * (C + 2);
-    if (tid == 0) {
-        float m = -3.0e38f;
-        for (int c = 0; c < nch; ++c) if (pv[(long long)c * (C + 2) + 1] > 0.f) m = fmaxf(m, pv[(long long)c * (C + 2)]);
-        float l = 0.f;
-        for (int c = 0; c < nch; ++c) {
-            const float lc = pv[(long long)c * (C + 2) + 1];
-            const float s = lc > 0.f ? expf(pv[(long long)c * (C + 2)] - m) : 0.f;
-            scl[c] = s; l += lc * s;
-        }
-        const float inv = 1.0f / l;
-        for (int c = 0; c < nch; ++c) scl[c] *= inv;
-        scl[32] = m; scl[33] = inv;
+    float mc[32], lc[32];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        mc[c] = c < nch ? pv[(long long)c * (C + 2)] : -3.0e38f;
+        lc[c] = c < nch ? pv[(long long)c * (C + 2) + 1] : 0.f;
+        if (lc[c] > 0.f) m = fmaxf(m, mc[c]);
     }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { mc[c] = lc[c] > 0.f ? expf(mc[c] - m) : 0.f; l += lc[c] * mc[c]; }
+    const float inv = 1.0f / l;
+    const int cq = (C + 3) / 4;
+    for (int c = qd * cq + tid; c < min(C, (qd + 1) * cq); c += 256) {
         float t = 0.f;
-        for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + c], scl[k], t);
-        ctx[(long long)v * ldctx + c] = t;
+        for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + c], mc[k], t);
+        ctx[(long long)v * ldctx + c] = t * inv;
     }
-    const float m = scl[32], inv = scl[33];
-    for (int r = tid; r < R; r += 256) alpha[(long long)v * Rp + r] = expf(alpha[(long long)v * Rp + r] - m) * inv;
+    const int rq = (R + 3) / 4;
+    for (int r = qd * rq + tid; r < min(R, (qd + 1) * rq); r += 256)
+        alpha[(long long)v * Rp + r] = expf(alpha[(long long)v * Rp + r] - m) * inv;
 }
 
 // ---- attention backward (per step): d_e and d_att_h in one pass; d_img / d_att_img are deferred ----
@@ -894,7 +895,7 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
         else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
     }
 #undef AF_ARGS
-    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
+    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
     DONE;
 }
 // datth must be zero on entry (chunks accumulate with atomics)
