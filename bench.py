@@ -167,9 +167,10 @@ def main():
         out["roofline_attention"] = roof_att
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         import torch.distributed as td
+        dist.barrier()                   # ranks > 0 wait for rank 0's roofline micro-timings before tearing down
         td.destroy_process_group()
 
 
