@@ -1,6 +1,10 @@
 // Launchers of the non-GEMM encoder kernels and of the weight-packing kernels.
 #pragma once
 #include "lxo_common.h"
+// one weight-pack job: kind 0 transpose (dst[n][coff+k] = src[k][n], k < Kpad zero padded), kind 1 padded row copy
+// (K rows, N real / Kpad padded columns), kind 2 conv dgrad layout (K = Cin, N = Cout)
+struct PackJob { int kind, K, N, lds, ldd, coff, Kpad, first_block, nblocks; long long src; long long dst; };
+struct PackTable { int n; PackJob job[64]; };
 int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s);
 int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s);
 int lxo_k_maxpool_fwd(int dt, const void* in, void* out, int B, int H, int W, int C, int ph, int pw, hipStream_t s);
@@ -10,3 +14,4 @@ int lxo_k_timing_signal(float* pos, int Hp, int Wp, int C, hipStream_t s);
 int lxo_k_pack_transpose(int dt, const float* src, void* dst, int K, int N, int lds, int ldd, int coff, int Kpad, hipStream_t s);
 int lxo_k_pack_copy(int dt, const float* src, void* dst, int R, int Ccols, int lds, int ldd, int Cpad, hipStream_t s);
 int lxo_k_pack_conv_dgrad(int dt, const float* w, void* dst, int Cin, int Cout, hipStream_t s);
+int lxo_k_pack_batch(int dt, const PackTable& tab, int total_blocks, const float* prm, void* wpk, hipStream_t s);

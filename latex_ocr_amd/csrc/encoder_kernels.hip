@@ -321,6 +321,49 @@ __global__ __launch_bounds__(256) void pack_conv_dgrad_kernel(const float* __res
     }
 }
 
+// All weight packs of one optimizer step in ONE launch: a table of jobs, each a 32x32-tiled transpose
+// (kind 0), a padded row copy (kind 1) or the flipped-tap dgrad layout (kind 2); blockIdx -> job by prefix sums.
+template <typename CT>
+__global__ __launch_bounds__(256) void pack_batch_kernel(PackTable tab, const float* __restrict__ prm, char* __restrict__ wpk) {
+    __shared__ float tile[32][33];
+    int j = 0;
+    while (j + 1 < tab.n && (int)blockIdx.x >= tab.job[j + 1].first_block) ++j;
+    const PackJob q = tab.job[j];
+    const int lb = blockIdx.x - q.first_block;
+    const float* src = prm + q.src;
+    CT* dst = reinterpret_cast<CT*>(wpk + q.dst);
+    if (q.kind == 0) {
+        const int tiles_k = (q.Kpad + 31) / 32;
+        const int k0 = (lb % tiles_k) * 32, n0 = (lb / tiles_k) * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, n = n0 + tx;
+            tile[r][tx] = (k < q.K && n < q.N) ? src[(long long)k * q.lds + n] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int n = n0 + r, k = k0 + tx;
+            if (n < q.N && k < q.Kpad) dst[(long long)n * q.ldd + q.coff + k] = from_f32<CT>(tile[tx][r]);
+        }
+    } else if (q.kind == 1) {
+        const long long total = (long long)q.K * q.Kpad;       // rows K, padded columns Kpad, real columns N
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < total; i += (long long)q.nblocks * 256) {
+            const int c = (int)(i % q.Kpad); const long long r = i / q.Kpad;
+            dst[r * q.ldd + c] = from_f32<CT>(c < q.N ? src[r * q.lds + c] : 0.f);
+        }
+    } else {
+        const int Cin = q.K, Cout = q.N;
+        const long long total = (long long)Cin * 9 * Cout;
+        for (long long i = (long long)lb * 256 + threadIdx.x; i < total; i += (long long)q.nblocks * 256) {
+            const int co = (int)(i % Cout);
+            const int tap = (int)((i / Cout) % 9);
+            const int ci = (int)(i / ((long long)Cout * 9));
+            const int a = tap / 3, b = tap - 3 * a;
+            dst[i] = from_f32<CT>(src[((long long)((2 - a) * 3 + (2 - b)) * Cin + ci) * Cout + co]);
+        }
+    }
+}
+
 inline int grid_for(long long items, int per_block, int cap = 2048) {
     long long g = (items + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -401,5 +444,12 @@ template <typename CT> static void pack_dg_t(const float* w, void* dst, int Cin,
 }
 int lxo_k_pack_conv_dgrad(int dt, const float* w, void* dst, int Cin, int Cout, hipStream_t s) {
     DISPATCH_CT(dt, pack_dg_t, w, dst, Cin, Cout, s);
+    return (int)hipGetLastError();
+}
+
+int lxo_k_pack_batch(int dt, const PackTable& tab, int total_blocks, const float* prm, void* wpk, hipStream_t s) {
+    if (tab.n <= 0) return 0;
+    if (dt == LXO_BF16) hipLaunchKernelGGL((pack_batch_kernel<bf16_t>), dim3(total_blocks), dim3(256), 0, s, tab, prm, (char*)wpk);
+    else hipLaunchKernelGGL((pack_batch_kernel<float>), dim3(total_blocks), dim3(256), 0, s, tab, prm, (char*)wpk);
     return (int)hipGetLastError();
 }

@@ -8,37 +8,48 @@
 // ---------------------------------------------------------------- pack ----
 int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t st) {
     const int dt = P.s.dtype, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
+    PackTable tab; memset(&tab, 0, sizeof(tab));
+    int blocks = 0;
+    auto add = [&](int kind, long long src, size_t dst, int K, int N, int lds, int ldd, int coff, int Kpad) {
+        PackJob& j = tab.job[tab.n++];
+        j.kind = kind; j.K = K; j.N = N; j.lds = lds; j.ldd = ldd; j.coff = coff; j.Kpad = Kpad; j.src = src; j.dst = (long long)dst;
+        if (kind == 0) j.nblocks = cdiv(Kpad, 32) * cdiv(N, 32);
+        else if (kind == 1) { long long t = cdivl((long long)K * Kpad, 256 * 4); j.nblocks = (int)(t < 1 ? 1 : (t > 512 ? 512 : t)); }
+        else { long long t = cdivl((long long)K * 9 * N, 256 * 4); j.nblocks = (int)(t < 1 ? 1 : (t > 512 ? 512 : t)); }
+        j.first_block = blocks; blocks += j.nblocks;
+    };
+    auto tr = [&](long long src, size_t dst, int K, int N, int ldd, int coff, int Kpad) { add(0, src, dst, K, N, N, ldd, coff, Kpad); };
+    auto cp = [&](long long src, size_t dst, int R, int Ccols, int ldd, int Cpad) { add(1, src, dst, R, Ccols, Ccols, ldd, 0, Cpad); };
     for (int l = 1; l < 6; ++l) {
         const int ci = P.convCin[l], co = P.convCout[l];
-        const float* w = prm + P.poff[2 * l];
-        RC(lxo_k_pack_transpose(dt, w, P.pk(wp, (PackId)(K_CONV2_F + l - 1)), 9 * ci, co, co, 9 * ci, 0, 9 * ci, st));
-        RC(lxo_k_pack_conv_dgrad(dt, w, P.pk(wp, (PackId)(K_CONV2_D + l - 1)), ci, co, st));
+        tr(P.poff[2 * l], P.koff[K_CONV2_F + l - 1], 9 * ci, co, 9 * ci, 0, 9 * ci);
+        add(2, P.poff[2 * l], P.koff[K_CONV2_D + l - 1], ci, co, 0, 0, 0, 0);
     }
-    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_ATT_IMG], P.pk(wp, K_ATT_IMG_T), C, E, E, C, 0, C, st));
-    RC(lxo_k_pack_copy(dt, prm + P.poff[P_ATT_IMG], P.pk(wp, K_ATT_IMG), C, E, E, E, E, st));
+    tr(P.poff[P_ATT_IMG], P.koff[K_ATT_IMG_T], C, E, C, 0, C);
+    cp(P.poff[P_ATT_IMG], P.koff[K_ATT_IMG], C, E, E, E);
     {   // init-state projections, order (c, h, o)
         const int pid[3] = {P_WC0, P_WH0, P_WO0};
         const int nout[3] = {U, U, O};
         size_t offT = 0, offN = 0;
         for (int i = 0; i < 3; ++i) {
-            RC(lxo_k_pack_transpose(dt, prm + P.poff[pid[i]], (char*)P.pk(wp, K_INIT_T) + offT, C, nout[i], nout[i], C, 0, C, st));
-            RC(lxo_k_pack_copy(dt, prm + P.poff[pid[i]], (char*)P.pk(wp, K_INIT) + offN, C, nout[i], nout[i], nout[i], nout[i], st));
+            tr(P.poff[pid[i]], P.koff[K_INIT_T] + offT, C, nout[i], C, 0, C);
+            cp(P.poff[pid[i]], P.koff[K_INIT] + offN, C, nout[i], nout[i], nout[i]);
             offT += (size_t)nout[i] * C * P.esz; offN += (size_t)C * nout[i] * P.esz;
         }
     }
-    const float* K = prm + P.poff[P_LSTM_K];
-    RC(lxo_k_pack_transpose(dt, K, P.pk(wp, K_LSTM_XT), D, 4 * U, 4 * U, P.Dp, 0, P.Dp, st));
-    RC(lxo_k_pack_transpose(dt, K + (long long)D * 4 * U, P.pk(wp, K_LSTM_RT), P.XH, 4 * U, 4 * U, P.XH, 0, P.XH, st));
-    RC(lxo_k_pack_copy(dt, K, P.pk(wp, K_LSTM), D + P.XH, 4 * U, 4 * U, 4 * U, 4 * U, st));
-    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_ATT_H], P.pk(wp, K_ATT_H_T), U, E, E, U, 0, U, st));
-    RC(lxo_k_pack_copy(dt, prm + P.poff[P_ATT_H], P.pk(wp, K_ATT_H), U, E, E, E, E, st));
-    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_OWH], P.pk(wp, K_OW_T), U, O, O, P.HC, 0, U, st));
-    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_OWC], P.pk(wp, K_OW_T), C, O, O, P.HC, U, C, st));
-    RC(lxo_k_pack_copy(dt, prm + P.poff[P_OWH], P.pk(wp, K_OW), U, O, O, O, O, st));
-    RC(lxo_k_pack_copy(dt, prm + P.poff[P_OWC], (char*)P.pk(wp, K_OW) + (size_t)U * O * P.esz, C, O, O, O, O, st));
-    RC(lxo_k_pack_transpose(dt, prm + P.poff[P_YWO], P.pk(wp, K_YWO_T), O, V, V, O, 0, O, st));
-    RC(lxo_k_pack_copy(dt, prm + P.poff[P_YWO], P.pk(wp, K_YWO), O, V, V, P.Vp, P.Vp, st));
-    return 0;
+    const long long K = P.poff[P_LSTM_K];
+    tr(K, P.koff[K_LSTM_XT], D, 4 * U, P.Dp, 0, P.Dp);
+    tr(K + (long long)D * 4 * U, P.koff[K_LSTM_RT], P.XH, 4 * U, P.XH, 0, P.XH);
+    cp(K, P.koff[K_LSTM], D + P.XH, 4 * U, 4 * U, 4 * U);
+    tr(P.poff[P_ATT_H], P.koff[K_ATT_H_T], U, E, U, 0, U);
+    cp(P.poff[P_ATT_H], P.koff[K_ATT_H], U, E, E, E);
+    tr(P.poff[P_OWH], P.koff[K_OW_T], U, O, P.HC, 0, U);
+    tr(P.poff[P_OWC], P.koff[K_OW_T], C, O, P.HC, U, C);
+    cp(P.poff[P_OWH], P.koff[K_OW], U, O, O, O);
+    cp(P.poff[P_OWC], P.koff[K_OW] + (size_t)U * O * P.esz, C, O, O, O);
+    tr(P.poff[P_YWO], P.koff[K_YWO_T], O, V, O, 0, O);
+    cp(P.poff[P_YWO], P.koff[K_YWO], O, V, P.Vp, P.Vp);
+    return lxo_k_pack_batch(dt, tab, blocks, prm, wp, st);
 }
 
 // -------------------------------------------------------------- conv ------
