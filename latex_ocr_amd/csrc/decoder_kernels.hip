@@ -486,201 +486,6 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
     }
 }
 
-// ---- register-resident variants (bf16, E <= 256): a wave holds ALL its rows of the chunk (<= NR, raw bf16) ----
-// One memory round trip per workgroup instead of one per 4 rows: every row of both streams is requested up front
-// (6 dwords per lane per row), then reduced.  rows_per <= 8 * NR.
-template <int NR>
-__global__ __launch_bounds__(512, 4) void attn_fwd_reg_kernel(const bf16_t* __restrict__ att_img, const bf16_t* __restrict__ img,
-                                                              const float* __restrict__ att_h, Slabs ahs, float* __restrict__ att_h_out,
-                                                              const float* __restrict__ beta,
-                                                              float* __restrict__ alpha, float* __restrict__ part,
-                                                              int R, int Rp, int E, int C, int beam, int nch, int rows_per) {
-    __shared__ float redc[ATT_W][512];
-    __shared__ float red[2 * ATT_W];
-    const int ch = blockIdx.x, v = blockIdx.y, bi = v / beam;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = ch * rows_per;
-    const int n = min(R, r0 + rows_per) - r0;
-    const bf16_t* ai = att_img + ((long long)bi * R + r0) * E;
-    const bf16_t* im = img + ((long long)bi * R + r0) * C;
-    float* pout = part + ((long long)v * nch + ch) * (C + 2);
-    const int k0 = lane * 4, c0 = lane * 8;
-    const bool kok = k0 < E, cok = c0 < C;
-    // every row of this wave, both streams, in flight at once
-    u32x4 ri[NR]; u32x2 ra[NR];
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        const int r = wave + ATT_W * u;
-        const u32x4 z4 = {0u, 0u, 0u, 0u}; const u32x2 z2 = {0u, 0u};
-        ri[u] = (cok && r < n) ? *reinterpret_cast<const u32x4*>(im + (long long)r * C + c0) : z4;
-        ra[u] = (kok && r < n) ? *reinterpret_cast<const u32x2*>(ai + (long long)r * E + k0) : z2;
-    }
-    float ah[4] = {0.f, 0.f, 0.f, 0.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
-    if (kok) {
-        const f32x4 a4 = ahs.n > 0 ? slab_sum4(ahs, v, k0) : *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + k0);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + k0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ah[j] = a4[j]; bt[j] = b4[j]; }
-        if (ahs.n > 0 && att_h_out && ch == 0 && wave == 0) *reinterpret_cast<f32x4*>(att_h_out + (long long)v * E + k0) = a4;
-    }
-    float pt[NR];
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        const float x0 = __uint_as_float(ra[u][0] << 16), x1 = __uint_as_float(ra[u][0] & 0xffff0000u);
-        const float x2 = __uint_as_float(ra[u][1] << 16), x3 = __uint_as_float(ra[u][1] & 0xffff0000u);
-        float a = tanh_ct<bf16_t>(x0 + ah[0]) * bt[0];
-        a = fmaf(tanh_ct<bf16_t>(x1 + ah[1]), bt[1], a);
-        a = fmaf(tanh_ct<bf16_t>(x2 + ah[2]), bt[2], a);
-        a = fmaf(tanh_ct<bf16_t>(x3 + ah[3]), bt[3], a);
-        pt[u] = a;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int u = 0; u < NR; ++u) pt[u] += __shfl_xor(pt[u], o);
-    }
-    float m = -3.0e38f;
-#pragma unroll
-    for (int u = 0; u < NR; ++u) if (wave + ATT_W * u < n) m = fmaxf(m, pt[u]);
-    float l = 0.f, acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        const int r = wave + ATT_W * u;
-        if (r < n) {
-            const float pw = expf(pt[u] - m);
-            l += pw;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[2 * i] = fmaf(pw, __uint_as_float(ri[u][i] << 16), acc[2 * i]);
-                acc[2 * i + 1] = fmaf(pw, __uint_as_float(ri[u][i] & 0xffff0000u), acc[2 * i + 1]);
-            }
-            if (lane == 0) alpha[(long long)v * Rp + r0 + r] = pt[u];       // raw score
-        }
-    }
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    float mc = red[0];
-#pragma unroll
-    for (int w = 1; w < ATT_W; ++w) mc = fmaxf(mc, red[w]);
-    const float sw = (l > 0.f) ? expf(m - mc) : 0.f;
-    if (lane == 0) red[ATT_W + wave] = l * sw;
-    if (cok) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e] * sw;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float lt = 0.f;
-#pragma unroll
-        for (int w = 0; w < ATT_W; ++w) lt += red[ATT_W + w];
-        pout[0] = mc; pout[1] = lt;
-    }
-    for (int c = tid; c < C; c += 512) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < ATT_W; ++w) t += redc[w][c];
-        pout[2 + c] = t;
-    }
-}
-
-template <int NR>
-__global__ __launch_bounds__(512, 4) void attn_bwd_reg_kernel(const bf16_t* __restrict__ att_img, const bf16_t* __restrict__ img,
-                                                              const float* __restrict__ att_h, const float* __restrict__ beta,
-                                                              const float* __restrict__ alpha, Slabs dcs, int dcoff, float* __restrict__ dctx_out, int lddc,
-                                                              const float* __restrict__ ctx, int ldctx,
-                                                              float* __restrict__ de, float* __restrict__ datth,
-                                                              int R, int Rp, int E, int C, int rows_per) {
-    __shared__ float rede[ATT_W][256];
-    __shared__ float red[ATT_W];
-    const int ch = blockIdx.x, v = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = ch * rows_per;
-    const int n = min(R, r0 + rows_per) - r0;
-    if (n <= 0) return;
-    const bf16_t* ai = att_img + ((long long)v * R + r0) * E;
-    const bf16_t* im = img + ((long long)v * R + r0) * C;
-    const int k0 = lane * 4, c0 = lane * 8;
-    const bool kok = k0 < E, cok = c0 < C;
-    u32x4 ri[NR]; u32x2 ra[NR];
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        const int r = wave + ATT_W * u;
-        const u32x4 z4 = {0u, 0u, 0u, 0u}; const u32x2 z2 = {0u, 0u};
-        ri[u] = (cok && r < n) ? *reinterpret_cast<const u32x4*>(im + (long long)r * C + c0) : z4;
-        ra[u] = (kok && r < n) ? *reinterpret_cast<const u32x2*>(ai + (long long)r * E + k0) : z2;
-    }
-    // s = <ctx, d_ctx>
-    float s = 0.f;
-    for (int c = tid; c < C; c += 512) {
-        const float d = slab_sum(dcs, v, dcoff + c);
-        if (ch == 0) dctx_out[(long long)v * lddc + c] = d;
-        s = fmaf(ctx[(long long)v * ldctx + c], d, s);
-    }
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    s = 0.f;
-#pragma unroll
-    for (int w = 0; w < ATT_W; ++w) s += red[w];
-    float dc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (cok) {
-        const f32x4 d0 = slab_sum4(dcs, v, dcoff + c0), d1 = slab_sum4(dcs, v, dcoff + c0 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { dc[e] = d0[e]; dc[4 + e] = d1[e]; }
-    }
-    float ah[4] = {0.f, 0.f, 0.f, 0.f};
-    if (kok) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + k0); ah[0] = a4[0]; ah[1] = a4[1]; ah[2] = a4[2]; ah[3] = a4[3]; }
-    float pt[NR];
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a = fmaf(__uint_as_float(ri[u][i] << 16), dc[2 * i], a);
-            a = fmaf(__uint_as_float(ri[u][i] & 0xffff0000u), dc[2 * i + 1], a);
-        }
-        pt[u] = a;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int u = 0; u < NR; ++u) pt[u] += __shfl_xor(pt[u], o);
-    }
-    // softmax backward: d_e = alpha (d_alpha - s); alpha is only needed now (one more small round trip, 14 registers saved)
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        const int r = wave + ATT_W * u;
-        pt[u] = (r < n ? alpha[(long long)v * Rp + r0 + r] : 0.f) * (pt[u] - s);
-    }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        const int r = wave + ATT_W * u;
-        const float d = pt[u];
-        if (lane == 0 && r < n) de[(long long)v * Rp + r0 + r] = d;
-        const float x0 = __uint_as_float(ra[u][0] << 16), x1 = __uint_as_float(ra[u][0] & 0xffff0000u);
-        const float x2 = __uint_as_float(ra[u][1] << 16), x3 = __uint_as_float(ra[u][1] & 0xffff0000u);
-        const float t0 = tanh_ct<bf16_t>(x0 + ah[0]), t1 = tanh_ct<bf16_t>(x1 + ah[1]);
-        const float t2 = tanh_ct<bf16_t>(x2 + ah[2]), t3 = tanh_ct<bf16_t>(x3 + ah[3]);
-        acc[0] = fmaf(d, 1.f - t0 * t0, acc[0]); acc[1] = fmaf(d, 1.f - t1 * t1, acc[1]);
-        acc[2] = fmaf(d, 1.f - t2 * t2, acc[2]); acc[3] = fmaf(d, 1.f - t3 * t3, acc[3]);
-    }
-    if (kok) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + k0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rede[wave][k0 + j] = acc[j] * b4[j];
-    }
-    __syncthreads();
-    for (int k = tid; k < E; k += 512) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < ATT_W; ++w) t += rede[w][k];
-        atomicAdd(&datth[(long long)v * E + k], t);
-    }
-}
-
 // deferred: d_att_img[b][r][k] = beta_k sum_t de[t][b][r] (1 - tau^2),  d_beta_k += sum de * tau
 template <typename CT>
 __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ att_img, const float* __restrict__ att_h,
@@ -1082,11 +887,6 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
 #define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per
-    if (dt == LXO_BF16 && E <= 256 && rows_per <= ATT_W * 14 && att_u() != 8) {
-        hipLaunchKernelGGL((attn_fwd_reg_kernel<14>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS);
-        hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
-        return (int)hipGetLastError();
-    }
     if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
         else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
@@ -1107,10 +907,6 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
     if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
 #define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per
-    if (dt == LXO_BF16 && E <= 256 && rows_per <= ATT_W * 14 && att_u() != 8) {
-        hipLaunchKernelGGL((attn_bwd_reg_kernel<14>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS);
-        return (int)hipGetLastError();
-    }
     if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
         else { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
