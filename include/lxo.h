@@ -76,6 +76,10 @@ typedef struct lxo_shape {
     int dtype;      /* LXO_F32 (parity mode) or LXO_BF16 (bf16 storage, f32 accumulate) */
     int beam;       /* decode only: beam width the workspace is sized for (>= 1) */
     int max_steps;  /* decode only: step capacity (max_length_formula + 2) */
+    /* training only: tf.nn.dropout keep probability on h and o (attention_cell.py:72,83; config.dropout,
+     * fed at img2seq.py:166) and the seed of this step's counter-based masks; 0 or >= 1 disables */
+    float keep_prob;
+    int dropout_seed;
 } lxo_shape;
 
 /* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF

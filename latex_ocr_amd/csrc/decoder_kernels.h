@@ -3,15 +3,19 @@
 #include "lxo_common.h"
 // split-K partial products of gemm_slab_kernel: value(row, col) = sum_{s<n} p[s*stride + row*ld + col]
 struct Slabs { const float* p; int n; long long stride; int ld; };
+// tf.nn.dropout(x, keep) of attention_cell.py:72,83 with a counter-based mask: element (step t, batch row
+// row0 + r, column c) of stream `which` is kept iff hash24(seed, which, (t*rows_total + row0 + r)*width + c) < thr;
+// kept values are scaled by inv_keep.  thr == 0 disables (keep_prob 1, decode).
+struct Drop { unsigned thr; float inv_keep; unsigned seed; int t, row0, rows_total; };
 int lxo_k_rowmean(int dt, const void* img, float* mean, int B, int R, int C, hipStream_t st);
 int lxo_k_embed_gather(int dt, const float* table, const float* start, const int* formula, void* out, int B, int T, int D, int Dp, int V, hipStream_t st);
 int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* ids, void* out, int n, int D, int Dp, int V, hipStream_t st);
-int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st);
+int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, float* ht_out, int ldh, Drop dr, int B, int U, hipStream_t st);
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
-                   float* dcc, float* dz, int B, int U, hipStream_t st);
-int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st);
+                   float* dcc, float* dz, Drop dr, int B, int U, hipStream_t st);
+int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, Drop dr, int rows, int cols, hipStream_t st);
 int lxo_k_slab_reduce(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st);
-int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st);
+int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, Drop dr, int rows, int cols, hipStream_t st);
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
                    float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st);
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,

@@ -115,10 +115,22 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     }
 }
 
+// dropout mask bit: splitmix64 of the element counter (oracle/ref_model.py drop_mask is the same arithmetic)
+__device__ __forceinline__ float drop_scale(const Drop& d, unsigned which, int r, int c, int width) {
+    if (d.thr == 0u) return 1.f;
+    unsigned long long z = ((unsigned long long)((long long)d.t * d.rows_total + d.row0 + r)) * (unsigned long long)width + (unsigned long long)c;
+    z += 0x9E3779B97F4A7C15ull * ((((unsigned long long)d.seed) << 2) | which);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return ((unsigned)(z >> 40) < d.thr) ? d.inv_keep : 0.f;
+}
+
 // TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71); 4 units per thread
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ z, Slabs zs, const float* __restrict__ c_prev,
                                                       float* __restrict__ gates, float* __restrict__ c_out,
-                                                      float* __restrict__ h_out, int ldh, int B, int U) {
+                                                      float* __restrict__ h_out, float* __restrict__ ht_out, int ldh, Drop dr,
+                                                      int B, int U) {
     const int total = B * (U >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int b = i / (U >> 2), u = (i - b * (U >> 2)) << 2;
@@ -142,19 +154,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
         }
         *reinterpret_cast<f32x4*>(c_out + (long long)b * U + u) = c;
         *reinterpret_cast<f32x4*>(h_out + (long long)b * ldh + u) = h;
+        // h~ = dropout(h): what attention and the o projection read; the LSTM carries the un-dropped h (attention_cell.py:71-72)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] *= drop_scale(dr, 1u, b, u + e, U);
+        *reinterpret_cast<f32x4*>(ht_out + (long long)b * ldh + u) = h;
     }
 }
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                       const float* __restrict__ c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
-                                                      float* __restrict__ dcc, float* __restrict__ dz, int B, int U) {
+                                                      float* __restrict__ dcc, float* __restrict__ dz, Drop dr, int B, int U) {
     const int total = B * (U >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int b = i / (U >> 2), u = (i - b * (U >> 2)) << 2;
         const float* gr = gates + (long long)b * 4 * U + u;
         const f32x4 gi = *reinterpret_cast<const f32x4*>(gr), gj = *reinterpret_cast<const f32x4*>(gr + U);
         const f32x4 gf = *reinterpret_cast<const f32x4*>(gr + 2 * U), go = *reinterpret_cast<const f32x4*>(gr + 3 * U);
-        const f32x4 dh = slab_sum4(s1, b, u) + slab_sum4(s3, b, u) + slab_sum4(s4, b, off4 + u);
+        f32x4 dh = slab_sum4(s1, b, u) + slab_sum4(s3, b, u);          // d_h~ (o projection + attention)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dh[e] *= drop_scale(dr, 1u, b, u + e, U);
+        dh += slab_sum4(s4, b, off4 + u);                              // d_h carried by the next step's LSTM
         const f32x4 cc = *reinterpret_cast<const f32x4*>(c_cur + (long long)b * U + u);
         const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + (long long)b * U + u);
         const f32x4 dci = *reinterpret_cast<const f32x4*>(dcc + (long long)b * U + u);
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 // g = (d_o from the logits + d_o carry) * (1 - o^2)      (backward through o = tanh(.), attention_cell.py:82)
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ a, int lda, Slabs carry,
                                                       const float* __restrict__ o, int ldo, float* __restrict__ g, int ldg,
-                                                      int rows, int cols) {
+                                                      Drop dr, int rows, int cols) {
     const int total = rows * (cols >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int r = i / (cols >> 2), c = (i - r * (cols >> 2)) << 2;
@@ -187,19 +206,24 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
         const f32x4 d = *reinterpret_cast<const f32x4*>(a + (long long)r * lda + c) + slab_sum4(carry, r, c);
         f32x4 out;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = d[e] * (1.f - ov[e] * ov[e]);
+        for (int e = 0; e < 4; ++e) {
+            // rec holds the dropped o = tanh * m/keep; where m = 1 the pre-dropout tanh is o * keep
+            const float sc = drop_scale(dr, 2u, r, c + e, cols);
+            const float th = (dr.thr == 0u) ? ov[e] : ov[e] / dr.inv_keep;
+            out[e] = d[e] * sc * (1.f - th * th);
+        }
         *reinterpret_cast<f32x4*>(g + (long long)r * ldg + c) = out;
     }
 }
 // o = tanh(sum of the K4 slabs) -> rec      (attention_cell.py:82)
-__global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __restrict__ o, int ldo, int rows, int cols) {
+__global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __restrict__ o, int ldo, Drop dr, int rows, int cols) {
     const int total = rows * (cols >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int r = i / (cols >> 2), c = (i - r * (cols >> 2)) << 2;
         const f32x4 v = slab_sum4(sl, r, c);
         f32x4 out;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = tanhf(v[e]);
+        for (int e = 0; e < 4; ++e) out[e] = tanhf(v[e]) * drop_scale(dr, 2u, r, c + e, cols);
         *reinterpret_cast<f32x4*>(o + (long long)r * ldo + c) = out;
     }
 }
@@ -847,17 +871,17 @@ int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* 
     else LAUNCH((embed_rows_kernel<float>), g, table, start, ids, (float*)out, n, D, Dp, V);
     DONE;
 }
-int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, int ldh, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U / 4), z, zs, c_prev, gates, c_out, h_out, ldh, B, U);
+int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, float* ht_out, int ldh, Drop dr, int B, int U, hipStream_t st) {
+    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U / 4), z, zs, c_prev, gates, c_out, h_out, ht_out, ldh, dr, B, U);
     DONE;
 }
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
-                   float* dcc, float* dz, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U / 4), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, B, U);
+                   float* dcc, float* dz, Drop dr, int B, int U, hipStream_t st) {
+    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U / 4), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, dr, B, U);
     DONE;
 }
-int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, int rows, int cols, hipStream_t st) {
-    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, rows, cols);
+int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, Drop dr, int rows, int cols, hipStream_t st) {
+    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, dr, rows, cols);
     DONE;
 }
 __global__ __launch_bounds__(256) static void slab_reduce_kernel(Slabs sl, float* __restrict__ o, int ldo, int rows, int cols) {
@@ -871,8 +895,8 @@ int lxo_k_slab_reduce(Slabs sl, float* o, int ldo, int rows, int cols, hipStream
     LAUNCH(slab_reduce_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, rows, cols);
     DONE;
 }
-int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st) {
-    LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, rows, cols);
+int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, Drop dr, int rows, int cols, hipStream_t st) {
+    LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, dr, rows, cols);
     DONE;
 }
 static int att_u() {

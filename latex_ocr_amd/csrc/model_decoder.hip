@@ -92,7 +92,7 @@ static int join_side(hipStream_t st) { HIPRC(hipEventRecord(g_ev_join, g_side));
 // consumes a product adds its slabs.
 static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int r0, int nr, int beam,
                      const float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
-                     float* gates_t, float* atth_t, float* alpha_t, hipStream_t st) {
+                     float* gates_t, float* atth_t, float* alpha_t, Drop dr, hipStream_t st) {
     const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
     const size_t r = (size_t)r0;
     float* s1 = P.ws<float>(ws, W_S_K1) + r * (P.XH / 128) * 4 * U;
@@ -106,15 +106,15 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
     float* part = P.ws<float>(ws, W_APART) + r * 32 * (C + 2);
     // z = zx + [o_prev, h_prev] K[D:]            (attention_cell.py:70-71)
     RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, s1, nr, 4 * U, P.XH, st));
-    RC(lxo_k_lstm_fwd(zx_t, view(s1, P.XH, nr, 4 * U), cs_prev, gates_t, cs_cur, rec_cur + O, P.REC, nr, U, st));
-    // att_h = h W                                 (attention_mechanism.py:79)
-    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_ATT_H_T), U, s2, nr, E, U, st));
+    RC(lxo_k_lstm_fwd(zx_t, view(s1, P.XH, nr, 4 * U), cs_prev, gates_t, cs_cur, rec_cur + O, rec_cur + P.OFF_HT, P.REC, dr, nr, U, st));
+    // att_h = h~ W                                (attention_mechanism.py:79)
+    RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_ATT_H_T), U, s2, nr, E, U, st));
     RC(lxo_k_attn_fwd(P.s.dtype, att_img, img, nullptr, view(s2, U, nr, E), atth_t,
-                      prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.XH, P.REC, nr, P.R, P.Rp, E, C, beam,
+                      prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.OFF_CTX, P.REC, nr, P.R, P.Rp, E, C, beam,
                       P.attn_chunks(nr), st));
     // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
-    RC(slab(P, rec_cur + O, P.REC, P.pk(wp, K_OW_T), P.HC, s4, nr, O, P.HC, st));
-    RC(lxo_k_tanh_finalize(view(s4, P.HC, nr, O), rec_cur, P.REC, nr, O, st));
+    RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_OW_T), P.HC, s4, nr, O, P.HC, st));
+    RC(lxo_k_tanh_finalize(view(s4, P.HC, nr, O), rec_cur, P.REC, dr, nr, O, st));
     return 0;
 }
 
@@ -136,7 +136,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
                          rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
                          P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
                          P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
-                         P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, h ? g_side : st));
+                         P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, P.drop(t, h * hb), h ? g_side : st));
     if (dual) RC(join_side(st));
     // logits_t = o_t y_W_o for every step at once  (attention_cell.py:84)
     RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
@@ -187,16 +187,17 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             // carry [d_o | d_h] from step t+1 = the B4 slabs of the previous iteration (none at t = T-1)
             const Slabs carry = (t == T - 1) ? kNoSlabs : view(sb4, 4 * U, hb, P.XH);
             // g = (d_o_logits + d_o_carry) * (1 - o^2)
-            RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, hb, O, sh));
+            const Drop dr = P.drop(t, (int)r0);
+            RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, dr, hb, O, sh));
             // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
             RC(slab(P, g_t, O, P.pk(wp, K_OW), O, sb1, hb, P.HC, O, sh));
             RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + ((size_t)t * B + r0) * E, prm + P.poff[P_BETA],
-                              alpha + ((size_t)t * B + r0) * P.Rp, view(sb1, O, hb, P.HC), U, dhc_t + U, P.HC, rec_cur + P.XH, P.REC,
+                              alpha + ((size_t)t * B + r0) * P.Rp, view(sb1, O, hb, P.HC), U, dhc_t + U, P.HC, rec_cur + P.OFF_CTX, P.REC,
                               de + ((size_t)t * B + r0) * P.Rp, datth + ((size_t)t * B + r0) * E, hb, P.R, P.Rp, E, C, nchb, sh));
             // d_h += d_att_h W_att_h^T
             RC(slab(P, datth + ((size_t)t * B + r0) * E, E, P.pk(wp, K_ATT_H), E, sb3, hb, U, E, sh));
             RC(lxo_k_lstm_bwd(gates + ((size_t)t * B + r0) * 4 * U, cs + ((size_t)t * B + r0) * U, cs + ((size_t)(t + 1) * B + r0) * U,
-                              view(sb1, O, hb, P.HC), view(sb3, E, hb, U), carry, O, dcc + r0 * U, dz + ((size_t)t * B + r0) * 4 * U, hb, U, sh));
+                              view(sb1, O, hb, P.HC), view(sb3, E, hb, U), carry, O, dcc + r0 * U, dz + ((size_t)t * B + r0) * 4 * U, dr, hb, U, sh));
             // [d_o carry | d_h carry] = d_z K[D:]^T
             RC(slab(P, dz + ((size_t)t * B + r0) * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
                     sb4, hb, P.XH, 4 * U, sh));
@@ -211,8 +212,8 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_k_slab_reduce(view(sb4, 4 * U, hb, P.XH), dxh + r0 * P.XH, P.XH, hb, P.XH, st));
     }
     // ---- deferred weight gradients over all steps ----
-    RC(tn(P, true, true, rec + (size_t)B * P.REC + O, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));       // d[o_W_h; o_W_c]
-    RC(tn(P, true, true, rec + (size_t)B * P.REC + O, P.REC, datth, E, gw(P_ATT_H), E, TB, U, E, st));       // dW_att_h
+    RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
+    RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, datth, E, gw(P_ATT_H), E, TB, U, E, st));      // dW_att_h
     RC(tn(P, false, true, P.ws<void>(ws, W_EMB_IN), P.Dp, dz, 4 * U, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st)); // dK rows 0..D
     RC(tn(P, true, true, rec, P.REC, dz, 4 * U, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st)); // dK rows D..
     RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, st));
@@ -263,7 +264,7 @@ static int decode_common_step(const Plan& P, const float* prm, const void* wp, v
     const int prev = cur ^ 1;
     RC(cell_step(P, prm, wp, ws, 0, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
                  rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U, nullptr,
-                 P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), st));
+                 P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st));
     RC(nt(P, true, true, nv <= 64, rec + (size_t)cur * nv * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_DEC_LOGITS), P.Vp,
           nv, V, O, nullptr, 0, false, st));
     (void)E;

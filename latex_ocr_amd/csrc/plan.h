@@ -5,6 +5,7 @@
 #pragma once
 #include "lxo.h"
 #include "lxo_common.h"
+#include "decoder_kernels.h"
 
 enum ParamId {
     P_CONV1_W, P_CONV1_B, P_CONV2_W, P_CONV2_B, P_CONV3_W, P_CONV3_B, P_CONV4_W, P_CONV4_B,
@@ -50,7 +51,9 @@ struct Plan {
     // encoder geometry
     int H1, W1, H2, W2, H4, W5, Hp, Wp, R;
     int convCin[6], convCout[6];
-    int Vp, Dp, Rp, XH, HC, REC;   // padded V / D / R (row pitches), O+U, U+C, O+U+C
+    int Vp, Dp, Rp, XH, HC, REC;   // padded V / D / R (row pitches), O+U, U+C, record width O+2U+C
+    int OFF_HT, OFF_CTX;           // record = [o | h | h~ | ctx]: [o|h] feeds the LSTM, [h~|ctx] the attention and o projection
+    Drop drop(int t, int row0) const;   // dropout descriptor of decoder step t for rows row0.. (off when keep_prob is 0 or >= 1)
     // flat parameter buffer
     long long poff[P_COUNT], pcount[P_COUNT], ptotal;
     // packed weights (bytes)

@@ -50,7 +50,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     Vp = (V + 31) / 32 * 32;
     Dp = (D + 31) / 32 * 32;
     Rp = (R + 7) / 8 * 8;
-    XH = O + U; HC = U + C; REC = O + U + C;
+    XH = O + U; HC = U + C; OFF_HT = O + U; OFF_CTX = O + 2 * U; REC = O + 2 * U + C;
 
     long long cnt[P_COUNT];
     for (int i = 0; i < 6; ++i) { cnt[2 * i] = 9LL * ci[i] * co[i]; cnt[2 * i + 1] = co[i]; }
@@ -178,4 +178,15 @@ int Plan::validate(char* msg, size_t n) const {
     BAD(R > 16384, "more than 16384 regions");
 #undef BAD
     return 0;
+}
+
+// tf.nn.dropout(., config.dropout) masks of one decoder step (attention_cell.py:72,83)
+Drop Plan::drop(int t, int row0) const {
+    Drop d = {0u, 1.f, (unsigned)s.dropout_seed, t, row0, s.B};
+    if (s.keep_prob > 0.f && s.keep_prob < 1.f) {
+        d.thr = (unsigned)(s.keep_prob * 16777216.0f);
+        if (d.thr == 0u) d.thr = 1u;
+        d.inv_keep = 1.f / s.keep_prob;
+    }
+    return d;
 }

@@ -142,11 +142,16 @@ class Engine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
     # ---------------------------------------------------------------- steps --
-    def forward(self, img, formula):
-        """Encoder + teacher-forced decoder; leaves logits in the workspace."""
+    def forward(self, img, formula, dropout=None):
+        """Encoder + teacher-forced decoder; leaves logits in the workspace.  dropout = (keep_prob, seed)
+        applies tf.nn.dropout on h and o (attention_cell.py:72,83) with this step's counter-based masks;
+        backward() regenerates the same masks from the bound shape."""
         B, H, W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
         T = int(formula.shape[1])
         self.ensure(B, H, W, T)
+        if dropout is not None and 0.0 < float(dropout[0]) < 1.0:
+            self.shape.keep_prob = float(dropout[0])
+            self.shape.dropout_seed = int(dropout[1]) & 0x7FFFFFFF
         self._img = self._to_dev(img, torch.uint8)
         self._formula = self._to_dev(formula, torch.int32)
         st = self._stream()
@@ -219,10 +224,16 @@ class Engine(object):
                                         _p(scale), st), "adam")
         self.pack()
 
-    def train_step(self, img, formula, lengths, lr, clip=-1.0, dist=None, sync_loss=True):
+    def train_step(self, img, formula, lengths, lr, clip=-1.0, dist=None, sync_loss=True, dropout=1.0, dropout_seed=None):
         """One optimisation step of img2seq.py:_run_train's body.  Returns the batch loss
-        (token mean over the global batch) or None when sync_loss is False."""
-        self.forward(img, formula)
+        (token mean over the global batch) or None when sync_loss is False.  dropout = config.dropout
+        (keep probability, img2seq.py:166); masks are keyed by (dropout_seed or a per-engine step counter)."""
+        drop = None
+        if dropout is not None and 0.0 < float(dropout) < 1.0:
+            self.drop_step = getattr(self, "drop_step", 0) + 1
+            world, rank = (dist.world, dist.rank) if dist is not None else (1, 0)
+            drop = (float(dropout), dropout_seed if dropout_seed is not None else self.drop_step * world + rank)
+        self.forward(img, formula, dropout=drop)
         n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
         n_global = dist.sum_scalar(n_local) if dist is not None else n_local
         stats = self.loss(lengths, 1.0 / float(n_global))

@@ -56,9 +56,10 @@ class Img2SeqModel(BaseModel):
     # ------------------------------------------------------------------ feeds --
     def _get_feed_dict(self, img, formula=None, lr=None, dropout=1):
         """Reference: model/img2seq.py:125-142.  `dropout` is a KEEP probability (quirk C-5);
-        every value >= 1 is the identity, which is all the shipped configs use."""
-        if dropout < 1:
-            raise NotImplementedError("dropout keep-prob < 1 is not built (shipped configs use 1 / 127 = identity)")
+        every value >= 1 is the identity (the shipped configs use 1 and 127); values in (0, 1) drop h and o
+        in the decoder cell (attention_cell.py:72,83) -- the encoder receives the placeholder but never uses it."""
+        if not dropout > 0:
+            raise ValueError("dropout is a keep probability and must be > 0, got {}".format(dropout))
         fd = {"img": pad_batch_images(img), "dropout": dropout}
         if formula is not None:
             f, l = pad_batch_formulas(formula, self._vocab.id_pad, self._vocab.id_end)
@@ -75,7 +76,8 @@ class Img2SeqModel(BaseModel):
         prog = Progbar(nbatches)
         for i, (img, formula) in enumerate(minibatches(train_set, batch_size)):
             fd = self._get_feed_dict(img, formula=formula, lr=lr_schedule.lr, dropout=config.dropout)
-            loss_eval = self.engine.train_step(fd["img"], fd["formula"], fd["formula_length"], fd["lr"], clip=self._clip)
+            loss_eval = self.engine.train_step(fd["img"], fd["formula"], fd["formula_length"], fd["lr"], clip=self._clip,
+                                               dropout=fd["dropout"])
             prog.update(i + 1, [("loss", loss_eval), ("perplexity", np.exp(loss_eval)), ("lr", lr_schedule.lr)])
             lr_schedule.update(batch_no=epoch * nbatches + i)
         self.logger.info("- Training: {}".format(prog.info))

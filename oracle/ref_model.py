@@ -161,9 +161,28 @@ def attention_prepare(P, enc):
     return img, att_img, (s0("c"), s0("h"), s0("o"))                     # LSTMStateTuple order c,h
 
 
-def cell_step(P, img, att_img, emb, state, return_alpha=False):
+def drop_mask(keep, seed, which, t, rows, width, rows_total=None, row0=0):
+    """Dropout scale (0 or 1/keep) of attention_cell.py:72 (which=1, on h) / :83 (which=2, on o) for decoder
+    step t.  tf.nn.dropout draws from TF's stateful Philox stream, which cannot be reproduced; the product and
+    this oracle share a counter-based mask instead: splitmix64 of ((t*rows_total + row)*width + col) offset by
+    (seed, which), kept iff its top 24 bits < keep * 2^24."""
+    rows_total = rows if rows_total is None else rows_total
+    with np.errstate(over="ignore"):
+        r = (np.uint64(t) * np.uint64(rows_total) + np.arange(row0, row0 + rows, dtype=np.uint64))[:, None]
+        z = r * np.uint64(width) + np.arange(width, dtype=np.uint64)[None, :]
+        z = z + np.uint64(0x9E3779B97F4A7C15) * np.uint64((int(seed) & 0xFFFFFFFF) << 2 | which)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    thr = max(1, int(np.float32(keep) * np.float32(16777216.0)))
+    kept = (z >> np.uint64(40)).astype(np.int64) < thr
+    return torch.from_numpy(kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep)))
+
+
+def cell_step(P, img, att_img, emb, state, return_alpha=False, drop=None):
     """attention_cell.py:58-89 with TF-1.12 LSTMCell (+TF: gate order i,j,f,o,
-    forget_bias 1.0, no peepholes), keep-prob 1."""
+    forget_bias 1.0, no peepholes).  drop = (keep, seed, t) applies the two
+    tf.nn.dropout calls (:72, :83); None = keep-prob 1."""
     c, h, o = state
     U = c.shape[1]
     x = torch.cat([emb, o], dim=-1)                                      # :70
@@ -171,15 +190,21 @@ def cell_step(P, img, att_img, emb, state, return_alpha=False):
     i, j, f, og = z[:, :U], z[:, U:2 * U], z[:, 2 * U:3 * U], z[:, 3 * U:]
     c2 = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
     h2 = torch.sigmoid(og) * torch.tanh(c2)                              # :71
+    h_carry = h2                                                         # LSTMStateTuple keeps the un-dropped h
+    if drop is not None:
+        keep, seed, t = drop
+        h2 = h2 * drop_mask(keep, seed, 1, t, h2.shape[0], h2.shape[1]).to(h2.dtype)   # :72
     att_h = h2 @ P[A_ + "rnn/att_mechanism/dense/kernel"]               # attention_mechanism.py:79
     e = torch.tanh(att_img + att_h[:, None, :]) @ P[A_ + "rnn/att_mechanism/att_beta"]  # :83-91
     alpha = torch.softmax(e.squeeze(-1), dim=-1)                         # :94
     ctx = (alpha[:, :, None] * img).sum(dim=1)                           # :73-74
     o2 = torch.tanh(h2 @ P[A_ + "rnn/o_W_h"] + ctx @ P[A_ + "rnn/o_W_c"])   # :82
+    if drop is not None:
+        o2 = o2 * drop_mask(keep, seed, 2, t, o2.shape[0], o2.shape[1]).to(o2.dtype)   # :83
     logits = o2 @ P[A_ + "rnn/y_W_o"]                                    # :84
     if return_alpha:
-        return logits, (c2, h2, o2), alpha
-    return logits, (c2, h2, o2)
+        return logits, (c2, h_carry, o2), alpha
+    return logits, (c2, h_carry, o2)
 
 
 def train_embeddings(P, formula):
@@ -191,17 +216,19 @@ def train_embeddings(P, formula):
     return torch.cat([start, e[:, :-1, :]], dim=1)
 
 
-def decoder_train(P, enc, formula, return_alpha=False):
-    """decoder.py:50-57: T = formula.shape[1] steps, padded steps computed."""
+def decoder_train(P, enc, formula, return_alpha=False, dropout=None):
+    """decoder.py:50-57: T = formula.shape[1] steps, padded steps computed.
+    dropout = (keep, seed) or None (config.dropout = 1, the shipped value)."""
     img, att_img, state = attention_prepare(P, enc)
     emb = train_embeddings(P, formula)
     outs, alphas = [], []
     for t in range(formula.shape[1]):
+        dr = None if dropout is None else (dropout[0], dropout[1], t)
         if return_alpha:
-            lg, state, a = cell_step(P, img, att_img, emb[:, t], state, True)
+            lg, state, a = cell_step(P, img, att_img, emb[:, t], state, True, drop=dr)
             alphas.append(a)
         else:
-            lg, state = cell_step(P, img, att_img, emb[:, t], state)
+            lg, state = cell_step(P, img, att_img, emb[:, t], state, drop=dr)
         outs.append(lg)
     logits = torch.stack(outs, dim=1)
     if return_alpha:
@@ -220,17 +247,17 @@ def loss_fn(logits, formula, lengths):
     return ce_words / mask.sum(), ce_words, n_words
 
 
-def forward_loss(P, img_u8, formula, lengths, positional=True):
+def forward_loss(P, img_u8, formula, lengths, positional=True, dropout=None):
     enc = encoder(P, img_u8, positional)
-    logits = decoder_train(P, enc, formula)
+    logits = decoder_train(P, enc, formula, dropout=dropout)
     return loss_fn(logits, formula, lengths)
 
 
-def train_grads(P, img_u8, formula, lengths, positional=True):
+def train_grads(P, img_u8, formula, lengths, positional=True, dropout=None):
     """loss and d(loss)/d(param) by autograd (the reference gets BPTT from TF
     autodiff, img2seq.py:119-123)."""
     Q = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
-    loss, ce_words, n_words = forward_loss(Q, img_u8, formula, lengths, positional)
+    loss, ce_words, n_words = forward_loss(Q, img_u8, formula, lengths, positional, dropout)
     grads = torch.autograd.grad(loss, list(Q.values()), allow_unused=True)
     G = OrderedDict((k, (g if g is not None else torch.zeros_like(P[k]))) for k, g in zip(Q.keys(), grads))
     return loss.detach(), G, ce_words.detach(), n_words
@@ -265,8 +292,8 @@ class AdamTF(object):
             P[k].sub_(lr_t * self.m[k] / (self.v[k].sqrt() + self.eps))
 
 
-def train_step(P, opt, img_u8, formula, lengths, lr, clip=-1.0, positional=True):
-    loss, G, _, _ = train_grads(P, img_u8, formula, lengths, positional)
+def train_step(P, opt, img_u8, formula, lengths, lr, clip=-1.0, positional=True, dropout=None):
+    loss, G, _, _ = train_grads(P, img_u8, formula, lengths, positional, dropout)
     if clip > 0:
         G, _ = clip_by_global_norm(G, clip)
     opt.step(P, G, lr)

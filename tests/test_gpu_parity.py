@@ -12,17 +12,17 @@ pytestmark = pytest.mark.gpu
 from gpu_common import *  # noqa
 
 
-def _grads_check(dtype, tol_loss, min_cos):
+def _grads_check(dtype, tol_loss, min_cos, dropout=None):
     V = 50
     img, f, l = batch(6, 32, 128, V, 5, 12, seed=7)
     eng = Engine(V, dtype=dtype, seed=3)
     P = oracle_params(eng)
-    eng.forward(img, f)
+    eng.forward(img, f, dropout=dropout)
     n = int(l.sum())
     stats = eng.loss(l, 1.0 / n).cpu().numpy()
     eng.backward()
     torch.cuda.synchronize()
-    loss_ref, G, ce, nw = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l))
+    loss_ref, G, ce, nw = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l), dropout=dropout)
     loss = stats[0] / stats[1]
     assert stats[1] == n
     assert abs(loss - float(loss_ref)) / float(loss_ref) < tol_loss, (loss, float(loss_ref))
@@ -41,6 +41,15 @@ def test_fwd_bwd_f32():
 
 def test_fwd_bwd_bf16():
     _grads_check("bf16", 1e-3, 0.98)
+
+
+def test_fwd_bwd_dropout_f32():
+    # config.dropout < 1: tf.nn.dropout on h and o (attention_cell.py:72,83), masks shared with the oracle
+    _grads_check("f32", 2e-5, 0.99999, dropout=(0.8, 77))
+
+
+def test_fwd_bwd_dropout_bf16():
+    _grads_check("bf16", 2e-3, 0.97, dropout=(0.8, 77))
 
 
 def test_encoder_features_f32():

@@ -146,3 +146,32 @@ def test_other_optimizers(method, mode, init):
         assert L.lxo_optimizer_step(mode, n, ptr(p), ptr(g), ptr(slot), ctypes.c_float(0.01), None, None) == 0
         opt.step(P, {"w": torch.from_numpy(g)}, 0.01)
     assert np.abs(p - P["w"].numpy()).max() < 1e-6
+
+
+@pytest.mark.parametrize("dual", [0, 1])
+def test_dropout_forward_backward_vs_oracle(dual):
+    """config.dropout < 1 (attention_cell.py:72,83): same counter-based masks in the kernels and in the oracle."""
+    import torch
+    from oracle import ref_model as R
+    img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
+    keep, seed = 0.7, 12345
+    S = Sim(2, 32, 48, f.shape[1], 11, dtype=0, seed=0)
+    S.shape.keep_prob, S.shape.dropout_seed = keep, seed
+    lib().lxo_set_side_stream(ctypes.c_void_p(1 if dual else 0))
+    try:
+        S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+        S.ck(S.L.lxo_decoder_train_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), None), "dec")
+        S.ck(S.L.lxo_ce_loss_fwd_bwd(S.sref(), ptr(S.ws), ptr(f), ptr(l), ctypes.c_float(1.0 / int(l.sum())), None), "loss")
+        S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), None), "decbwd")
+        S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, None), "encbwd")
+    finally:
+        lib().lxo_set_side_stream(ctypes.c_void_p(0))
+    P = {k: torch.from_numpy(np.asarray(v)) for k, v in S.P.items()}
+    loss, G, _, _ = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l), dropout=(keep, seed))
+    loss0 = float(GOLD["loss"])
+    st = S.region("loss", np.float32)[:2]
+    assert abs(st[0] / st[1] - float(loss)) < 5e-6
+    assert abs(float(loss) - loss0) > 1e-4            # the masks did something
+    for k, _, _ in S.specs:
+        g, r = S.grad(k), G[k].numpy()
+        assert np.abs(g - r).max() <= 3e-5 * max(np.abs(r).max(), 1e-6) + 1e-9, k
