@@ -80,6 +80,10 @@ typedef struct lxo_shape {
      * fed at img2seq.py:166) and the seed of this step's counter-based masks; 0 or >= 1 disables */
     float keep_prob;
     int dropout_seed;
+    /* beam decode only: add_div_penalty (beam_search_decoder_cell.py:258-287; configs/model.json:15-16).
+     * div_gamma 0 or 1, or div_prob 0, disables; div_seed keys the Bernoulli(div_prob) draws */
+    float div_gamma, div_prob;
+    int div_seed;
 } lxo_shape;
 
 /* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")
 
 class LxoShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("B", "H", "W", "T", "V", "C", "E", "U", "O", "D", "dtype", "beam", "max_steps")] + \
-               [("keep_prob", c_float), ("dropout_seed", c_int)]
+               [("keep_prob", c_float), ("dropout_seed", c_int), ("div_gamma", c_float), ("div_prob", c_float), ("div_seed", c_int)]
 
 
 def bind(lib):

@@ -31,7 +31,8 @@ int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, fl
 int lxo_k_init_bwd(const float* dcc, Slabs dxh, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st);
 int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids_step, int* ids_out, int max_steps, int step,
                  int* finished, int* n_unfinished, hipStream_t st);
-int lxo_k_beam_step(const float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float* logp, int* finished,
+int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float div_gamma, float div_prob, int div_seed,
+                    float* scratch, float* logp, int* finished,
                     int* ids_step, int* parents_step, int* ids_out, int* par_out, int max_steps, int* n_unfinished, hipStream_t st);
 int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, hipStream_t st);
 int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k, int cols, hipStream_t st);

@@ -702,7 +702,12 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
 // One block per image: beam_search_decoder_cell.py:146-187.
 //  log_softmax, mask finished beams (0 at END, f32 lowest elsewhere), add running log-probs,
 //  top-k over k*V (beam 0 only at time 0), ids = idx % V, parents = idx / V, gather finished.
-__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, int Vp, int V, int k, int id_end, int time,
+// add_div_penalty (beam_search_decoder_cell.py:258-287, Li et al. 2016): score += log(div_gamma) * rank * bernoulli(div_prob),
+// rank = position of the entry in the descending sort of its hypothesis' V scores (ties: lower id first, as
+// tf.nn.top_k orders them).  Bernoulli draws: the counter hash of drop_scale on (time, image, beam, id).
+struct DivPen { float log_gamma; unsigned thr; unsigned seed; float* scratch; };   // log_gamma == 0 or thr == 0: off
+
+__global__ __launch_bounds__(256) void beam_step_kernel(float* __restrict__ logits, int Vp, int V, int k, int id_end, int time, DivPen dp,
                                                        float* __restrict__ logp, int* __restrict__ finished,
                                                        int* __restrict__ ids_step, int* __restrict__ parents_step,
                                                        int* __restrict__ ids_out, int* __restrict__ par_out, int max_steps,
@@ -728,6 +733,29 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     __syncthreads();
     const int nb = time > 0 ? k : 1;
     const int total = nb * V;
+    const bool div = dp.log_gamma != 0.f && dp.thr != 0u;
+    float* pen = dp.scratch + (long long)b * k * Vp;
+    if (div) {
+        float* row0 = logits + (long long)b * k * Vp;
+        for (int i = tid; i < k * V; i += 256) {            // scores of every hypothesis, in place of its logits
+            const int j = i / V, c = i - j * V;
+            float sl = row0[j * Vp + c] - lse[j];
+            const float f = fin_old[j] ? 1.f : 0.f;
+            sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
+            row0[j * Vp + c] = logp[b * k + j] + sl;
+        }
+        __syncthreads();
+        for (int i = tid; i < k * V; i += 256) {
+            const int j = i / V, c = i - j * V;
+            const float* row = row0 + j * Vp;
+            const float v = row[c];
+            int rank = 0;
+            for (int q = 0; q < V; ++q) { const float w = row[q]; rank += (w > v || (w == v && q < c)) ? 1 : 0; }
+            const Drop dd = {dp.thr, 1.f, dp.seed, time, b * k + j, (int)gridDim.x * k};
+            pen[j * Vp + c] = v + dp.log_gamma * (float)rank * drop_scale(dd, 3u, 0, c, V);
+        }
+        __syncthreads();
+    }
     for (int sel = 0; sel < k; ++sel) {
         float best = -INFINITY; int bi = 0x7fffffff;
         for (int i = tid; i < total; i += 256) {
@@ -735,10 +763,14 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
             bool taken = false;
             for (int q = 0; q < sel; ++q) taken |= (sel_i[q] == i);
             if (taken) continue;
-            float sl = logits[((long long)b * k + j) * Vp + c] - lse[j];
-            const float f = fin_old[j] ? 1.f : 0.f;
-            sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
-            const float val = logp[b * k + j] + sl;
+            float val;
+            if (div) val = pen[j * Vp + c];
+            else {
+                float sl = logits[((long long)b * k + j) * Vp + c] - lse[j];
+                const float f = fin_old[j] ? 1.f : 0.f;
+                sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
+                val = logp[b * k + j] + sl;
+            }
             if (val > best || (val == best && i < bi)) { best = val; bi = i; }
         }
 #pragma unroll
@@ -977,10 +1009,16 @@ int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids
     LAUNCH(argmax_kernel, cdiv(n, 4), logits, Vp, V, n, id_end, ids_step, ids_out, max_steps, step, finished, n_unfinished);
     DONE;
 }
-int lxo_k_beam_step(const float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float* logp, int* finished,
+int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float div_gamma, float div_prob, int div_seed,
+                    float* scratch, float* logp, int* finished,
                     int* ids_step, int* parents_step, int* ids_out, int* par_out, int max_steps, int* n_unfinished, hipStream_t st) {
     if (k > 16) return -2;
-    LAUNCH(beam_step_kernel, nimg, logits, Vp, V, k, id_end, time, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
+    DivPen dp = {0.f, 0u, (unsigned)div_seed, scratch};
+    if (div_gamma > 0.f && div_gamma != 1.f && div_prob > 0.f) {      // the reference returns early for gamma == 1 or prob == 0
+        dp.log_gamma = logf(div_gamma);
+        dp.thr = div_prob >= 1.f ? 16777216u : (unsigned)(div_prob * 16777216.0f);
+    }
+    LAUNCH(beam_step_kernel, nimg, logits, Vp, V, k, id_end, time, dp, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
     DONE;
 }
 int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, hipStream_t st) {

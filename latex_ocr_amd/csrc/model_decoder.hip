@@ -333,7 +333,8 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
             const int time = steps + c;
             const int cur = (time + 1) & 1;
             RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st));
-            RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, logp, finished, ids_step, par_step,
+            RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, P.s.div_gamma, P.s.div_prob, P.s.div_seed, tmp,
+                               logp, finished, ids_step, par_step,
                                ids_out, parents_out, ms, flags + c, st));
             RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
                                  tmp, tmp + (size_t)nv * P.XH, nv, st));

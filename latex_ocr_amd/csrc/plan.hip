@@ -140,6 +140,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
         wb[W_BEAM_LP] = BK_ * 2 * f4;
         wb[W_BEAM_PAR] = BK_ * ms * 4;
         wb[W_BEAM_TMP] = 3 * (BK_ * REC + BK_ * U) * f4 / 3 + BK_ * 64;
+        if (wb[W_BEAM_TMP] < BK_ * Vp * f4) wb[W_BEAM_TMP] = BK_ * Vp * f4;   // also the penalised-score scratch of add_div_penalty
         // decode reuses rec / cs / att_h / alpha with (T = 2 ping-pong) rows per beam
         const size_t recd = 2 * BK_ * REC * f4, csd = 2 * BK_ * U * f4;
         if (wb[W_REC] < recd) wb[W_REC] = recd;

@@ -346,11 +346,14 @@ class Engine(object):
                                             _p(ids), ctypes.byref(steps), self._stream()), "greedy_decode")
         return ids[:, :steps.value].cpu().numpy()
 
-    def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False):
-        """ids int32 [B, T', k] as pred_test.ids of the beam graph before the transpose at img2seq.py:241."""
+    def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False, div_gamma=1.0, div_prob=0.0, div_seed=0):
+        """ids int32 [B, T', k] as pred_test.ids of the beam graph before the transpose at img2seq.py:241.
+        div_gamma / div_prob: add_div_penalty of beam_search_decoder_cell.py:258-287 (off at 1 / 0, the shipped values)."""
         if self.max_steps < max_iter + 1:
             self.max_steps, self.ws = max_iter + 1, None
         B = self._encode_only(img, int(beam_size))
+        self.shape.div_gamma, self.shape.div_prob = float(div_gamma or 0.0), float(div_prob or 0.0)
+        self.shape.div_seed = int(div_seed) & 0x7FFFFFFF
         ids = torch.zeros(B, self.max_steps, beam_size, dtype=torch.int32, device=self.device)
         par = torch.zeros(B, self.max_steps, beam_size, dtype=torch.int32, device=self.device)
         steps = ctypes.c_int(0)

@@ -100,7 +100,10 @@ class Img2SeqModel(BaseModel):
         cfg = self._config
         max_iter = getattr(cfg, "max_length_formula", 150) + 1          # decoder.py:70
         if getattr(cfg, "decoding", "greedy") == "beam_search":
-            ids = self.engine.beam_decode(img, self._vocab.id_end, cfg.beam_size, max_iter=max_iter)
+            self._div_calls = getattr(self, "_div_calls", 0) + 1
+            ids = self.engine.beam_decode(img, self._vocab.id_end, cfg.beam_size, max_iter=max_iter,
+                                          div_gamma=getattr(cfg, "div_gamma", 1), div_prob=getattr(cfg, "div_prob", 0),
+                                          div_seed=self._div_calls)              # decoder.py:67-68
             return np.transpose(ids, [0, 2, 1])
         ids = self.engine.greedy_decode(img, self._vocab.id_end, max_iter=max_iter)
         return np.expand_dims(ids, axis=1)

@@ -166,6 +166,13 @@ def drop_mask(keep, seed, which, t, rows, width, rows_total=None, row0=0):
     step t.  tf.nn.dropout draws from TF's stateful Philox stream, which cannot be reproduced; the product and
     this oracle share a counter-based mask instead: splitmix64 of ((t*rows_total + row)*width + col) offset by
     (seed, which), kept iff its top 24 bits < keep * 2^24."""
+    thr = max(1, int(np.float32(keep) * np.float32(16777216.0)))
+    kept = hash24(seed, which, t, rows, width, rows_total, row0) < thr
+    return torch.from_numpy(kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep)))
+
+
+def hash24(seed, which, t, rows, width, rows_total=None, row0=0):
+    """24-bit counter hash shared with csrc/decoder_kernels.hip drop_scale (int64 array [rows, width])."""
     rows_total = rows if rows_total is None else rows_total
     with np.errstate(over="ignore"):
         r = (np.uint64(t) * np.uint64(rows_total) + np.arange(row0, row0 + rows, dtype=np.uint64))[:, None]
@@ -174,9 +181,7 @@ def drop_mask(keep, seed, which, t, rows, width, rows_total=None, row0=0):
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
-    thr = max(1, int(np.float32(keep) * np.float32(16777216.0)))
-    kept = (z >> np.uint64(40)).astype(np.int64) < thr
-    return torch.from_numpy(kept.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(keep)))
+    return (z >> np.uint64(40)).astype(np.int64)
 
 
 def cell_step(P, img, att_img, emb, state, return_alpha=False, drop=None):
@@ -331,9 +336,24 @@ def greedy_decode(P, img_u8, id_end, max_iter=151, positional=True, return_logit
 
 
 @torch.no_grad()
-def beam_decode(P, img_u8, id_end, beam_size, max_iter=151, positional=True):
-    """beam_search_decoder_cell.py:98-250 in reference-faithful mode (div_gamma
-    1 / div_prob 0; `finalize` never follows parents, quirk C-1, so hypothesis
+def add_div_penalty(lp, div_gamma, div_prob, div_seed, time):
+    """beam_search_decoder_cell.py:258-287: lp[b,k,v] += log(div_gamma) * rank * bernoulli(div_prob), rank = the
+    position of v in the descending sort of lp[b,k,:] (+TF top_k: ties -> lower index first).  The Bernoulli
+    draws use the shared counter hash (stream 3) instead of TF's stateful RNG."""
+    if div_gamma is None or div_prob is None or div_gamma == 1.0 or div_prob == 0.0:      # :270-273
+        return lp
+    B, k, V = lp.shape
+    order = torch.argsort(lp.reshape(B * k, V), dim=1, descending=True, stable=True)         # :276
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(V).expand(B * k, V).contiguous())                # :278-280 invert_permutation
+    thr = 16777216 if div_prob >= 1.0 else int(np.float32(div_prob) * np.float32(16777216.0))
+    apply = torch.from_numpy((hash24(div_seed, 3, time, B * k, V) < thr).astype(np.float32))   # :284
+    pen = np.float32(math.log(np.float32(div_gamma))) * rank.to(torch.float32) * apply     # :282-285
+    return lp + pen.reshape(B, k, V)
+
+
+def beam_decode(P, img_u8, id_end, beam_size, max_iter=151, positional=True, div_gamma=1.0, div_prob=0.0, div_seed=0):
+    """beam_search_decoder_cell.py:98-250 (`finalize` never follows parents, quirk C-1, so hypothesis
     i is ids[:, t, i] at every t).  Returns int32 [B, T', k] and the parents."""
     enc = encoder(P, img_u8, positional)
     img, att_img, (c, h, o) = attention_prepare(P, enc)
@@ -356,6 +376,7 @@ def beam_decode(P, img_u8, id_end, beam_size, max_iter=151, positional=True):
         fin = finished.to(torch.float32)[:, :, None]
         step_lp = (1.0 - fin) * step_lp + fin * one_hot
         lp = log_probs[:, :, None] + step_lp                                 # :150
+        lp = add_div_penalty(lp, div_gamma, div_prob, div_seed, time)        # :151
         flat = lp.reshape(B, k * V) if time > 0 else lp[:, 0]                # :156-160
         new_probs, idx = _top_k_lowest_index(flat, k)                        # :161
         new_ids = idx % V                                                    # :164

@@ -126,3 +126,19 @@ def test_beam_f32():
     rid, rpar = R.beam_decode(oracle_params(eng), torch.from_numpy(img), V - 1, 3, max_iter=12)
     assert ids.shape == tuple(rid.shape)
     assert np.array_equal(ids, rid.numpy()) and np.array_equal(par, rpar.numpy())
+
+
+@pytest.mark.parametrize("gamma,prob", [(0.5, 1.0), (0.7, 0.4)])
+def test_beam_diversity_penalty_f32(gamma, prob):
+    # add_div_penalty (beam_search_decoder_cell.py:258-287); Bernoulli draws shared with the oracle
+    V = 50
+    imgs, _ = synthetic.config1()
+    img = pad_batch_images(imgs[:8])
+    eng = Engine(V, dtype="f32", seed=9)
+    ids, par = eng.beam_decode(img, V - 1, 3, max_iter=12, return_parents=True, div_gamma=gamma, div_prob=prob, div_seed=21)
+    rid, rpar = R.beam_decode(oracle_params(eng), torch.from_numpy(img), V - 1, 3, max_iter=12,
+                              div_gamma=gamma, div_prob=prob, div_seed=21)
+    assert ids.shape == tuple(rid.shape)
+    assert np.array_equal(ids, rid.numpy()) and np.array_equal(par, rpar.numpy())
+    ids0 = eng.beam_decode(img, V - 1, 3, max_iter=12)
+    assert ids0.shape != ids.shape or not np.array_equal(ids0, ids)

@@ -175,3 +175,21 @@ def test_dropout_forward_backward_vs_oracle(dual):
     for k, _, _ in S.specs:
         g, r = S.grad(k), G[k].numpy()
         assert np.abs(g - r).max() <= 3e-5 * max(np.abs(r).max(), 1e-6) + 1e-9, k
+
+
+@pytest.mark.parametrize("gamma,prob", [(0.5, 1.0), (0.3, 0.5)])
+def test_beam_diversity_penalty_vs_oracle(gamma, prob):
+    """add_div_penalty (beam_search_decoder_cell.py:258-287): rank penalty with shared Bernoulli draws."""
+    import torch
+    from oracle import ref_model as R
+    img = GOLD["img"]
+    S = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, beam=3, max_steps=9)
+    S.shape.div_gamma, S.shape.div_prob, S.shape.div_seed = gamma, prob, 4
+    S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+    bids = np.zeros((2, 9, 3), np.int32); bpar = np.zeros((2, 9, 3), np.int32); steps = ctypes.c_int(0)
+    S.ck(S.L.lxo_beam_decode(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), 10, 8, ptr(bids), ptr(bpar), ctypes.byref(steps), None), "beam")
+    P = {k: torch.from_numpy(np.asarray(v)) for k, v in S.P.items()}
+    ids, par = R.beam_decode(P, torch.from_numpy(img), 10, 3, max_iter=8, div_gamma=gamma, div_prob=prob, div_seed=4)
+    n = steps.value
+    assert n == ids.shape[1]
+    assert np.array_equal(bids[:, :n], ids.numpy()) and np.array_equal(bpar[:, :n], par.numpy())
