@@ -50,6 +50,15 @@ int lxo_gemm_slab(int dt, const void* A, const void* Bp, float* slab, int M, int
 int lxo_conv3x3(int dt, const void* in, const void* wpk, const float* bias, void* out, int B, int H, int W,
                 int Cin, int Ho, int Wo, int Cout, int pad, int relu, void* stream);
 
+/* lxo_conv3x3 with the rest of the fused epilogue the encoder uses: out_pre (optional) receives
+ * act(conv + bias) before `addend` (f32 [addend_rows][Cout], row = pixel index % addend_rows: the timing signal of
+ * positional.py:10-65 fused into conv6) is added; relu_ref (optional, same shape as out) zeroes out where the
+ * reference activation is <= 0 (the ReLU backward of the producing layer when this call is a dgrad) and
+ * colsum (optional, f32 [Cout], accumulated) receives the column sums of the result (that layer's bias gradient). */
+int lxo_conv3x3_ex(int dt, const void* in, const void* wpk, const float* bias, void* out, int B, int H, int W,
+                   int Cin, int Ho, int Wo, int Cout, int pad, int relu, const float* addend, int addend_rows,
+                   void* out_pre, const void* relu_ref, float* colsum, void* stream);
+
 /* weight gradient of lxo_conv3x3: dw[9*Cin][Cout] (f32, HWIO flattened) += sum_pixels in (x) dout.
  * What TF autodiff derives for the tf.layers.conv2d kernels (model/img2seq.py:119-123). */
 int lxo_conv3x3_wgrad(int dt, const void* in, const void* dout, float* dw, int B, int H, int W,

@@ -27,6 +27,7 @@ def bind(lib):
         "lxo_gemm_nt": (c_int, [c_int] * 4 + [c_void] * 3 + [c_int] * 6 + [c_void, c_int, c_float, c_int, c_void]),
         "lxo_gemm_tn": (c_int, [c_int] * 3 + [c_void] * 3 + [c_int] * 8 + [c_void]),
         "lxo_conv3x3": (c_int, [c_int, c_void, c_void, c_void, c_void] + [c_int] * 9 + [c_void]),
+        "lxo_conv3x3_ex": (c_int, [c_int, c_void, c_void, c_void, c_void] + [c_int] * 9 + [c_void, c_int, c_void, c_void, c_void, c_void]),
         "lxo_conv3x3_wgrad": (c_int, [c_int, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
         "lxo_gemm_slab": (c_int, [c_int, c_void, c_void, c_void] + [c_int] * 6 + [c_ll, c_void]),
         "lxo_attention_fwd": (c_int, [c_int] + [c_void] * 7 + [c_int] * 6 + [c_void]),
@@ -62,7 +63,7 @@ def bind(lib):
     return lib
 
 
-ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name",
+ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name",
                 "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
                 "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_set_side_stream", "lxo_decoder_train_fwd",
                 "lxo_ce_loss_fwd_bwd", "lxo_decoder_train_bwd", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",

@@ -131,6 +131,18 @@ extern "C" int lxo_conv3x3(int dt, const void* in, const void* wpk, const float*
     CHECK_LAUNCH(lxo_launch_gemm_nt(dt, 0, 0, 0, g, (hipStream_t)stream), "lxo_conv3x3");
     return 0;
 }
+extern "C" int lxo_conv3x3_ex(int dt, const void* in, const void* wpk, const float* bias, void* out, int B, int H, int W,
+                              int Cin, int Ho, int Wo, int Cout, int pad, int relu, const float* addend, int addend_rows,
+                              void* out_pre, const void* relu_ref, float* colsum, void* stream) {
+    GemmNT g; memset(&g, 0, sizeof(g));
+    g.A = in; g.Bp = wpk; g.C = out; g.conv = 1; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.pad = pad;
+    g.M = B * Ho * Wo; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
+    g.bias = bias; g.act = relu ? 1 : 0; g.alpha = 1.f;
+    g.addend = addend; g.addend_rows = addend_rows > 0 ? addend_rows : 1; g.out_pre = out_pre;
+    g.relu_ref = relu_ref; g.ldr = Cout; g.colsum = colsum;
+    CHECK_LAUNCH(lxo_launch_gemm_nt(dt, 0, 0, 0, g, (hipStream_t)stream), "lxo_conv3x3_ex");
+    return 0;
+}
 extern "C" int lxo_attention_fwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta,
                                  float* alpha, float* part, float* ctx, int ldctx, int nv, int R, int E, int C, int beam,
                                  void* stream) {

@@ -403,12 +403,206 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 256-channel-wide halo variant (layers with Cout % 256 == 0): a workgroup owns an 8 x 32 block
+// of output pixels x 256 channels; each of the 8 waves (2 M x 4 N) accumulates 128 pixels x 64
+// channels = 4 x 2 MFMA blocks, so one barrier covers 32 MFMAs per wave instead of 16, an MFMA
+// needs 0.75 instead of 1 ds_read_b128, and a weight tile crosses L2->LDS once per 256 pixels x
+// 256 channels.  LDS: two (8+2) x (32+2) patches of a 64-channel slice (6 LDS-DMA slots per
+// thread each) + two 256 x 64 weight stages = 160 KB.
+constexpr int QTH = 8, QTW = 32, QPW = QTW + 2, QPH = QTH + 2, QPROWS = QPH * QPW;   // 340 patch pixels
+constexpr int QPATCH = 6 * CTH * 16;                                                  // 49152 >= 340 * 128
+constexpr int QBN = 256, QB_STAGE = QBN * CBK * 2;                                    // 32768
+
+__global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    const int tx_i = mt % tiles_x, ty_i = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+    const int oy0 = ty_i * QTH, ox0 = tx_i * QTW, n0 = nt * QBN;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + (long long)b * p.H * p.W * p.Cin;   // this image
+    const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
+    const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
+    char* patch0 = lxo_conv_lds;
+    char* bst0 = lxo_conv_lds + 2 * QPATCH;
+
+    // patch staging: slot tid + 512 j -> patch pixel (tid >> 3) + 64 j, LDS chunk tid & 7 (its source chunk is the swizzled one)
+    const int sch = tid & 7;
+    int a_src[6];                            // element offset inside the image, < 0 = zero line (padding / outside)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int prow = (tid >> 3) + 64 * j;
+        const int py = prow / QPW, px = prow - py * QPW;
+        const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+        const bool ok = prow < QPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        a_src[j] = ok ? (iy * p.W + ix) * p.Cin + ((sch ^ ((prow >> 1) & 7)) << 3) : -1;
+    }
+    // weight staging: row (tid >> 3) + 64 j of the 256 (all < N: N % 256 == 0), chunk tid & 7
+    const int srow = tid >> 3;
+    const bf16_t* b_base = Bp + (long long)(n0 + srow) * p.ldb + ((sch ^ ((srow >> 1) & 7)) << 3);
+    const long long b_step = 64ll * p.ldb;
+    auto issue_patch = [&](int c, int buf) {          // 6 LDS-DMA per thread
+        char* dst = patch0 + buf * QPATCH + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const void* src = a_src[j] >= 0 ? (const void*)(A + a_src[j] + c * CBK) : (const void*)zline;
+            glds16(src, dst + 8192 * j);
+        }
+    };
+    auto issue_b = [&](int t, int stage) {             // 4 LDS-DMA per thread
+        const int c = t / 9, tap = t - 9 * c;
+        const bf16_t* src = b_base + tap * p.Cin + c * CBK;
+        char* dst = bst0 + stage * QB_STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(src + j * b_step, dst + 8192 * j);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment geometry: A block i = tile row wm*4 + i, pixel lane & 31; B block j = channels wn*64 + 32 j + (lane & 31)
+    const int a_prow0 = (wm * 4) * QPW + (lane & 31);
+    const int b_row0 = wn * 64 + (lane & 31);
+    const int khalf = lane >> 5;
+
+    const int nchunk = p.Cin / CBK, nk = nchunk * 9;
+    issue_patch(0, 0);
+    issue_b(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        const int tm = t % 9;
+        // in flight behind B(t): only the next patch, when it was issued during step t-1 (tm == 5 now)
+        if (tm == 5 && t / 9 + 1 < nchunk) LXO_VMCNT(6);
+        else LXO_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nk) issue_b(t + 1, (t + 1) & 1);
+        if (tm == 4 && t / 9 + 1 < nchunk) issue_patch(t / 9 + 1, (t / 9 + 1) & 1);
+        const int c = t / 9, tap = t - 9 * c;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const char* ps = patch0 + (c & 1) * QPATCH;
+        const char* bs = bst0 + (t & 1) * QB_STAGE;
+        const int prow_t = a_prow0 + kh * QPW + kw;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = ks * 2 + khalf;
+            u32x4 af[4], bfr[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int br = b_row0 + 32 * j;
+                bfr[j] = *reinterpret_cast<const u32x4*>(bs + br * 128 + ((kc ^ ((br >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int prow = prow_t + i * QPW;
+                af[i] = *reinterpret_cast<const u32x4*>(ps + prow * 128 + ((kc ^ ((prow >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: the two 128-pixel halves go through LDS as f32 [128][256 + 4]; every thread then owns the
+    // 8 channels (tid & 31) * 8 .. +7 of rows (tid >> 5) + 16 it and applies the whole GemmNT epilogue in f32 with
+    // 16-byte global accesses.  tile pixel r -> output pixel (oy0 + r / 32, ox0 + r % 32).
+    bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(p.C);
+    bf16_t* __restrict__ Cpre = reinterpret_cast<bf16_t*>(p.out_pre);
+    const bf16_t* __restrict__ ref = reinterpret_cast<const bf16_t*>(p.relu_ref);
+    float* ot = reinterpret_cast<float*>(lxo_conv_lds);
+    constexpr int OP = QBN + 4;
+    const int c8 = (tid & 31) * 8, n = n0 + c8;
+    float bias8[8], csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias8[e] = p.bias ? p.bias[n + e] : 0.f; csum[e] = 0.f; }
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        ot[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf) * OP + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int row = (tid >> 5) + 16 * it;                       // 0..127 within the half
+            const int oy = oy0 + half * 4 + (row >> 5), ox = ox0 + (row & 31);
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            const long long m = ((long long)b * p.Ho + oy) * p.Wo + ox;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ot + row * OP + c8), v1 = *reinterpret_cast<const f32x4*>(ot + row * OP + c8 + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = p.alpha * (e < 4 ? v0[e] : v1[e - 4]) + bias8[e];
+                if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+                else if (p.act == 2) v[e] = tanhf(v[e]);
+            }
+            if (Cpre) store8(Cpre + m * p.ldc + n, v);
+            if (p.addend) {
+                const float* ad = p.addend + (m % p.addend_rows) * p.N + n;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ad), a1 = *reinterpret_cast<const f32x4*>(ad + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (e < 4 ? a0[e] : a1[e - 4]);
+            }
+            if (ref) {
+                float rv[8];
+                load8(ref + m * p.ldr + n, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+            if (p.accumulate) {
+                float cv[8];
+                load8(C + m * p.ldc + n, cv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += cv[e];
+            }
+            store8(C + m * p.ldc + n, v);
+        }
+    }
+    if (p.colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sres = csum[e] + __shfl_xor(csum[e], 32);
+            if (lane < 32) atomicAdd(&p.colsum[n + e], sres);
+        }
+    }
+}
+
 }  // namespace
 
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
     static int use_halo = -1;
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
+    static int use_256 = -1;
+    if (use_256 < 0) { const char* e = getenv("LXO_CONV_256"); use_256 = (e && e[0] == '0') ? 0 : 1; }
+    if (use_halo && use_256 && (p.N % QBN) == 0) {
+        static bool q_attr = false;
+        constexpr int LDSQ = 2 * QPATCH + 2 * QB_STAGE;
+        if (!q_attr) {
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSQ));
+            q_attr = true;
+        }
+        const int B = p.M / (p.Ho * p.Wo);
+        const int tiles_n = p.N / QBN, tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
+        hipLaunchKernelGGL(conv_halo256_kernel, dim3(B * tiles_x * tiles_y * tiles_n), dim3(CTH), LDSQ, s, p, tiles_n, tiles_x, tiles_y);
+        return (int)hipGetLastError();
+    }
     if (use_halo) {
         static bool halo_attr = false;
         constexpr int LDSB = 2 * HPATCH + 3 * HB_STAGE;

@@ -118,3 +118,36 @@ def test_conv3x3_fwd_and_wgrad_bf16(B, H, W, Cin, Cout, valid):
     torch.cuda.synchronize()
     errw = (dw.cpu() - refw).abs().max().item() / refw.abs().max().item()
     assert errw < 2e-5, errw
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pad", [(2, 16, 64, 256, 256, 1), (3, 14, 62, 128, 512, 2), (2, 9, 37, 64, 256, 0), (2, 12, 70, 128, 128, 1)])
+def test_conv3x3_ex_full_epilogue_bf16(B, H, W, Cin, Cout, pad):
+    """fused epilogue of the conv kernels (bias, ReLU, pre-addend copy, f32 addend, ReLU mask, column sums) on the
+    8x32x256 (Cout % 256 == 0) and 4x64x128 halo tiles; pad 2 = the dgrad geometry of the VALID layer."""
+    import torch.nn.functional as F
+    L = _lib()
+    g = torch.Generator().manual_seed(Cin + Cout + H + pad)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(3, 3, Cin, Cout, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(Cout, generator=g)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    addend = torch.randn(Ho * Wo, Cout, generator=g)
+    mask = torch.randn(B, Ho, Wo, Cout, generator=g).to(torch.bfloat16)
+    wpk = w.reshape(9 * Cin, Cout).t().contiguous()
+    out = torch.zeros(B, Ho, Wo, Cout, dtype=torch.bfloat16, device="cuda"); pre = torch.zeros_like(out)
+    cs = torch.zeros(Cout, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd, wd, bd, ad, md = x.cuda(), wpk.cuda(), bias.cuda(), addend.cuda(), mask.cuda()
+    rc = L.lxo_conv3x3_ex(1, _p(xd), _p(wd), _p(bd), _p(out), B, H, W, Cin, Ho, Wo, Cout, pad, 1, _p(ad), Ho * Wo, _p(pre), _p(md), _p(cs), st)
+    assert rc == 0, L.lxo_last_error()
+    torch.cuda.synchronize()
+    y = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2).double(), w.float().permute(3, 2, 0, 1).double(), bias.double(), padding=pad))
+    y = y.permute(0, 2, 3, 1)
+    rpre = y.clone()
+    y = (y.reshape(B, Ho * Wo, Cout) + addend.double()[None]).reshape(B, Ho, Wo, Cout)
+    y = torch.where(mask.double() > 0, y, torch.zeros_like(y))
+    s = y.abs().max().item()
+    assert (pre.float().cpu().double() - rpre).abs().max().item() / s < 6e-3
+    assert (out.float().cpu().double() - y).abs().max().item() / s < 6e-3
+    rcs = y.reshape(-1, Cout).sum(0)
+    assert (cs.cpu().double() - rcs).abs().max().item() / rcs.abs().max().item() < 2e-4

@@ -193,3 +193,49 @@ def test_beam_diversity_penalty_vs_oracle(gamma, prob):
     n = steps.value
     assert n == ids.shape[1]
     assert np.array_equal(bids[:, :n], ids.numpy()) and np.array_equal(bpar[:, :n], par.numpy())
+
+
+def _conv_ex_ref(x, w, bias, pad, relu, addend, mask):
+    """float64 reference of lxo_conv3x3_ex on bf16-rounded operands: returns (out_pre, out, colsum)."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    xp = np.zeros((B, H + 2 * pad, W + 2 * pad, Cin), np.float64)
+    xp[:, pad:pad + H, pad:pad + W] = x
+    y = np.zeros((B, Ho, Wo, Cout), np.float64)
+    for kh in range(3):
+        for kw in range(3):
+            y += xp[:, kh:kh + Ho, kw:kw + Wo] @ w[kh, kw].astype(np.float64)
+    y += bias
+    if relu:
+        y = np.maximum(y, 0)
+    pre = y.copy()
+    if addend is not None:
+        y = (y.reshape(B, -1, Cout) + addend[None]).reshape(B, Ho, Wo, Cout)
+    if mask is not None:
+        y = np.where(mask > 0, y, 0.0)
+    return pre, y, y.reshape(-1, Cout).sum(0)
+
+
+@pytest.mark.parametrize("Cout,H,W,pad", [(256, 9, 35, 1), (256, 10, 34, 0), (128, 6, 70, 1)])
+def test_conv3x3_ex_full_epilogue_bf16(Cout, H, W, pad):
+    """fused conv epilogue (bias, ReLU, pre-addend copy, timing-signal addend, ReLU mask, bias-gradient column sums)
+    on the 8x32x256 and 4x64x128 halo kernels."""
+    L = lib()
+    rng = np.random.RandomState(Cout + H)
+    B, Cin = 2, 64
+    rb = lambda a: bf16_to_f32(f32_to_bf16(a.astype(np.float32)))
+    x = rb(rng.randn(B, H, W, Cin)); w = rb(rng.randn(3, 3, Cin, Cout) * 0.05); bias = rng.randn(Cout).astype(np.float32)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    addend = rng.randn(Ho * Wo, Cout).astype(np.float32)
+    mask = rb(rng.randn(B, Ho, Wo, Cout))
+    xb, wb, mb = f32_to_bf16(x), f32_to_bf16(np.ascontiguousarray(w.reshape(9 * Cin, Cout).T)), f32_to_bf16(mask)
+    out = np.zeros((B, Ho, Wo, Cout), np.uint16); pre = np.zeros_like(out); cs = np.zeros(Cout, np.float32)
+    rc = L.lxo_conv3x3_ex(1, ptr(xb), ptr(wb), ptr(bias), ptr(out), B, H, W, Cin, Ho, Wo, Cout, pad, 1, ptr(addend), Ho * Wo,
+                          ptr(pre), ptr(mb), ptr(cs), None)
+    assert rc == 0, L.lxo_last_error()
+    rpre, rout, rcs = _conv_ex_ref(x, w, bias, pad, 1, addend, mask)
+    s = np.abs(rout).max()
+    assert np.abs(bf16_to_f32(pre) - rpre).max() / s < 6e-3
+    assert np.abs(bf16_to_f32(out) - rout).max() / s < 6e-3
+    assert np.abs(cs - rcs).max() / np.abs(rcs).max() < 2e-4
