@@ -575,10 +575,16 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
         }
     }
     if (p.colsum) {
+        // 16 thread rows hold partial sums of the same 8 channels: reduce through LDS, then ONE coalesced atomic per channel
+        __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float sres = csum[e] + __shfl_xor(csum[e], 32);
-            if (lane < 32) atomicAdd(&p.colsum[n + e], sres);
+        for (int e = 0; e < 8; ++e) ot[(tid >> 5) * OP + c8 + e] = csum[e];
+        __syncthreads();
+        if (tid < QBN) {
+            float sres = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sres += ot[r * OP + tid];
+            atomicAdd(&p.colsum[n0 + tid], sres);
         }
     }
 }

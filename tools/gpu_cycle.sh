@@ -14,4 +14,4 @@ cd /tmp && export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_prof.log 2>&1; echo "prof rc=$?")
 cd $R
 DB=$(ls gpurun_out/${TAG}_prof/*/*_results.db 2>/dev/null | head -1)
-if [ -n "$DB" ]; then python tools/prof_summary.py $DB gpurun_out/${TAG}_kernels.csv "$TAG"; head -14 gpurun_out/${TAG}_kernels.csv | cut -c1-150; python tools/prof_by_grid.py $DB > gpurun_out/${TAG}_bygrid.txt 2>&1; rm -rf gpurun_out/${TAG}_prof; fi
+if [ -n "$DB" ]; then python tools/prof_summary.py $DB gpurun_out/${TAG}_kernels.csv "$TAG"; head -14 gpurun_out/${TAG}_kernels.csv | cut -c1-150; python tools/prof_by_grid.py $DB > gpurun_out/${TAG}_bygrid.txt 2>&1; python tools/prof_seq.py $DB conv_ 120 > gpurun_out/${TAG}_convseq.txt 2>&1; rm -rf gpurun_out/${TAG}_prof; fi
