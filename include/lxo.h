@@ -161,6 +161,11 @@ int lxo_optimizer_step(int method, long long n, float* params, const float* grad
  * *steps_out = number of steps executed (<= max_iter + 1).  Host-synchronising. */
 int lxo_greedy_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                       int id_end, int max_iter, int32_t* ids_out, int* steps_out, void* stream);
+/* lxo_greedy_decode that also exports the attention weights of every step: alpha_out f32
+ * [max_steps][B][Rp] (device), Rp = (R+7)/8*8, row r = region (y*W' + x) -- the data the reference taps with
+ * its tf.py_func hook (attention_mechanism.py:96-105) for visualize_attention.py. */
+int lxo_greedy_decode_attn(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                           int id_end, int max_iter, int32_t* ids_out, float* alpha_out, int* steps_out, void* stream);
 /* dynamic_decode + BeamSearchDecoderCell (beam_search_decoder_cell.py:98-250),
  * reference-faithful finalize (parents not followed): ids_out int32 [B, max_steps, beam],
  * parents_out same shape (may be NULL). */

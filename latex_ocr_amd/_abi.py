@@ -49,6 +49,7 @@ def bind(lib):
         "lxo_adam_step": (c_int, [c_ll, c_void, c_void, c_void, c_void, c_float, c_float, c_float, c_float, c_void, c_void]),
         "lxo_optimizer_step": (c_int, [c_int, c_ll, c_void, c_void, c_void, c_float, c_void, c_void]),
         "lxo_greedy_decode": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, P(c_int), c_void]),
+        "lxo_greedy_decode_attn": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, P(c_int), c_void]),
         "lxo_beam_decode": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, P(c_int), c_void]),
     }
     missing = []
@@ -67,7 +68,7 @@ ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_gemm_nt", "lxo_gemm_tn", "
                 "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
                 "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_set_side_stream", "lxo_decoder_train_fwd",
                 "lxo_ce_loss_fwd_bwd", "lxo_decoder_train_bwd", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",
-                "lxo_greedy_decode", "lxo_beam_decode"]
+                "lxo_greedy_decode", "lxo_greedy_decode_attn", "lxo_beam_decode"]
 
 _lib = None
 

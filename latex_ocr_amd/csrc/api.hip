@@ -112,7 +112,13 @@ extern "C" int lxo_adam_step(long long n, float* params, const float* grads, flo
 extern "C" int lxo_greedy_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                                  int id_end, int max_iter, int32_t* ids_out, int* steps_out, void* stream) {
     MAKE_PLAN(P, s);
-    CHECK_LAUNCH(lxo_impl_greedy_decode(P, params, wpack, ws, id_end, max_iter, ids_out, steps_out, (hipStream_t)stream), "lxo_greedy_decode");
+    CHECK_LAUNCH(lxo_impl_greedy_decode(P, params, wpack, ws, id_end, max_iter, ids_out, nullptr, steps_out, (hipStream_t)stream), "lxo_greedy_decode");
+    return 0;
+}
+extern "C" int lxo_greedy_decode_attn(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                      int id_end, int max_iter, int32_t* ids_out, float* alpha_out, int* steps_out, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_greedy_decode(P, params, wpack, ws, id_end, max_iter, ids_out, alpha_out, steps_out, (hipStream_t)stream), "lxo_greedy_decode_attn");
     return 0;
 }
 extern "C" int lxo_beam_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,

@@ -272,7 +272,7 @@ static int decode_common_step(const Plan& P, const float* prm, const void* wp, v
 }
 
 int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter,
-                           int* ids_out, int* steps_out, hipStream_t st) {
+                           int* ids_out, float* alpha_out, int* steps_out, hipStream_t st) {
     const int B = P.s.B, ms = P.s.max_steps;
     if (ms < max_iter + 1) return -5;
     RC(attention_prepare(P, prm, wp, ws, 1, st));
@@ -292,6 +292,8 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
             const int time = steps + c;
             const int cur = (time + 1) & 1;
             RC(decode_common_step(P, prm, wp, ws, B, 1, cur, time == 0 ? nullptr : ids_step, st));
+            if (alpha_out)      // attention weights of this step (what attention_mechanism.py:96-105 hands to its py_func hook)
+                HIPRC(hipMemcpyAsync(alpha_out + (size_t)time * B * P.Rp, P.ws<float>(ws, W_ALPHA), (size_t)B * P.Rp * 4, hipMemcpyDeviceToDevice, st));
             RC(lxo_k_argmax(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, id_end, ids_step, ids_out, ms, time, finished, flags + c, st));
             ++issued;
         }

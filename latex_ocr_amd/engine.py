@@ -335,16 +335,29 @@ class Engine(object):
                  "encoder_fwd")
         return B
 
-    def greedy_decode(self, img, id_end, max_iter=151):
-        """ids int32 [B, T'] as pred_test.ids of the greedy graph (decoder.py:64,70)."""
+    def greedy_decode(self, img, id_end, max_iter=151, return_attention=False):
+        """ids int32 [B, T'] as pred_test.ids of the greedy graph (decoder.py:64,70).  With return_attention also the
+        attention maps alpha f32 [B, T', H', W'] (what the reference collects through its py_func hook,
+        attention_mechanism.py:96-105, for visualize_attention.py)."""
         if self.max_steps < max_iter + 1:
             self.max_steps, self.ws = max_iter + 1, None
         B = self._encode_only(img, 1)
         ids = torch.zeros(B, self.max_steps, dtype=torch.int32, device=self.device)
         steps = ctypes.c_int(0)
-        self._ck(self.lib.lxo_greedy_decode(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(max_iter),
-                                            _p(ids), ctypes.byref(steps), self._stream()), "greedy_decode")
-        return ids[:, :steps.value].cpu().numpy()
+        if not return_attention:
+            self._ck(self.lib.lxo_greedy_decode(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(max_iter),
+                                                _p(ids), ctypes.byref(steps), self._stream()), "greedy_decode")
+            return ids[:, :steps.value].cpu().numpy()
+        from .model.utils.image import encoder_out_hw
+        Hp, Wp = encoder_out_hw(int(img.shape[1]), int(img.shape[2]))
+        R = Hp * Wp
+        Rp = (R + 7) // 8 * 8
+        alpha = torch.zeros(self.max_steps, B, Rp, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.lxo_greedy_decode_attn(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(max_iter),
+                                                 _p(ids), _p(alpha), ctypes.byref(steps), self._stream()), "greedy_decode_attn")
+        n = steps.value
+        a = alpha[:n, :, :R].permute(1, 0, 2).reshape(B, n, Hp, Wp).cpu().numpy()
+        return ids[:, :n].cpu().numpy(), a
 
     def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False, div_gamma=1.0, div_prob=0.0, div_seed=0):
         """ids int32 [B, T', k] as pred_test.ids of the beam graph before the transpose at img2seq.py:241.

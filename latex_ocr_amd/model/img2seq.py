@@ -101,9 +101,12 @@ class Img2SeqModel(BaseModel):
         max_iter = getattr(cfg, "max_length_formula", 150) + 1          # decoder.py:70
         if getattr(cfg, "decoding", "greedy") == "beam_search":
             self._div_calls = getattr(self, "_div_calls", 0) + 1
-            ids = self.engine.beam_decode(img, self._vocab.id_end, cfg.beam_size, max_iter=max_iter,
-                                          div_gamma=getattr(cfg, "div_gamma", 1), div_prob=getattr(cfg, "div_prob", 0),
-                                          div_seed=self._div_calls)              # decoder.py:67-68
+            ids, par = self.engine.beam_decode(img, self._vocab.id_end, cfg.beam_size, max_iter=max_iter, return_parents=True,
+                                               div_gamma=getattr(cfg, "div_gamma", 1), div_prob=getattr(cfg, "div_prob", 0),
+                                               div_seed=self._div_calls)         # decoder.py:67-68
+            if getattr(cfg, "beam_backtrace", False):      # extension: follow parents (the reference never does, quirk C-1)
+                from .utils.text import beam_backtrace
+                ids = beam_backtrace(ids, par)
             return np.transpose(ids, [0, 2, 1])
         ids = self.engine.greedy_decode(img, self._vocab.id_end, max_iter=max_iter)
         return np.expand_dims(ids, axis=1)
@@ -141,3 +144,12 @@ class Img2SeqModel(BaseModel):
     def predict(self, img):
         """Reference: model/img2seq.py:278-285."""
         return [hyp[0] for hyp in self.predict_batch([img])]
+
+    def predict_with_attention(self, img):
+        """Greedy hypothesis of one image plus its per-token attention maps [T', H', W'] -- the data the reference
+        gathers in the global `ctx_vector` through tf.py_func (attention_mechanism.py:96-105) for visualize_attention.py."""
+        fd = self._get_feed_dict([img], dropout=1)
+        max_iter = getattr(self._config, "max_length_formula", 150) + 1
+        ids, alpha = self.engine.greedy_decode(fd["img"], self._vocab.id_end, max_iter=max_iter, return_attention=True)
+        p = truncate_end(ids[0], self._vocab.id_end)
+        return " ".join(self._vocab.id_to_tok[int(i)] for i in p), alpha[0]

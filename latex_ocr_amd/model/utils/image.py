@@ -34,3 +34,10 @@ def greyscale(state):
 def downsample(state):
     """Every second pixel on the first two axes (reference: image.py:74-81)."""
     return state[::2, ::2, :]
+
+
+def encoder_out_hw(H, W):
+    """(H', W') of the encoder feature map for an H x W input: three /2 (SAME, ceil) reductions per axis and the
+    VALID 3x3 conv (model/encoder.py:37-59; the same arithmetic as visualize_attention.py:22-31 getWH)."""
+    c = lambda n: -(-n // 2)
+    return c(c(c(H))) - 2, c(c(c(W))) - 2

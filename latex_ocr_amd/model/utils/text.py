@@ -92,3 +92,20 @@ def load_formulas(filename):
     """dict line-index -> stripped line (reference: text.py:167-174)."""
     with open(filename) as f:
         return {i: line.strip() for i, line in enumerate(f)}
+
+
+def beam_backtrace(ids, parents):
+    """Follow the beam-search parent pointers: ids, parents int [B, T, k] as lxo_beam_decode returns them ->
+    hypotheses int [B, T, k] where out[b, :, i] is the token path that ENDS in beam slot i at the last step.
+    The reference's BeamSearchDecoderCell.finalize (beam_search_decoder_cell.py:190-250) never does this (it
+    returns ids[:, t, i] per step); this is the optional corrected read-out."""
+    import numpy as np
+    ids, parents = np.asarray(ids), np.asarray(parents)
+    B, T, k = ids.shape
+    out = np.empty_like(ids)
+    slot = np.tile(np.arange(k)[None, :], (B, 1))
+    rows = np.arange(B)[:, None]
+    for t in range(T - 1, -1, -1):
+        out[:, t, :] = ids[rows, t, slot]
+        slot = parents[rows, t, slot]
+    return out

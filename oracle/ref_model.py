@@ -306,7 +306,7 @@ def train_step(P, opt, img_u8, formula, lengths, lr, clip=-1.0, positional=True,
 
 
 @torch.no_grad()
-def greedy_decode(P, img_u8, id_end, max_iter=151, positional=True, return_logits=False):
+def greedy_decode(P, img_u8, id_end, max_iter=151, positional=True, return_logits=False, return_alpha=False):
     """dynamic_decode.py:34-73 + greedy_decoder_cell.py:40-66.  Loop while not
     all finished; after the step at `time`, finished |= time >= max_iter, so at
     most max_iter+1 steps.  Finished rows keep stepping.  argmax ties -> lowest
@@ -317,10 +317,11 @@ def greedy_decode(P, img_u8, id_end, max_iter=151, positional=True, return_logit
     tab = P["Decoder/embedding_table"]
     emb = P["Decoder/start_token"].reshape(1, -1).expand(B, -1)
     finished = torch.zeros(B, dtype=torch.bool)
-    ids_all, logits_all = [], []
+    ids_all, logits_all, alpha_all = [], [], []
     time = 0
     while not bool(finished.all()):
-        logits, state = cell_step(P, img, att_img, emb, state)
+        logits, state, alpha = cell_step(P, img, att_img, emb, state, return_alpha=True)
+        alpha_all.append(alpha)                                  # attention_mechanism.py:96-105 py_func tap
         ids = torch.argmax(logits, dim=-1)
         emb = tab[ids]
         finished = finished | (ids == id_end)
@@ -330,6 +331,8 @@ def greedy_decode(P, img_u8, id_end, max_iter=151, positional=True, return_logit
             finished = torch.ones_like(finished)
         time += 1
     ids = torch.stack(ids_all, dim=1)
+    if return_alpha:
+        return ids, torch.stack(alpha_all, dim=1)                # [B, T', R]
     if return_logits:
         return ids, torch.stack(logits_all, dim=1)
     return ids

@@ -142,3 +142,18 @@ def test_beam_diversity_penalty_f32(gamma, prob):
     assert np.array_equal(ids, rid.numpy()) and np.array_equal(par, rpar.numpy())
     ids0 = eng.beam_decode(img, V - 1, 3, max_iter=12)
     assert ids0.shape != ids.shape or not np.array_equal(ids0, ids)
+
+
+def test_greedy_attention_export_f32():
+    # lxo_greedy_decode_attn: the per-step attention weights the reference taps with tf.py_func for visualize_attention.py
+    V = 50
+    imgs, _ = synthetic.config1()
+    img = pad_batch_images(imgs[:6])
+    eng = Engine(V, dtype="f32", seed=4)
+    ids, alpha = eng.greedy_decode(img, V - 1, max_iter=10, return_attention=True)
+    rid, ralpha = R.greedy_decode(oracle_params(eng), torch.from_numpy(img), V - 1, max_iter=10, return_alpha=True)
+    assert np.array_equal(ids, rid.numpy())
+    B, T = ids.shape
+    assert alpha.shape[:2] == (B, T)
+    assert np.abs(alpha.reshape(B, T, -1) - ralpha.numpy()).max() < 1e-6
+    assert np.abs(alpha.reshape(B, T, -1).sum(-1) - 1).max() < 1e-5

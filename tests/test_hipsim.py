@@ -239,3 +239,20 @@ def test_conv3x3_ex_full_epilogue_bf16(Cout, H, W, pad):
     assert np.abs(bf16_to_f32(pre) - rpre).max() / s < 6e-3
     assert np.abs(bf16_to_f32(out) - rout).max() / s < 6e-3
     assert np.abs(cs - rcs).max() / np.abs(rcs).max() < 2e-4
+
+
+def test_greedy_attention_export_vs_oracle():
+    """lxo_greedy_decode_attn: per-step attention weights (the reference's py_func tap, attention_mechanism.py:96-105)."""
+    import torch
+    from oracle import ref_model as R
+    img = GOLD["img"]
+    S = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, max_steps=9)
+    S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+    ids = np.zeros((2, 9), np.int32); steps = ctypes.c_int(0)
+    alpha = np.zeros((9, 2, 8), np.float32)                      # R = 2 x 4 regions, Rp = 8
+    S.ck(S.L.lxo_greedy_decode_attn(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), 10, 8, ptr(ids), ptr(alpha), ctypes.byref(steps), None), "greedy")
+    P = {k: torch.from_numpy(np.asarray(v)) for k, v in S.P.items()}
+    rid, ralpha = R.greedy_decode(P, torch.from_numpy(img), 10, max_iter=8, return_alpha=True)
+    n = steps.value
+    assert np.array_equal(ids[:, :n], rid.numpy())
+    assert np.abs(alpha[:n].transpose(1, 0, 2) - ralpha.numpy()).max() < 1e-6
