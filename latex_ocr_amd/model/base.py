@@ -86,6 +86,8 @@ class BaseModel(object):
     def save_session(self, epoch):
         """Reference: model/base.py:61-69 (Saver(max_to_keep=1): older checkpoints are removed;
         Adam slots are saved, LR-schedule state and best_score are not)."""
+        if getattr(self, "dist", None) is not None and self.dist.rank != 0:
+            return                                    # data parallel: parameters are replicated, rank 0 writes
         dir_model = self._dir_model()
         init_dir(dir_model)
         self.logger.info("- Saving model...")

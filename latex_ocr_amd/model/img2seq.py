@@ -20,6 +20,12 @@ class Img2SeqModel(BaseModel):
         """Reference: model/img2seq.py:23-32."""
         super(Img2SeqModel, self).__init__(config, dir_output)
         self._vocab = vocab
+        self.dist = None            # latex_ocr_amd.dist.DataParallel when launched one process per GPU (attach_dist)
+
+    def attach_dist(self, dist):
+        """Data-parallel training: every rank builds the same model, trains on its share of each
+        shape bucket and all-reduces gradients; evaluation / checkpoints are written by rank 0 only."""
+        self.dist = dist
 
     # ------------------------------------------------------------------ build --
     def _build_engine(self):
@@ -70,18 +76,38 @@ class Img2SeqModel(BaseModel):
 
     # ------------------------------------------------------------------ train --
     def _run_train(self, config, train_set, val_set, epoch, lr_schedule):
-        """Reference: model/img2seq.py:144-196."""
+        """Reference: model/img2seq.py:144-196.  The feed runs on the background input pipeline (pipeline.py:
+        pinned staging + copy stream, `prefetch_depth` batches ahead; config.prefetch_depth = 0 restores the
+        reference's synchronous feed); under data parallelism every rank takes its slice of each shape bucket."""
+        from ..pipeline import Prefetcher, ShardedBuckets
         batch_size = config.batch_size
-        nbatches = (len(train_set) + batch_size - 1) // batch_size
+        world = self.dist.world if self.dist is not None else 1
+        rank = self.dist.rank if self.dist is not None else 0
+        nbatches = (len(train_set) + batch_size * world - 1) // (batch_size * world)
         prog = Progbar(nbatches)
-        for i, (img, formula) in enumerate(minibatches(train_set, batch_size)):
-            fd = self._get_feed_dict(img, formula=formula, lr=lr_schedule.lr, dropout=config.dropout)
-            loss_eval = self.engine.train_step(fd["img"], fd["formula"], fd["formula_length"], fd["lr"], clip=self._clip,
-                                               dropout=fd["dropout"])
+        keep = getattr(config, "dropout", 1)
+        if not keep > 0:
+            raise ValueError("dropout is a keep probability and must be > 0, got {}".format(keep))
+        depth = int(getattr(config, "prefetch_depth", 2))
+        batches = ShardedBuckets(train_set, batch_size, world, rank) if world > 1 else None
+        if depth > 0:
+            feed = Prefetcher(train_set, batch_size, self._vocab.id_pad, self._vocab.id_end, device=self.engine.device,
+                              depth=depth, batches=batches)
+            it = ((b.img, b.formula, b.lengths) for b in feed)
+        else:
+            def sync_feed():
+                for img, formula in (batches if batches is not None else minibatches(train_set, batch_size)):
+                    fd = self._get_feed_dict(img, formula=formula)
+                    yield fd["img"], fd["formula"], fd["formula_length"]
+            it = sync_feed()
+        for i, (img, formula, lengths) in enumerate(it):
+            loss_eval = self.engine.train_step(img, formula, lengths, lr_schedule.lr, clip=self._clip, dist=self.dist,
+                                               dropout=keep)
             prog.update(i + 1, [("loss", loss_eval), ("perplexity", np.exp(loss_eval)), ("lr", lr_schedule.lr)])
             lr_schedule.update(batch_no=epoch * nbatches + i)
         self.logger.info("- Training: {}".format(prog.info))
-        config_eval = Config({"dir_answers": self._dir_output + "formulas_val/", "batch_size": config.batch_size})
+        sub = "formulas_val/" if rank == 0 else "formulas_val_rank%d/" % rank    # every rank scores (keeps LR schedules equal)
+        config_eval = Config({"dir_answers": self._dir_output + sub, "batch_size": config.batch_size})
         scores = self.evaluate(config_eval, val_set)
         score = scores["perplexity"]
         lr_schedule.update(score=score)

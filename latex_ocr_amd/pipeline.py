@@ -1,0 +1,136 @@
+"""Input pipeline of the training step.
+
+The reference feeds its graph synchronously: `minibatches` (model/utils/general.py:15-35) yields Python lists, the
+step pads them (`pad_batch_images` utils/image.py:46-62, `pad_batch_formulas` utils/text.py:116-139) and
+`sess.run` copies them in, all on the training thread (img2seq.py:160-167).  Here the same host functions run on a
+background thread into PINNED staging buffers and cross PCIe on a dedicated copy stream, `depth` batches ahead of
+the compute stream; the step receives device tensors plus host-side lengths (so it never synchronises to count
+tokens).  `ShardedBuckets` gives every data-parallel rank batches of ONE image shape per step (equal shapes on all
+ranks, the reference's `bucket` grouping of data_generator.py:84-122 lifted to the global batch).
+"""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from .model.utils.general import minibatches
+from .model.utils.image import pad_batch_images
+from .model.utils.text import pad_batch_formulas
+
+
+class Batch(object):
+    """One staged batch: img u8 [B,H,W,1] and formula i32 [B,T] on the device, lengths (numpy, host)."""
+
+    def wait(self, stream=None):
+        """Make `stream` (default: the current stream) wait for this batch's host-to-device copies."""
+        if self.ready is not None:
+            (stream or torch.cuda.current_stream(self.img.device)).wait_event(self.ready)
+        return self
+
+
+class Prefetcher(object):
+    """Iterate over `dataset` in minibatches of `batch_size`, padding + uploading `depth` batches ahead."""
+
+    def __init__(self, dataset, batch_size, id_pad, id_end, device="cuda:0", depth=2, batches=None):
+        self.dataset, self.batch_size, self.id_pad, self.id_end = dataset, batch_size, id_pad, id_end
+        self.device = torch.device(device)
+        self.depth = max(1, int(depth))
+        self.batches = batches                      # optional iterable of (imgs, formulas) lists (e.g. ShardedBuckets)
+        self.cuda = self.device.type == "cuda"
+        self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+
+    def _source(self):
+        return self.batches if self.batches is not None else minibatches(self.dataset, self.batch_size)
+
+    def _stage(self, imgs, forms):
+        img = torch.from_numpy(pad_batch_images(imgs))
+        f, l = pad_batch_formulas(forms, self.id_pad, self.id_end)
+        f = torch.from_numpy(np.ascontiguousarray(f, dtype=np.int32))
+        b = Batch()
+        b.lengths, b.n_tokens, b.size, b.ready = np.asarray(l), int(np.sum(l)), len(imgs), None
+        if self.cuda:
+            img, f = img.pin_memory(), f.pin_memory()
+            with torch.cuda.stream(self.copy_stream):
+                b.img = img.to(self.device, non_blocking=True)
+                b.formula = f.to(self.device, non_blocking=True)
+                b.ready = torch.cuda.Event()
+                b.ready.record(self.copy_stream)
+            self._pinned.append((img, f, b.ready))   # the pinned sources must outlive their asynchronous copies
+            while len(self._pinned) > self.depth + 2:
+                self._pinned.pop(0)[2].synchronize()
+        else:
+            b.img, b.formula = img, f
+        return b
+
+    def __iter__(self):
+        q = queue.Queue(maxsize=self.depth)
+        self._pinned = []
+        stop = threading.Event()
+        END = object()
+
+        def work():
+            try:
+                if self.cuda:
+                    torch.cuda.set_device(self.device)
+                for imgs, forms in self._source():
+                    if stop.is_set():
+                        return
+                    q.put(self._stage(imgs, forms))
+                q.put(END)
+            except BaseException as e:              # surface loader errors on the training thread
+                q.put(e)
+
+        th = threading.Thread(target=work, name="lxo-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is END:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item.wait() if self.cuda else item
+        finally:
+            stop.set()
+            while th.is_alive():                    # unblock a producer stuck on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+
+
+class ShardedBuckets(object):
+    """Shape-bucketed batches for `world` data-parallel ranks.
+
+    Examples are grouped by image shape (first-seen order, like DataGenerator.bucket, data_generator.py:84-122);
+    every group is cut into GLOBAL batches of world * batch_size examples and rank r takes the r-th slice, so at
+    each step all ranks run the same (H, W) and -- except for the ragged tail of a bucket -- the same batch size.
+    A tail smaller than `world` examples is dropped on every rank (a rank with no data would desynchronise the
+    collectives); `dropped` counts them."""
+
+    def __init__(self, dataset, batch_size, world=1, rank=0):
+        self.dataset, self.batch_size, self.world, self.rank = dataset, int(batch_size), int(world), int(rank)
+        self.dropped = 0
+
+    def __iter__(self):
+        groups, order = {}, []
+        for img, form in self.dataset:
+            key = tuple(np.asarray(img).shape)
+            if key not in groups:
+                groups[key] = []
+                order.append(key)
+            groups[key].append((img, form))
+        self.dropped = 0
+        gb = self.batch_size * self.world
+        for key in order:
+            items = groups[key]
+            for i in range(0, len(items), gb):
+                chunk = items[i:i + gb]
+                if len(chunk) < self.world:
+                    self.dropped += len(chunk)
+                    continue
+                base, rem = divmod(len(chunk), self.world)          # balanced: the first `rem` ranks take one more
+                lo = self.rank * base + min(self.rank, rem)
+                mine = chunk[lo:lo + base + (1 if self.rank < rem else 0)]
+                yield [m[0] for m in mine], [m[1] for m in mine]

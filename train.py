@@ -37,9 +37,34 @@ def main(argv=None):
     lr_schedule = LRSchedule(lr_init=config.lr_init, start_decay=config.start_decay * n_batches_epoch,
                              end_decay=config.end_decay * n_batches_epoch, end_warm=config.end_warm * n_batches_epoch,
                              lr_warm=config.lr_warm, lr_min=config.lr_min)
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:        # one process per GPU: python -m torch.distributed.run --nproc-per-node N train.py ...
+        import torch
+        import torch.distributed as td
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(local)
+            config.device = "cuda:%d" % local
+        td.init_process_group(backend="nccl" if use_gpu else "gloo")
+        from latex_ocr_amd.dist import DataParallel
+        dist = DataParallel(device=config.device if use_gpu else "cpu")
+        n_batches_epoch = (len(train_set) + config.batch_size * world - 1) // (config.batch_size * world)
+        lr_schedule = LRSchedule(lr_init=config.lr_init, start_decay=config.start_decay * n_batches_epoch,
+                                 end_decay=config.end_decay * n_batches_epoch, end_warm=config.end_warm * n_batches_epoch,
+                                 lr_warm=config.lr_warm, lr_min=config.lr_min)
     model = Img2SeqModel(config, a.output, vocab)
     model.build_train(config)
-    return model.train(config, train_set, val_set, lr_schedule)
+    if dist is not None:
+        model.attach_dist(dist)
+    best = model.train(config, train_set, val_set, lr_schedule)
+    if dist is not None:
+        dist.barrier()
+        td.destroy_process_group()
+    return best
 
 
 if __name__ == "__main__":
