@@ -44,7 +44,7 @@ class BaseModel(object):
                 if line.startswith("model_checkpoint_path:"):
                     name = line.split(":", 1)[1].strip().strip('"')
                     path = name if os.path.isabs(name) else os.path.join(dir_model, name)
-                    return path if os.path.exists(path) else None
+                    return path if (os.path.exists(path) or os.path.exists(path + ".index")) else None
         return None
 
     def init_session(self):
@@ -70,18 +70,43 @@ class BaseModel(object):
             path = self.latest_checkpoint(path if path.endswith("/") else path + "/")
             if path is None:
                 raise IOError("no checkpoint in directory")
-        with np.load(path, allow_pickle=False) as z:
-            names = [k for k, _, _ in self.engine.specs]
-            sd = {"params": {k: z[k] for k in names}}
+        z = self._open_checkpoint(path)
+        names = [k for k, _, _ in self.engine.specs]
+        missing = [k for k in names if k not in z]
+        if missing:
+            raise KeyError("checkpoint %s lacks variables: %s" % (path, ", ".join(missing[:4])))
+        sd = {"params": {k: np.asarray(z[k], np.float32) for k in names}}
+        have_slots = all(("optimize/" + k + "/Adam") in z and ("optimize/" + k + "/Adam_1") in z for k in names)
+        if have_slots and ("optimize/adam_t" in z or "optimize/beta1_power" in z):
+            off, m, v = 0, np.zeros(self.engine.n_params, np.float32), np.zeros(self.engine.n_params, np.float32)
+            for k, shp, _ in self.engine.specs:
+                n = int(np.prod(shp))
+                m[off:off + n] = np.asarray(z["optimize/" + k + "/Adam"]).reshape(-1)
+                v[off:off + n] = np.asarray(z["optimize/" + k + "/Adam_1"]).reshape(-1)
+                off += n
             if "optimize/adam_t" in z:
-                off, m, v = 0, np.zeros(self.engine.n_params, np.float32), np.zeros(self.engine.n_params, np.float32)
-                for k, shp, _ in self.engine.specs:
-                    n = int(np.prod(shp))
-                    m[off:off + n] = z["optimize/" + k + "/Adam"].reshape(-1)
-                    v[off:off + n] = z["optimize/" + k + "/Adam_1"].reshape(-1)
-                    off += n
-                sd.update(adam_m=m, adam_v=v, adam_t=int(z["optimize/adam_t"]))
+                t = int(np.asarray(z["optimize/adam_t"]).reshape(-1)[0])
+            else:       # tf.train.AdamOptimizer keeps beta1^t in `beta1_power` (default beta1 = 0.9)
+                t = int(round(np.log(float(np.asarray(z["optimize/beta1_power"]).reshape(-1)[0])) / np.log(0.9)))
+            sd.update(adam_m=m, adam_v=v, adam_t=t)
+        self._lr_state = {k[len("lxo/lr_schedule/"):]: z[k] for k in z if k.startswith("lxo/lr_schedule/")}
         self.engine.load_state_dict(sd)
+
+    @staticmethod
+    def _open_checkpoint(path):
+        """{name: array} of a checkpoint in any of the three containers: this framework's npz file (the default,
+        written at the reference's path), safetensors, or a TensorFlow Saver bundle (`<path>.index` +
+        `<path>.data-*`, what the reference's model/base.py:61-69 writes) read by latex_ocr_amd/tf_checkpoint.py."""
+        if path.endswith(".index"):
+            path = path[:-len(".index")]
+        if os.path.exists(path + ".index") and not os.path.isfile(path):
+            from ..tf_checkpoint import read_bundle
+            return read_bundle(path)
+        if path.endswith(".safetensors"):
+            from safetensors.numpy import load_file
+            return load_file(path)
+        with np.load(path, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
 
     def save_session(self, epoch):
         """Reference: model/base.py:61-69 (Saver(max_to_keep=1): older checkpoints are removed;
@@ -100,6 +125,10 @@ class BaseModel(object):
             arrays["optimize/" + k + "/Adam_1"] = sd["adam_v"][off:off + n].reshape(shp)
             off += n
         arrays["optimize/adam_t"] = np.int64(sd["adam_t"])
+        sched = getattr(self, "_lr_schedule", None)
+        if sched is not None:       # extension: the reference loses the schedule on resume
+            for k, v in sched.state_dict().items():
+                arrays["lxo/lr_schedule/" + k] = np.float64(v)
         name = "model.cpkt-%d" % epoch
         with open(dir_model + name, "wb") as f:
             np.savez(f, **arrays)
@@ -115,6 +144,10 @@ class BaseModel(object):
         """Reference: model/base.py:95-138.  Epochs below `startepoch` are skipped; the model is
         saved when the epoch score is >= the best so far; early stop on lr_schedule."""
         best_score = None
+        self._lr_schedule = lr_schedule
+        if getattr(self, "_lr_state", None) and getattr(config, "resume_lr_schedule", True):
+            lr_schedule.load_state_dict(self._lr_state)
+            self.logger.info("- restored the learning-rate schedule (lr {:.6g})".format(lr_schedule.lr))
         for epoch in range(config.n_epochs):
             if epoch < self.startepoch:
                 continue

@@ -32,6 +32,17 @@ class LRSchedule(object):
             self._exp_decay = np.power(lr_min / lr_init,
                                        1 / float(end_decay - self._start_decay))
 
+    def state_dict(self):
+        """Mutable state (not in the reference, whose Saver never stores it): lr, last score, no-improvement count."""
+        return {"lr": float(self.lr), "score": float("nan") if self._score is None else float(self._score),
+                "n_batch_no_imprv": float(self._n_batch_no_imprv)}
+
+    def load_state_dict(self, sd):
+        self.lr = float(sd["lr"])
+        sc = float(sd["score"])
+        self._score = None if sc != sc else sc
+        self._n_batch_no_imprv = int(float(sd["n_batch_no_imprv"]))
+
     @property
     def stop_training(self):
         return (self._early_stopping is not None

@@ -36,6 +36,32 @@ def test_train_eval_predict(tmp_path, monkeypatch):
     assert os.path.exists("results/small/formulas_test/hyp_1.txt")  # beam_size 2 -> two hypothesis files
     # perplexity after the restore equals what training saw for that checkpoint's weights (same data? no: test set) -> finite
     assert np.isfinite(scores["perplexity"])
+    # the same weights through a tf.train.Saver bundle (the reference's container): predictions and attention identical
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import convert_checkpoint as CC
+    from latex_ocr_amd.model.img2seq import Img2SeqModel
+    from latex_ocr_amd.model.utils.general import Config
+    from latex_ocr_amd.model.utils.image import greyscale
+    from latex_ocr_amd.model.utils.text import Vocab
+    from PIL import Image
+    os.makedirs("results/tf/model_weights")
+    for n in ("model.json", "vocab.json"):
+        shutil.copy("results/small/" + n, "results/tf/" + n)
+    CC.main([wdir + ck[0], "results/tf/model_weights/" + ck[0], "--to", "tf"])
+    open("results/tf/model_weights/checkpoint", "w").write('model_checkpoint_path: "%s"\n' % ck[0])
+    img_path = sorted(p for p in os.listdir("data/synthetic/test") if p.endswith(".png"))[0]
+    img = greyscale(np.asarray(Image.open("data/synthetic/test/" + img_path).convert("RGB")))
+    hyps = []
+    for d in ("results/small/", "results/tf/"):
+        m = Img2SeqModel(Config(d + "model.json"), d, Vocab(Config(d + "vocab.json")))
+        m.build_pred()
+        hyps.append((m.predict(img), m.predict_with_attention(img)))
+    assert hyps[0][0] == hyps[1][0] and hyps[0][1][0] == hyps[1][1][0]
+    assert np.array_equal(hyps[0][1][1], hyps[1][1][1])
+    import visualize_attention as VA
+    hyp, files = VA.vis_img_with_attention(m, "data/synthetic/test/" + img_path, "results/tf/")
+    assert all(os.path.exists(f) for f in files)
 
 
 def test_single_rank_rccl_path():
