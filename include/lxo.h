@@ -93,12 +93,20 @@ typedef struct lxo_shape {
      * div_gamma 0 or 1, or div_prob 0, disables; div_seed keys the Bernoulli(div_prob) draws */
     float div_gamma, div_prob;
     int div_seed;
+    /* encoder variants of configs/model.json: encoder_cnn 0 = "vanilla" (pools after conv4 / conv5,
+     * encoder.py:46-52), 1 = "cnn" (no pools, a (2,4) stride-2 SAME conv after conv5, encoder.py:54-56);
+     * no_positional != 0 = positional_embeddings false (encoder.py:60-65 skipped) */
+    int encoder_cnn;
+    int no_positional;
 } lxo_shape;
 
 /* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF
  * checkpoint order.  id in [0, lxo_param_num()). */
 int lxo_param_num(void);
 const char* lxo_param_name(int id);
+/* the TF variable name of slot id for this shape's encoder variant (the tf.layers.conv2d scopes are numbered in
+ * creation order, so "cnn" renames the last two convs); slots with count 0 in lxo_param_info are absent */
+const char* lxo_param_name_for(const lxo_shape* s, int id);
 long long lxo_param_total(const lxo_shape* s);
 int lxo_param_info(const lxo_shape* s, int id, long long* offset, long long* count);
 

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")
 
 class LxoShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("B", "H", "W", "T", "V", "C", "E", "U", "O", "D", "dtype", "beam", "max_steps")] + \
-               [("keep_prob", c_float), ("dropout_seed", c_int), ("div_gamma", c_float), ("div_prob", c_float), ("div_seed", c_int)]
+               [("keep_prob", c_float), ("dropout_seed", c_int), ("div_gamma", c_float), ("div_prob", c_float), ("div_seed", c_int),
+                ("encoder_cnn", c_int), ("no_positional", c_int)]
 
 
 def bind(lib):
@@ -33,6 +34,7 @@ def bind(lib):
         "lxo_attention_fwd": (c_int, [c_int] + [c_void] * 7 + [c_int] * 6 + [c_void]),
         "lxo_param_num": (c_int, []),
         "lxo_param_name": (ctypes.c_char_p, [c_int]),
+        "lxo_param_name_for": (ctypes.c_char_p, [S, c_int]),
         "lxo_param_total": (c_ll, [S]),
         "lxo_param_info": (c_int, [S, c_int, P(c_ll), P(c_ll)]),
         "lxo_wpack_bytes": (c_size, [S]),
@@ -64,7 +66,7 @@ def bind(lib):
     return lib
 
 
-ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name",
+ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name", "lxo_param_name_for",
                 "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
                 "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_set_side_stream", "lxo_decoder_train_fwd",
                 "lxo_ce_loss_fwd_bwd", "lxo_decoder_train_bwd", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",

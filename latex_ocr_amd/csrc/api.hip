@@ -39,6 +39,7 @@ extern "C" int lxo_gemm_tn(int dt, int a_f32, int b_f32, const void* A, const vo
     { char m_[200]; int v_ = P.validate(m_, sizeof(m_)); if (v_) { snprintf(g_err, sizeof(g_err), "%s", m_); return v_; } }
 
 extern "C" int lxo_param_num(void) { return P_COUNT; }
+extern "C" const char* lxo_param_name_for(const lxo_shape* s, int id) { return lxo_param_name_mode(id, s ? s->encoder_cnn : 0); }
 extern "C" long long lxo_param_total(const lxo_shape* s) { if (!s) return -1; Plan P(*s); return P.ptotal; }
 extern "C" int lxo_param_info(const lxo_shape* s, int id, long long* offset, long long* count) {
     if (!s || id < 0 || id >= P_COUNT) return fail(-1, "lxo_param_info");

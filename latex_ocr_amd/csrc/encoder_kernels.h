@@ -15,3 +15,7 @@ int lxo_k_pack_transpose(int dt, const float* src, void* dst, int K, int N, int 
 int lxo_k_pack_copy(int dt, const float* src, void* dst, int R, int Ccols, int lds, int ldd, int Cpad, hipStream_t s);
 int lxo_k_pack_conv_dgrad(int dt, const float* w, void* dst, int Cin, int Cout, hipStream_t s);
 int lxo_k_pack_batch(int dt, const PackTable& tab, int total_blocks, const float* prm, void* wpk, hipStream_t s);
+// "cnn" encoder: (2,4) stride-2 SAME conv of encoder.py:54-56 as im2col + dense GEMM; its input gradient through the ReLU of conv5
+int lxo_k_im2col_s2(int dt, const void* in, void* cols, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s);
+int lxo_k_col2im_s2_relu(int dt, const void* dcols, const void* yref, void* dy, float* db, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s);
+int lxo_k_colsum_ct(int dt, const void* a, float* out, long long M, int N, hipStream_t s);

@@ -364,6 +364,80 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackTable tab, const fl
     }
 }
 
+
+// ---- "cnn" encoder: the (2,4) stride-2 SAME convolution of encoder.py:54-56 as im2col + dense GEMM ----
+// TF SAME padding for kernel (2,4), stride 2: rows pad (0 top, 0/1 bottom), columns pad (1 left, 1/2 right).
+// cols[(b,oy,ox)][(kh,kw,c)] = in[b, 2oy+kh, 2ox+kw-1, c]   (zero outside)
+template <typename CT>
+__global__ __launch_bounds__(256) void im2col_s2_kernel(const CT* __restrict__ in, CT* __restrict__ cols, int B, int H, int W, int Ho, int Wo, int C) {
+    const int c8n = C >> 3;
+    const long long total = (long long)B * Ho * Wo * 8 * c8n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        const int tap = (int)((i / c8n) & 7);
+        const long long m = i / (8 * c8n);
+        const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+        const int iy = 2 * oy + (tap >> 2), ix = 2 * ox + (tap & 3) - 1;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (iy < H && ix >= 0 && ix < W) load8(in + (((long long)b * H + iy) * W + ix) * C + c8 * 8, v);
+        store8(cols + (m * 8 + tap) * C + c8 * 8, v);
+    }
+}
+// dy[b,y,x,c] = (y5 > 0) * sum over the <= 2 windows covering (y,x) of dcols ;  db[c] += column sums of dy
+template <typename CT>
+__global__ __launch_bounds__(256) void col2im_s2_relu_kernel(const CT* __restrict__ dcols, const CT* __restrict__ yref, CT* __restrict__ dy,
+                                                            float* __restrict__ db, int B, int H, int W, int Ho, int Wo, int C, int ppt) {
+    const int c8n = C >> 3;
+    const long long npix = (long long)B * H * W;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = (int)(t % c8n);
+    const long long p0 = (t / c8n) * ppt;
+    if (p0 >= npix) return;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long p1 = p0 + ppt < npix ? p0 + ppt : npix;
+    for (long long p = p0; p < p1; ++p) {
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
+        const int oy = y >> 1, kh = y & 1;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (oy < Ho) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kw = ((x + 1) & 1) + 2 * h;
+                const int ox2 = x + 1 - kw;                 // = 2 * ox
+                if (ox2 < 0 || (ox2 >> 1) >= Wo) continue;
+                float v[8];
+                load8(dcols + ((((long long)b * Ho + oy) * Wo + (ox2 >> 1)) * 8 + kh * 4 + kw) * C + c8 * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+        }
+        float r[8];
+        load8(yref + p * C + c8 * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] = r[e] > 0.f ? acc[e] : 0.f; cs[e] += acc[e]; }
+        store8(dy + p * C + c8 * 8, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&db[c8 * 8 + e], cs[e]);
+}
+// out[n] += sum_m a[m][n] for a compute-dtype matrix (bias gradient of the strided conv)
+template <typename CT>
+__global__ __launch_bounds__(256) void colsum_ct_kernel(const CT* __restrict__ a, float* __restrict__ out, long long M, int N, int rpb) {
+    const int c8n = N >> 3;
+    const int c8 = threadIdx.x % c8n, sub = threadIdx.x / c8n, nsub = 256 / c8n;
+    const long long m0 = (long long)blockIdx.x * rpb, m1 = m0 + rpb < M ? m0 + rpb : M;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (sub < nsub)
+        for (long long m = m0 + sub; m < m1; m += nsub) {
+            float v[8];
+            load8(a + m * N + c8 * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += v[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&out[c8 * 8 + e], cs[e]);
+}
+
 inline int grid_for(long long items, int per_block, int cap = 2048) {
     long long g = (items + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -451,5 +525,35 @@ int lxo_k_pack_batch(int dt, const PackTable& tab, int total_blocks, const float
     if (tab.n <= 0) return 0;
     if (dt == LXO_BF16) hipLaunchKernelGGL((pack_batch_kernel<bf16_t>), dim3(total_blocks), dim3(256), 0, s, tab, prm, (char*)wpk);
     else hipLaunchKernelGGL((pack_batch_kernel<float>), dim3(total_blocks), dim3(256), 0, s, tab, prm, (char*)wpk);
+    return (int)hipGetLastError();
+}
+
+template <typename CT> static void im2col_s2_t(const void* in, void* cols, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s) {
+    hipLaunchKernelGGL((im2col_s2_kernel<CT>), dim3(grid_for((long long)B * Ho * Wo * C, 256 * 4, 8192)), dim3(256), 0, s,
+                       (const CT*)in, (CT*)cols, B, H, W, Ho, Wo, C);
+}
+int lxo_k_im2col_s2(int dt, const void* in, void* cols, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s) {
+    if (C % 8) return -2;
+    DISPATCH_CT(dt, im2col_s2_t, in, cols, B, H, W, Ho, Wo, C, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void col2im_s2_t(const void* dcols, const void* yref, void* dy, float* db, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s) {
+    const int ppt = 32;
+    const long long threads = (((long long)B * H * W + ppt - 1) / ppt) * (C / 8);
+    hipLaunchKernelGGL((col2im_s2_relu_kernel<CT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                       (const CT*)dcols, (const CT*)yref, (CT*)dy, db, B, H, W, Ho, Wo, C, ppt);
+}
+int lxo_k_col2im_s2_relu(int dt, const void* dcols, const void* yref, void* dy, float* db, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s) {
+    if (C % 8) return -2;
+    DISPATCH_CT(dt, col2im_s2_t, dcols, yref, dy, db, B, H, W, Ho, Wo, C, s);
+    return (int)hipGetLastError();
+}
+template <typename CT> static void colsum_ct_t(const void* a, float* out, long long M, int N, hipStream_t s) {
+    const int rpb = 256;
+    hipLaunchKernelGGL((colsum_ct_kernel<CT>), dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, s, (const CT*)a, out, M, N, rpb);
+}
+int lxo_k_colsum_ct(int dt, const void* a, float* out, long long M, int N, hipStream_t s) {
+    if (N % 8 || N > 2048 || 256 % (N / 8)) return -2;
+    DISPATCH_CT(dt, colsum_ct_t, a, out, M, N, s);
     return (int)hipGetLastError();
 }

@@ -22,8 +22,12 @@ int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t
     auto cp = [&](long long src, size_t dst, int R, int Ccols, int ldd, int Cpad) { add(1, src, dst, R, Ccols, Ccols, ldd, 0, Cpad); };
     for (int l = 1; l < 6; ++l) {
         const int ci = P.convCin[l], co = P.convCout[l];
-        tr(P.poff[2 * l], P.koff[K_CONV2_F + l - 1], 9 * ci, co, 9 * ci, 0, 9 * ci);
-        add(2, P.poff[2 * l], P.koff[K_CONV2_D + l - 1], ci, co, 0, 0, 0, 0);
+        tr(P.poff[P.convW[l]], P.koff[K_CONV2_F + l - 1], 9 * ci, co, 9 * ci, 0, 9 * ci);
+        add(2, P.poff[P.convW[l]], P.koff[K_CONV2_D + l - 1], ci, co, 0, 0, 0, 0);
+    }
+    if (P.cnn) {        // strided conv: HWIO [8C][C] -> [C][8C] for the forward GEMM, straight copy for the column gradient
+        tr(P.poff[P_CONVS_W], P.koff[K_CONVS_F], 8 * C, C, 8 * C, 0, 8 * C);
+        cp(P.poff[P_CONVS_W], P.koff[K_CONVS_D], 8 * C, C, C, C);
     }
     tr(P.poff[P_ATT_IMG], P.koff[K_ATT_IMG_T], C, E, C, 0, C);
     cp(P.poff[P_ATT_IMG], P.koff[K_ATT_IMG], C, E, E, E);
@@ -106,12 +110,24 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
     RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y2), P.ws<void>(ws, W_P2), B, P.H1, P.W1, 128, 2, 2, st));
     RC(conv_fwd(P, P.ws<void>(ws, W_P2), P.pk(wp, K_CONV3_F), prm + P.poff[P_CONV3_B], P.ws<void>(ws, W_Y3), P.H2, P.W2, 128, 256, false, nullptr, 0, nullptr, st));
     RC(conv_fwd(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.ws<void>(ws, W_Y4), P.H2, P.W2, 256, 256, false, nullptr, 0, nullptr, st));
-    RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y4), P.ws<void>(ws, W_P4), B, P.H2, P.W2, 256, 2, 1, st));
-    RC(conv_fwd(P, P.ws<void>(ws, W_P4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
-    RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_P5), B, P.H4, P.W2, C, 1, 2, st));
-    RC(lxo_k_timing_signal(P.ws<float>(ws, W_POS), P.Hp, P.Wp, C, st));
-    RC(conv_fwd(P, P.ws<void>(ws, W_P5), P.pk(wp, K_CONV6_F), prm + P.poff[P_CONV6_B], P.ws<void>(ws, W_IMG), P.H4, P.W5, C, C, true,
-                P.ws<float>(ws, W_POS), P.R, P.ws<void>(ws, W_Y6), st));
+    if (!P.cnn) {
+        RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y4), P.ws<void>(ws, W_P4), B, P.H2, P.W2, 256, 2, 1, st));
+        RC(conv_fwd(P, P.ws<void>(ws, W_P4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
+        RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_P5), B, P.H4, P.W2, C, 1, 2, st));
+    } else {
+        // encoder.py:54-56: conv5 on the un-pooled conv4 output, then the (2,4) stride-2 SAME conv (no activation)
+        RC(conv_fwd(P, P.ws<void>(ws, W_Y4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
+        RC(lxo_k_im2col_s2(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_COLS), B, P.H4, P.W2, P.H6, P.W5, C, st));
+        GemmNT g; memset(&g, 0, sizeof(g));
+        g.A = P.ws<void>(ws, W_COLS); g.Bp = P.pk(wp, K_CONVS_F); g.C = P.ws<void>(ws, W_P5);
+        g.M = B * P.H6 * P.W5; g.N = C; g.K = 8 * C; g.lda = 8 * C; g.ldb = 8 * C; g.ldc = C;
+        g.bias = prm + P.poff[P_CONVS_B]; g.alpha = 1.f; g.addend_rows = 1;
+        RC(lxo_launch_gemm_nt(dt, 0, 0, 0, g, st));
+    }
+    const bool pos = P.s.no_positional == 0;                    // positional_embeddings (encoder.py:60-65)
+    if (pos) RC(lxo_k_timing_signal(P.ws<float>(ws, W_POS), P.Hp, P.Wp, C, st));
+    RC(conv_fwd(P, P.ws<void>(ws, W_P5), P.pk(wp, K_CONV6_F), prm + P.poff[P_CONV6_B], P.ws<void>(ws, W_IMG), P.H6, P.W5, C, C, true,
+                pos ? P.ws<float>(ws, W_POS) : nullptr, P.R, P.ws<void>(ws, W_Y6), st));
     return 0;
 }
 
@@ -120,21 +136,49 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
 int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, float* grads,
                          int last_layer, int first_layer, hipStream_t st) {
     const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
-    void* G0 = P.ws<void>(ws, W_G0); void* G1 = P.ws<void>(ws, W_G1);
+    void* const GA = P.ws<void>(ws, W_G0); void* const GB = P.ws<void>(ws, W_G1);
     auto gw = [&](int pid) { return grads + P.poff[pid]; };
     for (int l = last_layer; l >= first_layer; --l) {
+        // "cnn" has no pool between conv4 and conv5, so from layer 3 down the ping-pong roles are swapped
+        const bool swapped = P.cnn && l <= 3;
+        void* const G0 = swapped ? GB : GA; void* const G1 = swapped ? GA : GB;
         switch (l) {
         case 6:   // d_y6 = d_img * (y6>0) -> G0 ; wgrad6 ; d_p5 = dgrad6 -> G1
             RC(lxo_k_mask_convert(dt, P.ws<float>(ws, W_DIMG), P.ws<void>(ws, W_Y6), G0, gw(P_CONV6_B), (long long)B * P.R, C, st));
-            RC(conv_wgrad(P, P.ws<void>(ws, W_P5), G0, gw(P_CONV6_W), P.H4, P.W5, C, C, true, st));
-            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV6_D), G1, P.Hp, P.Wp, C, P.H4, P.W5, C, true, nullptr, nullptr, st));
+            RC(conv_wgrad(P, P.ws<void>(ws, W_P5), G0, gw(P_CONV6_W), P.H6, P.W5, C, C, true, st));
+            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV6_D), G1, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, st));
             break;
         case 5:   // d_y5 = route(d_p5 in G1) -> G0 ; wgrad5 ; d_p4 = dgrad5 -> G1
+            if (P.cnn) {
+                // strided conv backward: db = colsum(d_p5), dW = cols^T d_p5, d_cols = d_p5 W^T, d_y5 = col2im(d_cols) * (y5 > 0) -> G0
+                const int M = B * P.H6 * P.W5;
+                RC(lxo_k_colsum_ct(dt, G1, gw(P_CONVS_B), M, C, st));
+                GemmTN t; memset(&t, 0, sizeof(t));
+                t.A = P.ws<void>(ws, W_COLS); t.B = G1; t.C = gw(P_CONVS_W); t.M = M; t.I = 8 * C; t.J = C;
+                t.lda = 8 * C; t.ldb = C; t.ldc = C;
+                { int ns = M / 2048; if (ns < 1) ns = 1; if (ns > 16) ns = 16; t.nsplit = ns; }
+                t.nbatch = 1; t.atomic = 1;
+                RC(lxo_launch_gemm_tn(dt, 0, 0, t, st));
+                GemmNT g; memset(&g, 0, sizeof(g));
+                g.A = G1; g.Bp = P.pk(wp, K_CONVS_D); g.C = P.ws<void>(ws, W_COLS);
+                g.M = M; g.N = 8 * C; g.K = C; g.lda = C; g.ldb = C; g.ldc = 8 * C; g.alpha = 1.f; g.addend_rows = 1;
+                RC(lxo_launch_gemm_nt(dt, 0, 0, 0, g, st));
+                RC(lxo_k_col2im_s2_relu(dt, P.ws<void>(ws, W_COLS), P.ws<void>(ws, W_Y5), G0, gw(P_CONV5_B), B, P.H4, P.W2, P.H6, P.W5, C, st));
+                // conv5 at H2 x W2 on the un-pooled y4: d_y4 = dgrad5 * (y4 > 0) -> G1 (+ db4)
+                RC(conv_wgrad(P, P.ws<void>(ws, W_Y4), G0, gw(P_CONV5_W), P.H4, P.W2, 256, C, false, st));
+                RC(conv_dgrad(P, G0, P.pk(wp, K_CONV5_D), G1, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), st));
+                break;
+            }
             RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), G1, G0, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
             RC(conv_wgrad(P, P.ws<void>(ws, W_P4), G0, gw(P_CONV5_W), P.H4, P.W2, 256, C, false, st));
             RC(conv_dgrad(P, G0, P.pk(wp, K_CONV5_D), G1, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, st));
             break;
         case 4:   // d_y4 = route(d_p4 in G1) -> G0 ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> G1 (+ db3)
+            if (P.cnn) {     // d_y4 already masked, in G1: wgrad4 ; d_y3 -> G0 (layer 3 reads it as its G1: roles swap below)
+                RC(conv_wgrad(P, P.ws<void>(ws, W_Y3), G1, gw(P_CONV4_W), P.H2, P.W2, 256, 256, false, st));
+                RC(conv_dgrad(P, G1, P.pk(wp, K_CONV4_D), G0, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), st));
+                break;
+            }
             RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), G1, G0, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
             RC(conv_wgrad(P, P.ws<void>(ws, W_Y3), G0, gw(P_CONV4_W), P.H2, P.W2, 256, 256, false, st));
             RC(conv_dgrad(P, G0, P.pk(wp, K_CONV4_D), G1, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), st));

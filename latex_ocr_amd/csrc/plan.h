@@ -9,7 +9,9 @@
 
 enum ParamId {
     P_CONV1_W, P_CONV1_B, P_CONV2_W, P_CONV2_B, P_CONV3_W, P_CONV3_B, P_CONV4_W, P_CONV4_B,
-    P_CONV5_W, P_CONV5_B, P_CONV6_W, P_CONV6_B,
+    P_CONV5_W, P_CONV5_B,
+    P_CONVS_W, P_CONVS_B,          // encoder_cnn == "cnn": the (2,4) stride-2 conv of encoder.py:54-56 (count 0 otherwise)
+    P_CONV6_W, P_CONV6_B,
     P_EMB, P_START, P_ATT_IMG, P_WC0, P_BC0, P_WH0, P_BH0, P_WO0, P_BO0,
     P_LSTM_K, P_LSTM_B, P_ATT_H, P_BETA, P_OWH, P_OWC, P_YWO, P_COUNT
 };
@@ -30,6 +32,8 @@ enum PackId {
     K_OW,          // [U+C][O]
     K_YWO_T,       // [V][O]
     K_YWO,         // [O][Vp]
+    K_CONVS_F,     // [C][8C]   strided conv, tap-major rows (cnn encoder only)
+    K_CONVS_D,     // [8C][C]
     K_COUNT
 };
 
@@ -41,6 +45,7 @@ enum WsId {
     W_S_K1, W_S_K2, W_S_K4, W_S_B1, W_S_B3, W_S_B4,   // split-K slabs of the recurrent GEMMs
     // decode-only
     W_DEC_IDS, W_DEC_FLAGS, W_DEC_EMB, W_DEC_ZX, W_DEC_LOGITS, W_BEAM_LP, W_BEAM_PAR, W_BEAM_TMP,
+    W_COLS,        // cnn encoder only: im2col of the strided conv [B*H6*W5][8C], reused for its column gradient
     W_COUNT
 };
 
@@ -49,8 +54,9 @@ struct Plan {
     bool bf;                 // compute dtype is bf16
     size_t esz;              // bytes per compute-dtype element
     // encoder geometry
-    int H1, W1, H2, W2, H4, W5, Hp, Wp, R;
-    int convCin[6], convCout[6];
+    int H1, W1, H2, W2, H4, W5, H6, Hp, Wp, R;   // conv5 runs at H4 x W2, conv6 reads H6 x W5 (vanilla: H6 == H4)
+    bool cnn;                                    // encoder_cnn == "cnn": no pools after conv4/conv5, (2,4)/2 conv instead
+    int convCin[6], convCout[6], convW[6], convB[6];   // per 3x3 layer: channels and ParamIds
     int Vp, Dp, Rp, XH, HC, REC;   // padded V / D / R (row pitches), O+U, U+C, record width O+2U+C
     int OFF_HT, OFF_CTX;           // record = [o | h | h~ | ctx]: [o|h] feeds the LSTM, [h~|ctx] the attention and o projection
     Drop drop(int t, int row0) const;   // dropout descriptor of decoder step t for rows row0.. (off when keep_prob is 0 or >= 1)
@@ -72,3 +78,4 @@ struct Plan {
 };
 
 const char* lxo_param_name(int id);
+const char* lxo_param_name_mode(int id, int encoder_cnn);

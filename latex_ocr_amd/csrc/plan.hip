@@ -10,6 +10,7 @@ static const char* kParamNames[P_COUNT] = {
     "Encoder/convolutional_encoder/conv2d_2/kernel", "Encoder/convolutional_encoder/conv2d_2/bias",
     "Encoder/convolutional_encoder/conv2d_3/kernel", "Encoder/convolutional_encoder/conv2d_3/bias",
     "Encoder/convolutional_encoder/conv2d_4/kernel", "Encoder/convolutional_encoder/conv2d_4/bias",
+    "Encoder/convolutional_encoder/conv2d_strided/kernel", "Encoder/convolutional_encoder/conv2d_strided/bias",
     "Encoder/convolutional_encoder/conv2d_5/kernel", "Encoder/convolutional_encoder/conv2d_5/bias",
     "Decoder/embedding_table", "Decoder/start_token",
     "Decoder/AttentionCell/att_img/kernel",
@@ -21,6 +22,20 @@ static const char* kParamNames[P_COUNT] = {
     "Decoder/AttentionCell/rnn/o_W_h", "Decoder/AttentionCell/rnn/o_W_c", "Decoder/AttentionCell/rnn/y_W_o",
 };
 const char* lxo_param_name(int id) { return (id >= 0 && id < P_COUNT) ? kParamNames[id] : ""; }
+// TF numbers the tf.layers.conv2d scopes in creation order: with encoder_cnn == "cnn" the strided conv is
+// conv2d_5 and the last 3x3 conv conv2d_6 (encoder.py:54-59)
+const char* lxo_param_name_mode(int id, int encoder_cnn) {
+    if (encoder_cnn) {
+        switch (id) {
+        case P_CONVS_W: return "Encoder/convolutional_encoder/conv2d_5/kernel";
+        case P_CONVS_B: return "Encoder/convolutional_encoder/conv2d_5/bias";
+        case P_CONV6_W: return "Encoder/convolutional_encoder/conv2d_6/kernel";
+        case P_CONV6_B: return "Encoder/convolutional_encoder/conv2d_6/bias";
+        default: break;
+        }
+    }
+    return lxo_param_name(id);
+}
 
 static const char* kWsNames[W_COUNT] = {
     "p1", "y2", "p2", "y3", "y4", "p4", "y5", "p5", "y6", "img", "pos",
@@ -29,6 +44,7 @@ static const char* kWsNames[W_COUNT] = {
     "d_emb", "dpre0", "dmean", "g0", "g1", "gnorm",
     "s_k1", "s_k2", "s_k4", "s_b1", "s_b3", "s_b4",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
+    "cols",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
 
@@ -41,19 +57,23 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     const int B = s.B, C = s.C, E = s.E, U = s.U, O = s.O, D = s.D, V = s.V, T = s.T > 0 ? s.T : 1;
     H1 = cd2(s.H); W1 = cd2(s.W);          // after conv1's 2x2 pool      (encoder.py:34)
     H2 = cd2(H1); W2 = cd2(W1);            // after conv2's 2x2 pool      (encoder.py:39)
-    H4 = cd2(H2);                          // after conv4's (2,1) pool    (encoder.py:47)
-    W5 = cd2(W2);                          // after conv5's (1,2) pool    (encoder.py:52)
-    Hp = H4 - 2; Wp = W5 - 2;              // conv6 VALID                 (encoder.py:59)
+    cnn = s.encoder_cnn != 0;
+    H4 = cnn ? H2 : cd2(H2);               // after conv4's (2,1) pool    (encoder.py:47; "cnn": no pool)
+    W5 = cd2(W2);                          // after conv5's (1,2) pool    (encoder.py:52) / the stride-2 conv (:54-56)
+    H6 = cnn ? cd2(H2) : H4;               // rows conv6 reads
+    Hp = H6 - 2; Wp = W5 - 2;              // conv6 VALID                 (encoder.py:59)
     R = Hp > 0 && Wp > 0 ? Hp * Wp : 0;
     const int ci[6] = {1, 64, 128, 256, 256, C}, co[6] = {64, 128, 256, 256, C, C};
-    for (int i = 0; i < 6; ++i) { convCin[i] = ci[i]; convCout[i] = co[i]; }
+    const int wid[6] = {P_CONV1_W, P_CONV2_W, P_CONV3_W, P_CONV4_W, P_CONV5_W, P_CONV6_W};
+    for (int i = 0; i < 6; ++i) { convCin[i] = ci[i]; convCout[i] = co[i]; convW[i] = wid[i]; convB[i] = wid[i] + 1; }
     Vp = (V + 31) / 32 * 32;
     Dp = (D + 31) / 32 * 32;
     Rp = (R + 7) / 8 * 8;
     XH = O + U; HC = U + C; OFF_HT = O + U; OFF_CTX = O + 2 * U; REC = O + 2 * U + C;
 
     long long cnt[P_COUNT];
-    for (int i = 0; i < 6; ++i) { cnt[2 * i] = 9LL * ci[i] * co[i]; cnt[2 * i + 1] = co[i]; }
+    for (int i = 0; i < 6; ++i) { cnt[convW[i]] = 9LL * ci[i] * co[i]; cnt[convB[i]] = co[i]; }
+    cnt[P_CONVS_W] = cnn ? 8LL * C * C : 0; cnt[P_CONVS_B] = cnn ? C : 0;
     cnt[P_EMB] = (long long)V * D; cnt[P_START] = D; cnt[P_ATT_IMG] = (long long)C * E;
     cnt[P_WC0] = (long long)C * U; cnt[P_BC0] = U; cnt[P_WH0] = (long long)C * U; cnt[P_BH0] = U;
     cnt[P_WO0] = (long long)C * O; cnt[P_BO0] = O;
@@ -75,6 +95,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     kb[K_ATT_H_T] = (size_t)E * U * esz; kb[K_ATT_H] = (size_t)U * E * esz;
     kb[K_OW_T] = (size_t)O * HC * esz; kb[K_OW] = (size_t)HC * O * esz;
     kb[K_YWO_T] = (size_t)V * O * esz; kb[K_YWO] = (size_t)O * Vp * esz;
+    kb[K_CONVS_F] = cnn ? (size_t)8 * C * C * esz : 0; kb[K_CONVS_D] = kb[K_CONVS_F];
     ktotal = 0;
     for (int i = 0; i < K_COUNT; ++i) { koff[i] = ktotal; ktotal += al256(kb[i] + 64); }
 
@@ -85,8 +106,9 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_P1] = BL * H1 * W1 * 64 * esz;
     wb[W_Y2] = BL * H1 * W1 * 128 * esz;  wb[W_P2] = BL * H2 * W2 * 128 * esz;
     wb[W_Y3] = BL * H2 * W2 * 256 * esz;  wb[W_Y4] = BL * H2 * W2 * 256 * esz;
-    wb[W_P4] = BL * H4 * W2 * 256 * esz;
-    wb[W_Y5] = BL * H4 * W2 * C * esz;    wb[W_P5] = BL * H4 * W5 * C * esz;
+    wb[W_P4] = cnn ? 0 : BL * H4 * W2 * 256 * esz;
+    wb[W_Y5] = BL * H4 * W2 * C * esz;    wb[W_P5] = BL * H6 * W5 * C * esz;
+    wb[W_COLS] = cnn ? BL * H6 * W5 * 8 * C * esz : 0;
     wb[W_Y6] = BL * R * C * esz;          wb[W_IMG] = BL * R * C * esz;
     wb[W_POS] = (size_t)R * C * f4;
     const int nb = s.beam > 1 ? s.beam : 1;

@@ -54,6 +54,12 @@ class Engine(object):
             off += n
         # gradient buckets for data-parallel all-reduce, in the order backward finishes them
         first_dec = self._offsets["Decoder/embedding_table"][0]
+        for i in range(self.lib.lxo_param_num()):          # the C plan and this inventory must agree slot by slot
+            o, c = ctypes.c_longlong(), ctypes.c_longlong()
+            self._ck(self.lib.lxo_param_info(ctypes.byref(probe), i, ctypes.byref(o), ctypes.byref(c)), "param_info")
+            if c.value:
+                name = self.lib.lxo_param_name_for(ctypes.byref(probe), i).decode()
+                assert self._offsets[name][:2] == (o.value, c.value), (name, self._offsets[name], o.value, c.value)
         c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]
         self.buckets = [(first_dec, self.n_params), (c5, first_dec), (0, c5)]
         # optional second stream for the half-batch interleave of the recurrent loop (LXO_DUAL_STREAM=1).
@@ -67,8 +73,11 @@ class Engine(object):
     # ------------------------------------------------------------ plumbing --
     def _shape(self, B, H, W, T):
         d = self.dims
-        return _abi.LxoShape(B, H, W, T, self.n_tok, d["C"], d["E"], d["U"], d["O"], d["D"], self.dtype,
-                             self.beam, self.max_steps)
+        sh = _abi.LxoShape(B, H, W, T, self.n_tok, d["C"], d["E"], d["U"], d["O"], d["D"], self.dtype,
+                           self.beam, self.max_steps)
+        sh.encoder_cnn = 1 if d.get("cnn") else 0                 # configs/model.json encoder_cnn (encoder.py:46-56)
+        sh.no_positional = 0 if d.get("positional", True) else 1  # positional_embeddings (encoder.py:60-65)
+        return sh
 
     def _stream(self):
         if self.device.type == "cuda":

@@ -31,10 +31,6 @@ class Img2SeqModel(BaseModel):
     def _build_engine(self):
         from ..engine import Engine
         cfg = self._config
-        if getattr(cfg, "encoder_cnn", "vanilla") != "vanilla":
-            raise NotImplementedError("encoder_cnn=%r: only the 'vanilla' encoder (encoder.py:46-52) is built" % cfg.encoder_cnn)
-        if not getattr(cfg, "positional_embeddings", True):
-            raise NotImplementedError("positional_embeddings=false is not built")
         self.engine = Engine(self._vocab.n_tok, dims=dims_from_config(cfg),
                              dtype=getattr(cfg, "compute_dtype", "bf16"),
                              device=getattr(cfg, "device", "cuda:0") if str(getattr(cfg, "device", "")).startswith("cuda") else "cuda:0",

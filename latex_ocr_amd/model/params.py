@@ -26,19 +26,26 @@ _A = "Decoder/AttentionCell/"
 
 def dims_from_config(config):
     ac = getattr(config, "attn_cell_config", {}) or {}
+    enc = getattr(config, "encoder_cnn", "vanilla")
+    if enc not in ("vanilla", "cnn"):
+        raise NotImplementedError("encoder_cnn=%r (model/encoder.py knows 'vanilla' and 'cnn')" % (enc,))
     return dict(C=512, E=ac.get("dim_e", 256), U=ac.get("num_units", 512),
-                O=ac.get("dim_o", 512), D=ac.get("dim_embeddings", 80))
+                O=ac.get("dim_o", 512), D=ac.get("dim_embeddings", 80), cnn=(enc == "cnn"),
+                positional=bool(getattr(config, "positional_embeddings", True)))
 
 
 def param_specs(n_tok, dims=None):
     d = dict(DEFAULT_DIMS, **(dims or {}))
     C, E, U, O, D, V = d["C"], d["E"], d["U"], d["O"], d["D"], n_tok
     chans = [(1, 64), (64, 128), (128, 256), (256, 256), (256, C), (C, C)]
+    kernels = [(3, 3, ci, co) for ci, co in chans]
+    if d.get("cnn"):        # encoder_cnn == "cnn" (model/encoder.py:54-56): TF numbers the strided conv conv2d_5
+        kernels.insert(5, (2, 4, C, C))
     specs = []
-    for i, (ci, co) in enumerate(chans):
+    for i, shp in enumerate(kernels):
         scope = "Encoder/convolutional_encoder/conv2d" + ("" if i == 0 else "_%d" % i)
-        specs.append((scope + "/kernel", (3, 3, ci, co), "glorot"))
-        specs.append((scope + "/bias", (co,), "zeros"))
+        specs.append((scope + "/kernel", shp, "glorot"))
+        specs.append((scope + "/bias", (shp[3],), "zeros"))
     specs += [
         ("Decoder/embedding_table", (V, D), "embed"),
         ("Decoder/start_token", (D,), "embed"),

@@ -44,11 +44,14 @@ def param_specs(V, dims=None):
     chans = list(CONV_CHANNELS)
     chans[4] = (256, C)
     chans[5] = (C, C)
+    kernels = [(3, 3, ci, co) for ci, co in chans]
+    if d.get("cnn"):        # encoder_cnn == "cnn" (encoder.py:54-56): a (2,4) stride-2 conv before the last one
+        kernels.insert(5, (2, 4, C, C))
     specs = []
-    for i, (ci, co) in enumerate(chans):
+    for i, shp in enumerate(kernels):
         sfx = "" if i == 0 else "_%d" % i
-        specs.append(("Encoder/convolutional_encoder/conv2d%s/kernel" % sfx, (3, 3, ci, co), "glorot"))
-        specs.append(("Encoder/convolutional_encoder/conv2d%s/bias" % sfx, (co,), "zeros"))
+        specs.append(("Encoder/convolutional_encoder/conv2d%s/kernel" % sfx, shp, "glorot"))
+        specs.append(("Encoder/convolutional_encoder/conv2d%s/bias" % sfx, (shp[3],), "zeros"))
     A = "Decoder/AttentionCell/"
     specs += [
         ("Decoder/embedding_table", (V, D), "embed"),
@@ -123,8 +126,16 @@ def timing_signal_2d(H, W, C, dtype=torch.float32):
     return sig
 
 
+def _same_pad(n, k, s):
+    """+TF SAME padding of one axis: (before, after)."""
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return tot // 2, tot - tot // 2
+
+
 def encoder(P, img_u8, positional=True, return_all=False):
-    """encoder.py:25-68 (vanilla).  img_u8: uint8 [B,H,W,1] -> f32 [B,H',W',C]."""
+    """encoder.py:25-68.  img_u8: uint8 [B,H,W,1] -> f32 [B,H',W',C].  The "cnn" variant (encoder.py:54-56; present
+    when the parameter set holds conv2d_6) drops the two late pools for a (2,4) stride-2 SAME conv without activation."""
     pre = "Encoder/convolutional_encoder/conv2d"
     x = (img_u8.to(torch.float32) - 128.0) / 128.0          # encoder.py:26-27
     x = x.permute(0, 3, 1, 2)
@@ -135,10 +146,18 @@ def encoder(P, img_u8, positional=True, return_all=False):
     x = F.max_pool2d(x, 2, 2, ceil_mode=True)                                       # :39
     x = _conv(x, P[pre + "_2/kernel"], P[pre + "_2/bias"], 1); acts.append(x)      # :42
     x = _conv(x, P[pre + "_3/kernel"], P[pre + "_3/bias"], 1); acts.append(x)      # :44
-    x = F.max_pool2d(x, (2, 1), (2, 1), ceil_mode=True)                             # :47
+    cnn = (pre + "_6/kernel") in P
+    if not cnn:
+        x = F.max_pool2d(x, (2, 1), (2, 1), ceil_mode=True)                         # :47
     x = _conv(x, P[pre + "_4/kernel"], P[pre + "_4/bias"], 1); acts.append(x)      # :49
-    x = F.max_pool2d(x, (1, 2), (1, 2), ceil_mode=True)                             # :52
-    x = _conv(x, P[pre + "_5/kernel"], P[pre + "_5/bias"], 0); acts.append(x)      # :59 VALID
+    if not cnn:
+        x = F.max_pool2d(x, (1, 2), (1, 2), ceil_mode=True)                         # :52
+        last = "_5"
+    else:
+        (pt, pb), (pl, pr) = _same_pad(x.shape[2], 2, 2), _same_pad(x.shape[3], 4, 2)
+        x = F.conv2d(F.pad(x, (pl, pr, pt, pb)), P[pre + "_5/kernel"].permute(3, 2, 0, 1), P[pre + "_5/bias"], stride=2)   # :56
+        last = "_6"
+    x = _conv(x, P[pre + last + "/kernel"], P[pre + last + "/bias"], 0); acts.append(x)   # :59 VALID
     x = x.permute(0, 2, 3, 1)
     if positional:
         x = x + timing_signal_2d(x.shape[1], x.shape[2], x.shape[3])[None]          # :66

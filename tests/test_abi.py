@@ -32,18 +32,25 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_param_table_matches_python(lib):
-    for V in (50, 500):
+    for V, cnn in ((50, 0), (500, 0), (50, 1)):
         s = _abi.LxoShape(4, 32, 128, 10, V, 512, 256, 512, 512, 80, 1, 1, 0)
-        assert lib.lxo_param_total(ctypes.byref(s)) == PP.n_params(V)
+        s.encoder_cnn = cnn
+        dims = dict(PP.DEFAULT_DIMS, cnn=bool(cnn))
+        assert lib.lxo_param_total(ctypes.byref(s)) == PP.n_params(V, dims)
         off = 0
-        specs = PP.param_specs(V)
-        assert lib.lxo_param_num() == len(specs)
-        for i, (name, shp, _) in enumerate(specs):
+        specs = list(PP.param_specs(V, dims))
+        for i in range(lib.lxo_param_num()):              # slots of the other encoder variant have count 0
             o, c = ctypes.c_longlong(), ctypes.c_longlong()
             assert lib.lxo_param_info(ctypes.byref(s), i, ctypes.byref(o), ctypes.byref(c)) == 0
-            assert lib.lxo_param_name(i).decode() == name
+            if c.value == 0:
+                continue
+            name, shp, _ = specs.pop(0)
+            assert lib.lxo_param_name_for(ctypes.byref(s), i).decode() == name
+            if not cnn:
+                assert lib.lxo_param_name(i).decode() == name
             assert (o.value, c.value) == (off, int(np.prod(shp)))
             off += int(np.prod(shp))
+        assert not specs
 
 
 def test_workspace_queries_and_validation(lib):

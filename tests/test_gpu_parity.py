@@ -12,17 +12,19 @@ pytestmark = pytest.mark.gpu
 from gpu_common import *  # noqa
 
 
-def _grads_check(dtype, tol_loss, min_cos, dropout=None):
+def _grads_check(dtype, tol_loss, min_cos, dropout=None, dims=None):
     V = 50
     img, f, l = batch(6, 32, 128, V, 5, 12, seed=7)
-    eng = Engine(V, dtype=dtype, seed=3)
+    eng = Engine(V, dtype=dtype, seed=3, dims=dims)
     P = oracle_params(eng)
+    positional = (dims or {}).get("positional", True)
     eng.forward(img, f, dropout=dropout)
     n = int(l.sum())
     stats = eng.loss(l, 1.0 / n).cpu().numpy()
     eng.backward()
     torch.cuda.synchronize()
-    loss_ref, G, ce, nw = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l), dropout=dropout)
+    loss_ref, G, ce, nw = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l), positional=positional,
+                                        dropout=dropout)
     loss = stats[0] / stats[1]
     assert stats[1] == n
     assert abs(loss - float(loss_ref)) / float(loss_ref) < tol_loss, (loss, float(loss_ref))
@@ -41,6 +43,15 @@ def test_fwd_bwd_f32():
 
 def test_fwd_bwd_bf16():
     _grads_check("bf16", 1e-3, 0.98)
+
+
+def test_fwd_bwd_encoder_cnn_f32():
+    # encoder_cnn == "cnn" (encoder.py:54-56) and positional_embeddings false (encoder.py:60-65)
+    _grads_check("f32", 2e-5, 0.99999, dims=dict(cnn=True, positional=False))
+
+
+def test_fwd_bwd_encoder_cnn_bf16():
+    _grads_check("bf16", 1e-3, 0.97, dims=dict(cnn=True))
 
 
 def test_fwd_bwd_dropout_f32():

@@ -256,3 +256,35 @@ def test_greedy_attention_export_vs_oracle():
     n = steps.value
     assert np.array_equal(ids[:, :n], rid.numpy())
     assert np.abs(alpha[:n].transpose(1, 0, 2) - ralpha.numpy()).max() < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_encoder_cnn_variant_and_no_positional_vs_oracle(dtype):
+    """encoder_cnn == "cnn" (encoder.py:54-56: no late pools, (2,4) stride-2 SAME conv) with positional_embeddings
+    false (encoder.py:60-65 skipped): forward loss and every gradient against the oracle."""
+    import torch
+    from oracle import ref_model as R
+    img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
+    dims = dict(C=128, E=128, U=128, O=128, D=16, cnn=True, positional=False)
+    S = Sim(2, 32, 48, f.shape[1], 11, dtype=dtype, seed=2, dims=dims)
+    S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+    S.ck(S.L.lxo_decoder_train_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), None), "dec")
+    S.ck(S.L.lxo_ce_loss_fwd_bwd(S.sref(), ptr(S.ws), ptr(f), ptr(l), ctypes.c_float(1.0 / int(l.sum())), None), "loss")
+    S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), None), "decbwd")
+    S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 5, None), "encbwd")
+    S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 4, 1, None), "encbwd")
+    P = {k: torch.from_numpy(np.asarray(v)) for k, v in S.P.items()}
+    assert "Encoder/convolutional_encoder/conv2d_6/kernel" in P and P["Encoder/convolutional_encoder/conv2d_5/kernel"].shape == (2, 4, 128, 128)
+    loss, G, _, _ = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l), positional=False)
+    st = S.region("loss", np.float32)[:2]
+    if dtype == 0:
+        assert abs(st[0] / st[1] - float(loss)) < 5e-6
+        for k, _, _ in S.specs:
+            g, r = S.grad(k), G[k].numpy()
+            assert np.abs(g - r).max() <= 3e-5 * max(np.abs(r).max(), 1e-6) + 1e-9, k
+    else:
+        assert abs(st[0] / st[1] - float(loss)) / float(loss) < 1e-3
+        for k, _, _ in S.specs:
+            g, r = S.grad(k).reshape(-1), G[k].numpy().reshape(-1)
+            if np.abs(r).max() > 0:
+                assert float(g @ r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30) > 0.97, k
