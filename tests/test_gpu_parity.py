@@ -47,7 +47,7 @@ def test_fwd_bwd_bf16():
 
 def test_fwd_bwd_encoder_cnn_f32():
     # encoder_cnn == "cnn" (encoder.py:54-56) and positional_embeddings false (encoder.py:60-65)
-    _grads_check("f32", 2e-5, 0.99999, dims=dict(cnn=True, positional=False))
+    _grads_check("f32", 2e-5, 0.9999, dims=dict(cnn=True, positional=False))    # tiny attention gradients without the timing signal
 
 
 def test_fwd_bwd_encoder_cnn_bf16():
