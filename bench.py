@@ -173,6 +173,21 @@ def main():
         }
         out["roofline"] = roof
         out["roofline_attention"] = roof_att
+        if world == 1:
+            # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still
+            # inside their formula (same loss and gradients; the reference and `value` above run every padded step)
+            eng.skip_padded = True
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / args.steps
+            eng.skip_padded = False
+            out["extension_skip_padded_steps"] = {"value": round(B / dts, 2), "unit": "img/s", "ms_per_step": round(dts * 1e3, 3),
+                                                  "note": "not the headline metric: padded (sample, step) pairs skipped, batch sorted by length"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

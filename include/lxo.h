@@ -141,6 +141,15 @@ int lxo_set_side_stream(void* stream);
  * (attention_cell.py:58-89) under teacher forcing, logits for every step. */
 int lxo_decoder_train_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                           const int32_t* formula, void* stream);
+/* Extension (off by default; the reference runs every padded step, decoder.py:50-57): the same recurrence restricted
+ * to the live (sample, step) pairs.  The batch must be sorted by formula length, longest first;
+ * active_rows (HOST, T entries) = number of samples with length > t.  The skipped steps are dead code for the loss
+ * (masked at img2seq.py:68-71) and for every gradient, so loss and gradients are unchanged; their rows of the workspace
+ * regions "logits", "alpha", "rec" are not written.  The _bwd_active call must get the same active_rows. */
+int lxo_decoder_train_fwd_active(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                 const int32_t* formula, const int32_t* active_rows, void* stream);
+int lxo_decoder_train_bwd_active(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                 const int32_t* formula, float* grads, const int32_t* active_rows, void* stream);
 /* loss of model/img2seq.py:68-75 and d(loss)/d(logits).  inv_ntok = 1 / (number of
  * unmasked tokens in the GLOBAL batch).  ws region "loss" = {sum CE, token count}. */
 int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula,

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                       const float* __restrict__ c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
-                                                      float* __restrict__ dcc, float* __restrict__ dz, Drop dr, int B, int U) {
+                                                      float* __restrict__ dcc, float* __restrict__ dz, Drop dr, int carry_rows,
+                                                      int B, int U) {
     const int total = B * (U >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int b = i / (U >> 2), u = (i - b * (U >> 2)) << 2;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
         f32x4 dh = slab_sum4(s1, b, u) + slab_sum4(s3, b, u);          // d_h~ (o projection + attention)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dh[e] *= drop_scale(dr, 1u, b, u + e, U);
-        dh += slab_sum4(s4, b, off4 + u);                              // d_h carried by the next step's LSTM
+        if (b < carry_rows) dh += slab_sum4(s4, b, off4 + u);          // d_h carried by the next step's LSTM (rows that ran it)
         const f32x4 cc = *reinterpret_cast<const f32x4*>(c_cur + (long long)b * U + u);
         const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + (long long)b * U + u);
         const f32x4 dci = *reinterpret_cast<const f32x4*>(dcc + (long long)b * U + u);
@@ -198,12 +199,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 // g = (d_o from the logits + d_o carry) * (1 - o^2)      (backward through o = tanh(.), attention_cell.py:82)
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ a, int lda, Slabs carry,
                                                       const float* __restrict__ o, int ldo, float* __restrict__ g, int ldg,
-                                                      Drop dr, int rows, int cols) {
+                                                      Drop dr, int carry_rows, int rows, int cols) {
     const int total = rows * (cols >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int r = i / (cols >> 2), c = (i - r * (cols >> 2)) << 2;
         const f32x4 ov = *reinterpret_cast<const f32x4*>(o + (long long)r * ldo + c);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(a + (long long)r * lda + c) + slab_sum4(carry, r, c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(a + (long long)r * lda + c);
+        if (r < carry_rows) d += slab_sum4(carry, r, c);
         f32x4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -908,12 +910,12 @@ int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, 
     DONE;
 }
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
-                   float* dcc, float* dz, Drop dr, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U / 4), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, dr, B, U);
+                   float* dcc, float* dz, Drop dr, int carry_rows, int B, int U, hipStream_t st) {
+    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U / 4), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, dr, carry_rows, B, U);
     DONE;
 }
-int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, Drop dr, int rows, int cols, hipStream_t st) {
-    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, dr, rows, cols);
+int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, Drop dr, int carry_rows, int rows, int cols, hipStream_t st) {
+    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, dr, carry_rows, rows, cols);
     DONE;
 }
 __global__ __launch_bounds__(256) static void slab_reduce_kernel(Slabs sl, float* __restrict__ o, int ldo, int rows, int cols) {

@@ -6,9 +6,9 @@ int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t
 int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, hipStream_t st);
 int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, float* grads,
                          int last_layer, int first_layer, hipStream_t st);
-int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, hipStream_t st);
+int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, const int* active, hipStream_t st);
 int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, hipStream_t st);
-int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads, hipStream_t st);
+int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads, const int* active, hipStream_t st);
 int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, float* alpha_out, int* steps_out, hipStream_t st);
 int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, int* parents_out, int* steps_out, hipStream_t st);
 int lxo_impl_set_side_stream(hipStream_t s);

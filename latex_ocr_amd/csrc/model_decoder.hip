@@ -118,7 +118,11 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
     return 0;
 }
 
-int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, hipStream_t st) {
+// active (host, T entries, non-increasing, may be null): rows [0, active[t]) are the samples whose formula is longer
+// than t (batch sorted by length, longest first); the steps of the other rows are dead for the loss (masked,
+// img2seq.py:68-71) and for every gradient, so they are not run.  null = the reference's behaviour: all B rows, all T steps.
+int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, const int* active,
+                               hipStream_t st) {
     const int B = P.s.B, T = P.s.T, U = P.s.U, O = P.s.O, E = P.s.E, D = P.s.D, V = P.s.V;
     RC(attention_prepare(P, prm, wp, ws, 1, st));
     RC(lxo_k_embed_gather(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], formula, P.ws<void>(ws, W_EMB_IN), B, T, D, P.Dp, V, st));
@@ -126,17 +130,20 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     RC(nt(P, false, true, false, P.ws<void>(ws, W_EMB_IN), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, T * B, 4 * U, P.Dp,
           prm + P.poff[P_LSTM_B], 0, false, st));
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
-    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
-    const int nh = dual ? 2 : 1, hb = B / nh;
+    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
+    const int nh = dual ? 2 : 1;
     if (dual) RC(fork_side(st));
     for (int t = 0; t < T; ++t)
-        for (int h = 0; h < nh; ++h)
+        for (int h = 0; h < nh; ++h) {
+            const int hb = active ? active[t] : B / nh;
+            if (hb <= 0) continue;
             RC(cell_step(P, prm, wp, ws, h * hb, hb, 1, zx + (size_t)t * B * 4 * U,
                          rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
                          rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
                          P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
                          P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
                          P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, P.drop(t, h * hb), h ? g_side : st));
+        }
     if (dual) RC(join_side(st));
     // logits_t = o_t y_W_o for every step at once  (attention_cell.py:84)
     RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
@@ -151,7 +158,8 @@ int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* len
     return 0;
 }
 
-int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads, hipStream_t st) {
+int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads,
+                               const int* active, hipStream_t st) {
     const int B = P.s.B, T = P.s.T, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
     const int TB = T * B;
     auto gw = [&](int pid) { return grads + P.poff[pid]; };
@@ -168,12 +176,22 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
 
     HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
     HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));     // attention chunks accumulate d_att_h with atomics
-    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
-    const int nh = dual ? 2 : 1, hb = B / nh;
-    const int nchb = P.attn_chunks(hb);
+    if (active) {    // rows of skipped steps must read as zero in the deferred all-step GEMMs below
+        HIPRC(hipMemsetAsync(gall, 0, (size_t)TB * O * 4, st));
+        HIPRC(hipMemsetAsync(dhc, 0, (size_t)TB * P.HC * 4, st));
+        HIPRC(hipMemsetAsync(de, 0, (size_t)TB * P.Rp * 4, st));
+        HIPRC(hipMemsetAsync(dz, 0, (size_t)TB * 4 * U * 4, st));
+    }
+    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
+    const int nh = dual ? 2 : 1;
     if (dual) RC(fork_side(st));
     for (int t = T - 1; t >= 0; --t) {
         for (int h = 0; h < nh; ++h) {
+            const int hb = active ? active[t] : B / nh;
+            if (hb <= 0) continue;
+            // rows that also ran step t+1 receive its carries; the others end here (their later steps were skipped)
+            const int crows = (t == T - 1) ? 0 : (active ? active[t + 1] : hb);
+            const int nchb = P.attn_chunks(hb);
             hipStream_t sh = h ? g_side : st;
             const size_t r0 = (size_t)h * hb;
             float* sb1 = P.ws<float>(ws, W_S_B1) + r0 * (O / 128) * P.HC;
@@ -185,10 +203,10 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG) + r0 * P.R * E * P.esz;
             const char* img = (const char*)P.ws<void>(ws, W_IMG) + r0 * P.R * C * P.esz;
             // carry [d_o | d_h] from step t+1 = the B4 slabs of the previous iteration (none at t = T-1)
-            const Slabs carry = (t == T - 1) ? kNoSlabs : view(sb4, 4 * U, hb, P.XH);
+            const Slabs carry = (crows <= 0) ? kNoSlabs : view(sb4, 4 * U, crows, P.XH);
             // g = (d_o_logits + d_o_carry) * (1 - o^2)
             const Drop dr = P.drop(t, (int)r0);
-            RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, dr, hb, O, sh));
+            RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, dr, crows, hb, O, sh));
             // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
             RC(slab(P, g_t, O, P.pk(wp, K_OW), O, sb1, hb, P.HC, O, sh));
             RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + ((size_t)t * B + r0) * E, prm + P.poff[P_BETA],
@@ -197,7 +215,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             // d_h += d_att_h W_att_h^T
             RC(slab(P, datth + ((size_t)t * B + r0) * E, E, P.pk(wp, K_ATT_H), E, sb3, hb, U, E, sh));
             RC(lxo_k_lstm_bwd(gates + ((size_t)t * B + r0) * 4 * U, cs + ((size_t)t * B + r0) * U, cs + ((size_t)(t + 1) * B + r0) * U,
-                              view(sb1, O, hb, P.HC), view(sb3, E, hb, U), carry, O, dcc + r0 * U, dz + ((size_t)t * B + r0) * 4 * U, dr, hb, U, sh));
+                              view(sb1, O, hb, P.HC), view(sb3, E, hb, U), carry, O, dcc + r0 * U, dz + ((size_t)t * B + r0) * 4 * U, dr, crows, hb, U, sh));
             // [d_o carry | d_h carry] = d_z K[D:]^T
             RC(slab(P, dz + ((size_t)t * B + r0) * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
                     sb4, hb, P.XH, 4 * U, sh));
@@ -207,6 +225,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     // the final carries of the two halves are separate slab sets; gather them into one [B][XH] buffer
     float* dxh = P.ws<float>(ws, W_DXH);
     for (int h = 0; h < nh; ++h) {
+        const int hb = active ? active[0] : B / nh;       // every formula has at least its END token: step 0 runs all rows
         const size_t r0 = (size_t)h * hb;
         float* sb4 = P.ws<float>(ws, W_S_B4) + r0 * (4 * U / 128) * P.XH;
         RC(lxo_k_slab_reduce(view(sb4, 4 * U, hb, P.XH), dxh + r0 * P.XH, P.XH, hb, P.XH, st));

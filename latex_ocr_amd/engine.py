@@ -22,7 +22,7 @@ def _p(t):
 
 
 class Engine(object):
-    def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None):
+    def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None, skip_padded=None):
         self.lib = lib if lib is not None else _abi.load()
         self.device = torch.device(device)
         if self.device.type != "cuda" and lib is None:
@@ -31,6 +31,10 @@ class Engine(object):
         self.n_tok = int(n_tok)
         self.dtype = _abi.LXO_BF16 if dtype in ("bf16", 1) else _abi.LXO_F32
         self.beam, self.max_steps = int(beam), int(max_steps)
+        # extension, off by default (the reference runs every padded step): train_step sorts the batch by length and runs
+        # each decoder step only for the samples still inside their formula (lxo_decoder_train_*_active); same loss and gradients
+        self.skip_padded = (os.environ.get("LXO_SKIP_PADDED", "0") == "1") if skip_padded is None else bool(skip_padded)
+        self._active = None
         self.specs = PP.param_specs(self.n_tok, self.dims)
         self.n_params = PP.n_params(self.n_tok, self.dims)
         probe = self._shape(1, 32, 32, 1)
@@ -151,7 +155,7 @@ class Engine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
     # ---------------------------------------------------------------- steps --
-    def forward(self, img, formula, dropout=None):
+    def forward(self, img, formula, dropout=None, active_rows=None):
         """Encoder + teacher-forced decoder; leaves logits in the workspace.  dropout = (keep_prob, seed)
         applies tf.nn.dropout on h and o (attention_cell.py:72,83) with this step's counter-based masks;
         backward() regenerates the same masks from the bound shape."""
@@ -166,8 +170,14 @@ class Engine(object):
         st = self._stream()
         self._bind_side()
         self._ck(self.lib.lxo_encoder_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), st), "encoder_fwd")
-        self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
-                 "decoder_train_fwd")
+        self._active = None if active_rows is None else np.ascontiguousarray(active_rows, dtype=np.int32)
+        if self._active is None:
+            self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
+                     "decoder_train_fwd")
+        else:
+            assert self._active.shape == (T,)
+            self._ck(self.lib.lxo_decoder_train_fwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                           self._active.ctypes.data_as(ctypes.c_void_p), st), "decoder_train_fwd_active")
 
     def _bind_side(self):
         side = ctypes.c_void_p(self.side_stream.cuda_stream) if self.side_stream is not None else ctypes.c_void_p(0)
@@ -185,8 +195,13 @@ class Engine(object):
         st = self._stream()
         self._bind_side()
         self.grads.zero_()
-        self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                _p(self.grads), st), "decoder_train_bwd")
+        if self._active is None:
+            self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                    _p(self.grads), st), "decoder_train_bwd")
+        else:
+            self._ck(self.lib.lxo_decoder_train_bwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                           _p(self.grads), self._active.ctypes.data_as(ctypes.c_void_p), st),
+                     "decoder_train_bwd_active")
         if comm:
             comm(*self.buckets[0])
         self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
@@ -242,7 +257,10 @@ class Engine(object):
             self.drop_step = getattr(self, "drop_step", 0) + 1
             world, rank = (dist.world, dist.rank) if dist is not None else (1, 0)
             drop = (float(dropout), dropout_seed if dropout_seed is not None else self.drop_step * world + rank)
-        self.forward(img, formula, dropout=drop)
+        active = None
+        if self.skip_padded:
+            img, formula, lengths, active = self.sort_by_length(img, formula, lengths)
+        self.forward(img, formula, dropout=drop, active_rows=active)
         n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
         n_global = dist.sum_scalar(n_local) if dist is not None else n_local
         stats = self.loss(lengths, 1.0 / float(n_global))
@@ -259,6 +277,24 @@ class Engine(object):
         else:
             s = stats.cpu().numpy()
         return float(s[0]) / float(s[1])
+
+    def sort_by_length(self, img, formula, lengths):
+        """Longest formula first (stable), plus active_rows[t] = #samples with length > t for the *_active calls."""
+        l = lengths.cpu().numpy() if isinstance(lengths, torch.Tensor) else np.asarray(lengths)
+        order = np.argsort(-l, kind="stable")
+        T = int(formula.shape[1])
+        ls = l[order]
+        active = (ls[None, :] > np.arange(T)[:, None]).sum(axis=1).astype(np.int32)
+        if isinstance(img, torch.Tensor):
+            idx = torch.from_numpy(order).to(img.device)
+            img = img.index_select(0, idx)
+        else:
+            img = np.asarray(img)[order]
+        if isinstance(formula, torch.Tensor):
+            formula = formula.index_select(0, torch.from_numpy(order).to(formula.device))
+        else:
+            formula = np.asarray(formula)[order]
+        return img, formula, ls, active
 
     def evaluate_batch(self, img, formula, lengths):
         """(sum CE, n_words) of img2seq.py:74-75 for one batch (teacher forced)."""
