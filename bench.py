@@ -145,10 +145,10 @@ def main():
             except Exception:
                 traffic = None
         # dominant kernel: conv_halo256_kernel (the 8x32-pixel x 256-channel halo tiles; 7 of the 10 conv launches)
-        dom = [l for l in per if l["kernel"] == "conv_halo256_kernel"] or per
-        dflops, dsecs = sum(l["flops"] for l in dom), sum(l["us"] for l in dom) * 1e-6
-        for l in per:
-            l.pop("flops", None)
+        dom = [x for x in per if x["kernel"] == "conv_halo256_kernel"] or per
+        dflops, dsecs = sum(x["flops"] for x in dom), sum(x["us"] for x in dom) * 1e-6
+        for x in per:
+            x.pop("flops", None)
         roof = {"kernel": "%s (bf16 implicit-GEMM 3x3 conv, halo tiles): %d of the %d conv forward/dgrad launches of a step"
                           % (dom[0]["kernel"], len(dom), len(per)),
                 "bound": "mfma", "achieved": round(dflops / dsecs / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
