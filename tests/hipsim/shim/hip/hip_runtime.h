@@ -117,7 +117,9 @@ template <class T> inline T __builtin_amdgcn_readfirstlane_sim(T v) {
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipsim::syncthreads()
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
-#define __builtin_amdgcn_s_waitcnt(n) ((void)0)
+// a counted wait is executed by the whole wave: rendezvous its live lanes so that LDS-DMA pieces issued by
+// other lanes of the SAME wave have been copied before this lane reads them (the hardware lands a wave's DMA as a unit)
+#define __builtin_amdgcn_s_waitcnt(n) hipsim::wave_sync()
 
 // ---- atomics (single host thread: plain read-modify-write) ----
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

@@ -151,3 +151,30 @@ def test_conv3x3_ex_full_epilogue_bf16(B, H, W, Cin, Cout, pad):
     assert (out.float().cpu().double() - y).abs().max().item() / s < 6e-3
     rcs = y.reshape(-1, Cout).sum(0)
     assert (cs.cpu().double() - rcs).abs().max().item() / rcs.abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("dt,nv,nimg,R,E,C", [(1, 64, 64, 868, 256, 512), (1, 6, 2, 84, 256, 512), (1, 3, 3, 37, 256, 512),
+                                              (1, 4, 4, 100, 128, 256), (0, 5, 5, 84, 256, 512)])
+def test_attention_fwd_vs_float64(dt, nv, nimg, R, E, C):
+    """AttentionMechanism.context (attention_mechanism.py:46-94): scores, softmax over regions, context -- the LDS-DMA
+    stream kernel (bf16, E=256, C=512), the register-staged kernel (other widths / f32) and the chunk combine."""
+    L = _lib()
+    g = torch.Generator().manual_seed(R + nv)
+    beam = nv // nimg
+    cdt = torch.bfloat16 if dt == 1 else torch.float32
+    att_img = torch.randn(nimg, R, E, generator=g).to(cdt); img = torch.randn(nimg, R, C, generator=g).to(cdt)
+    att_h = torch.randn(nv, E, generator=g); beta = torch.randn(E, generator=g) * 0.3
+    Rp = (R + 7) // 8 * 8
+    alpha = torch.zeros(nv, Rp, device="cuda"); part = torch.zeros(nv * 32 * (C + 2), device="cuda"); ctx = torch.zeros(nv, C, device="cuda")
+    a_d, i_d, h_d, b_d = att_img.cuda(), img.cuda(), att_h.cuda(), beta.cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.lxo_attention_fwd(dt, _p(a_d), _p(i_d), _p(h_d), _p(b_d), _p(alpha), _p(part), _p(ctx), C, nv, R, E, C, beam, st)
+    assert rc == 0, L.lxo_last_error()
+    torch.cuda.synchronize()
+    idx = torch.arange(nv) // beam
+    e = (torch.tanh(att_img.double()[idx] + att_h.double()[:, None, :]) * beta.double()).sum(-1)
+    a = torch.softmax(e, dim=-1)
+    c = (a[:, :, None] * img.double()[idx]).sum(1)
+    tol = 2e-5 if dt == 1 else 2e-6          # bf16 mode: fast tanh (1 - 2 rcp(exp(2x)+1)) on exact bf16 inputs
+    assert (alpha[:, :R].cpu().double() - a).abs().max().item() < tol
+    assert (ctx.cpu().double() - c).abs().max().item() < 50 * tol
