@@ -393,11 +393,6 @@ __global__ __launch_bounds__(512) void attn_fwd_lds_kernel(const bf16_t* __restr
     float* pout = part + ((long long)v * nch + ch) * (C + 2);
     char* ring = lxo_att_lds + wave * AL_WAVE;
     float* scw = reinterpret_cast<float*>(lxo_att_lds + AL_SC) + wave * 2 * AL_MAXP;
-    const int k0 = lane * 4;
-    const f32x4 ah = ahs.n > 0 ? slab_sum4(ahs, v, k0) : *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + k0);
-    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + k0);
-    if (ahs.n > 0 && att_h_out && ch == 0 && wave == 0) *reinterpret_cast<f32x4*>(att_h_out + (long long)v * E + k0) = ah;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): from here on only the DMA is counted
     const int npairs = n > 0 ? (n + 1) >> 1 : 0;
     const int nmine = npairs > wave ? (npairs - wave + ATT_W - 1) / ATT_W : 0;
     auto issue = [&](int j) {
@@ -408,12 +403,21 @@ __global__ __launch_bounds__(512) void attn_fwd_lds_kernel(const bf16_t* __restr
         att_glds16(im + (long long)ra * C + lane * 8, sl + 1024);
         att_glds16(im + (long long)rb * C + lane * 8, sl + 2048);
     };
+    // the first row pairs go out BEFORE the att_h slabs are fetched (they do not depend on them); one full drain
+    // then covers both, and from the second pair on only the DMA is counted
     for (int j = 0; j < AL_NP && j < nmine; ++j) issue(j);
+    const int k0 = lane * 4;
+    const f32x4 ah = ahs.n > 0 ? slab_sum4(ahs, v, k0) : *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + k0);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + k0);
+    if (ahs.n > 0 && att_h_out && ch == 0 && wave == 0) *reinterpret_cast<f32x4*>(att_h_out + (long long)v * E + k0) = ah;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+    asm volatile("" ::: "memory");
     float m = -3.0e38f, l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     for (int j = 0; j < nmine; ++j) {
-        const int ahead = min(nmine - 1 - j, AL_NP - 1);      // pairs issued after pair j
+        // pairs issued after pair j that may still be in flight (none during the first AL_NP: everything was drained)
+        const int ahead = j < AL_NP ? min(j, min(nmine - 1 - j, AL_NP - 1)) : min(nmine - 1 - j, AL_NP - 1);
         if (ahead >= 2) ATT_VMCNT(6);
         else if (ahead == 1) ATT_VMCNT(3);
         else ATT_VMCNT(0);
