@@ -5,8 +5,6 @@
 #include "api_util.h"
 #include <stdlib.h>
 
-HIP_DYNAMIC_SHARED(char, lxo_att_lds)
-
 namespace {
 
 
@@ -362,127 +360,6 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
     }
 }
 
-
-// ---- LDS-DMA variant of the forward stream (bf16, E = 256, C = 512) ----
-// Same arithmetic as attn_fwd_part_kernel, but the att_img / img rows are pulled straight into a per-wave LDS
-// ring by global_load_lds (no VGPRs held by loads in flight): three row PAIRS = 6 rows x 1.5 KB stay in flight
-// per wave while the previous pair is being reduced, 144 KB per CU at two workgroups per CU, instead of 4 rows
-// per wave that all have to land before any arithmetic starts.  A pair slot = [att row a | att row b (2 x 512 B)]
-// [img row a (1 KB)][img row b (1 KB)]; lanes 0-31 fetch row a's att_img line and lanes 32-63 row b's in ONE DMA.
-// No global stores inside the loop (stores share vmcnt with the counted DMA waits): raw scores go through LDS.
-typedef __attribute__((address_space(1))) const void* att_gptr_t;
-typedef __attribute__((address_space(3))) void* att_lptr_t;
-LXO_DEV void att_glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((att_gptr_t)(uintptr_t)g, (att_lptr_t)(uintptr_t)l, 16, 0, 0);
-}
-#define ATT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
-constexpr int AL_NP = 3, AL_PAIR = 3072, AL_WAVE = AL_NP * AL_PAIR, AL_MAXP = 16;       // pairs in flight, bytes, max pairs per wave
-constexpr int AL_SC = ATT_W * AL_WAVE, AL_RED = AL_SC + ATT_W * 2 * AL_MAXP * 4, AL_BYTES = AL_RED + 2 * ATT_W * 4;
-
-__global__ __launch_bounds__(512) void attn_fwd_lds_kernel(const bf16_t* __restrict__ att_img, const bf16_t* __restrict__ img,
-                                                          const float* __restrict__ att_h, Slabs ahs, float* __restrict__ att_h_out,
-                                                          const float* __restrict__ beta, float* __restrict__ alpha, float* __restrict__ part,
-                                                          int R, int Rp, int beam, int nch, int rows_per) {
-    constexpr int E = 256, C = 512;
-    const int ch = blockIdx.x, v = blockIdx.y, bi = v / beam;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = ch * rows_per;
-    const int n = min(R, r0 + rows_per) - r0;          // may be <= 0 for a trailing chunk
-    const bf16_t* ai = att_img + ((long long)bi * R + r0) * E;
-    const bf16_t* im = img + ((long long)bi * R + r0) * C;
-    float* pout = part + ((long long)v * nch + ch) * (C + 2);
-    char* ring = lxo_att_lds + wave * AL_WAVE;
-    float* scw = reinterpret_cast<float*>(lxo_att_lds + AL_SC) + wave * 2 * AL_MAXP;
-    const int npairs = n > 0 ? (n + 1) >> 1 : 0;
-    const int nmine = npairs > wave ? (npairs - wave + ATT_W - 1) / ATT_W : 0;
-    auto issue = [&](int j) {
-        const int p = wave + ATT_W * j;
-        const int ra = 2 * p, rb = min(2 * p + 1, n - 1);
-        char* sl = ring + (j % AL_NP) * AL_PAIR;
-        att_glds16(ai + (long long)(lane < 32 ? ra : rb) * E + (lane & 31) * 8, sl);
-        att_glds16(im + (long long)ra * C + lane * 8, sl + 1024);
-        att_glds16(im + (long long)rb * C + lane * 8, sl + 2048);
-    };
-    // the first row pairs go out BEFORE the att_h slabs are fetched (they do not depend on them); one full drain
-    // then covers both, and from the second pair on only the DMA is counted
-    for (int j = 0; j < AL_NP && j < nmine; ++j) issue(j);
-    const int k0 = lane * 4;
-    const f32x4 ah = ahs.n > 0 ? slab_sum4(ahs, v, k0) : *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + k0);
-    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + k0);
-    if (ahs.n > 0 && att_h_out && ch == 0 && wave == 0) *reinterpret_cast<f32x4*>(att_h_out + (long long)v * E + k0) = ah;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
-    asm volatile("" ::: "memory");
-    float m = -3.0e38f, l = 0.f, acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int j = 0; j < nmine; ++j) {
-        // pairs issued after pair j that may still be in flight (none during the first AL_NP: everything was drained)
-        const int ahead = j < AL_NP ? min(j, min(nmine - 1 - j, AL_NP - 1)) : min(nmine - 1 - j, AL_NP - 1);
-        if (ahead >= 2) ATT_VMCNT(6);
-        else if (ahead == 1) ATT_VMCNT(3);
-        else ATT_VMCNT(0);
-        asm volatile("" ::: "memory");
-        const char* sl = ring + (j % AL_NP) * AL_PAIR;
-        const u32x2 xa = *reinterpret_cast<const u32x2*>(sl + lane * 8), xb = *reinterpret_cast<const u32x2*>(sl + 512 + lane * 8);
-        const u32x4 ia = *reinterpret_cast<const u32x4*>(sl + 1024 + lane * 16), ib = *reinterpret_cast<const u32x4*>(sl + 2048 + lane * 16);
-        const bool has_b = 2 * (wave + ATT_W * j) + 1 < n;
-        float pa = 0.f, pb = 0.f;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            pa = fmaf(tanh_ct<bf16_t>(__uint_as_float(xa[w] << 16) + ah[2 * w]), bt[2 * w], pa);
-            pa = fmaf(tanh_ct<bf16_t>(__uint_as_float(xa[w] & 0xffff0000u) + ah[2 * w + 1]), bt[2 * w + 1], pa);
-            pb = fmaf(tanh_ct<bf16_t>(__uint_as_float(xb[w] << 16) + ah[2 * w]), bt[2 * w], pb);
-            pb = fmaf(tanh_ct<bf16_t>(__uint_as_float(xb[w] & 0xffff0000u) + ah[2 * w + 1]), bt[2 * w + 1], pb);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o); pb += __shfl_xor(pb, o); }
-        const float mn = has_b ? fmaxf(m, fmaxf(pa, pb)) : fmaxf(m, pa);
-        const float sc = expf(m - mn);
-        m = mn;
-        const float wa = expf(pa - m), wb = has_b ? expf(pb - m) : 0.f;
-        l = l * sc + wa + wb;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            acc[2 * w] = fmaf(wb, __uint_as_float(ib[w] << 16), fmaf(wa, __uint_as_float(ia[w] << 16), acc[2 * w] * sc));
-            acc[2 * w + 1] = fmaf(wb, __uint_as_float(ib[w] & 0xffff0000u), fmaf(wa, __uint_as_float(ia[w] & 0xffff0000u), acc[2 * w + 1] * sc));
-        }
-        if (lane == 0) { scw[2 * j] = pa; scw[2 * j + 1] = pb; }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this slot's ds_reads have retired before it is refilled
-        asm volatile("" ::: "memory");
-        if (j + AL_NP < nmine) issue(j + AL_NP);
-    }
-    // raw scores -> alpha (attn_fwd_combine normalises them)
-    if (lane < 2 * nmine) {
-        const int r = 2 * (wave + ATT_W * (lane >> 1)) + (lane & 1);
-        if (r < n) alpha[(long long)v * Rp + r0 + r] = scw[lane];
-    }
-    // merge the 8 waves (the rings are idle now: reuse them for the context partials)
-    float* red = reinterpret_cast<float*>(lxo_att_lds + AL_RED);
-    float* redc = reinterpret_cast<float*>(lxo_att_lds);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    float mc = red[0];
-#pragma unroll
-    for (int w = 1; w < ATT_W; ++w) mc = fmaxf(mc, red[w]);
-    const float sw = (l > 0.f) ? expf(m - mc) : 0.f;
-    if (lane == 0) red[ATT_W + wave] = l * sw;
-    const int c0 = lane * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) redc[wave * C + c0 + e] = acc[e] * sw;
-    __syncthreads();
-    if (tid == 0) {
-        float lt = 0.f;
-#pragma unroll
-        for (int w = 0; w < ATT_W; ++w) lt += red[ATT_W + w];
-        pout[0] = mc; pout[1] = lt;
-    }
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < ATT_W; ++w) t += redc[w * C + tid];
-        pout[2 + tid] = t;
-    }
-}
 
 // merge the chunk partials: alpha = exp(e - m) / l ; ctx = sum_c ctx_c exp(m_c - m) / l.
 // grid (4, nv): every workgroup recomputes the (tiny) chunk scales in registers, then handles a
@@ -1068,16 +945,6 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     const int rows_per = cdiv(R, nch);
     if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
-    static int use_lds = -1;
-    if (use_lds < 0) { const char* e = getenv("LXO_ATT_LDS"); use_lds = (e && e[0] == '0') ? 0 : 1; }
-    if (use_lds && dt == LXO_BF16 && E == 256 && C == 512 && rows_per <= 2 * ATT_W * AL_MAXP) {
-        static bool attr = false;
-        if (!attr) { HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AL_BYTES)); attr = true; }
-        hipLaunchKernelGGL(attn_fwd_lds_kernel, grid, dim3(512), AL_BYTES, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, ahs, att_h_out,
-                           beta, alpha, part, R, Rp, beam, nch, rows_per);
-        hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
-        DONE;
-    }
 #define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per
     if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
