@@ -489,26 +489,34 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
         const char* ps = patch0 + (c & 1) * QPATCH;
         const char* bs = bst0 + (t & 1) * QB_STAGE;
         const int prow_t = a_prow0 + kh * QPW + kw;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        // fragments of the next 16-wide k slice are read (two register sets) before the MFMAs of the current one
+        // issue, so that the LDS latency is covered by the matrix pipe instead of an lgkmcnt(0) wait in front of
+        // every MFMA pair (what the compiler schedules on its own)
+        u32x4 af[2][4], bfr[2][2];
+        auto ldfrag = [&](int ks, u32x4 (&a4)[4], u32x4 (&b2)[2]) {
             const int kc = ks * 2 + khalf;
-            u32x4 af[4], bfr[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int br = b_row0 + 32 * j;
-                bfr[j] = *reinterpret_cast<const u32x4*>(bs + br * 128 + ((kc ^ ((br >> 1) & 7)) << 4));
+                b2[j] = *reinterpret_cast<const u32x4*>(bs + br * 128 + ((kc ^ ((br >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int prow = prow_t + i * QPW;
-                af[i] = *reinterpret_cast<const u32x4*>(ps + prow * 128 + ((kc ^ ((prow >> 1) & 7)) << 4));
+                a4[i] = *reinterpret_cast<const u32x4*>(ps + prow * 128 + ((kc ^ ((prow >> 1) & 7)) << 4));
             }
+        };
+        ldfrag(0, af[0], bfr[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) ldfrag(ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);          // keep "reads of slice ks+1, then MFMAs of slice ks" as written
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]),
-                                                                        acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ks & 1][i]),
+                                                                        __builtin_bit_cast(bf16x8_t, bfr[ks & 1][j]), acc[i][j], 0, 0, 0);
         }
     }
 

@@ -115,6 +115,7 @@ template <class T> inline T __builtin_amdgcn_readfirstlane_sim(T v) {
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_sim(v)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipsim::syncthreads()
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 // a counted wait is executed by the whole wave: rendezvous its live lanes so that LDS-DMA pieces issued by
