@@ -554,13 +554,18 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
                         else { a[tt][0] = a[tt][1] = a[tt][2] = a[tt][3] = 0.f; d[tt] = 0.f; }
                     }
 #pragma unroll
-                    for (int tt = 0; tt < 8; ++tt)
+                    for (int tt = 0; tt < 8; ++tt) {
+                        // d_e is wave-uniform and exactly 0 for every padded (sample, step) pair (the loss mask zeroes
+                        // the whole gradient flow of those steps): their 256 tanh evaluations contribute nothing
+                        const float dd = d[tt];
+                        if (dd == 0.f) continue;            // same value in every lane: the branch skips the whole wave
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float tau = tanh_ct<CT>(x[kc][j] + a[tt][j]);
-                            acc[kc][j] = fmaf(d[tt], 1.f - tau * tau, acc[kc][j]);
-                            db[kc][j] = fmaf(d[tt], tau, db[kc][j]);
+                            acc[kc][j] = fmaf(dd, 1.f - tau * tau, acc[kc][j]);
+                            db[kc][j] = fmaf(dd, tau, db[kc][j]);
                         }
+                    }
                 }
             }
         }
@@ -598,36 +603,43 @@ __global__ __launch_bounds__(256) void add_mean_grad_kernel(float* __restrict__ 
     }
 }
 
-// loss of img2seq.py:68-75 + gradient; one wave per (t, b) row
+// loss of img2seq.py:68-75 + gradient; one wave per (t, b) row, rows strided over the grid; the two loss statistics
+// are summed per workgroup first (one atomic pair per workgroup instead of one per token: the tokens all hit the same
+// two addresses)
 template <typename CT>
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int* __restrict__ formula,
                                                      const int* __restrict__ lengths, CT* __restrict__ dlogits,
                                                      float* __restrict__ loss_acc, float inv_ntok, int B, int T, int V, int Vp) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= T * B) return;                              // wave-uniform exit
-    const int t = row / B, b = row - t * B;
-    const float* lg = logits + (long long)row * Vp;
-    CT* dl = dlogits + (long long)row * Vp;
-    const bool valid = t < lengths[b];
-    int tgt = formula[(long long)b * T + t];
-    tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
-    float m = -3.0e38f;
-    for (int j = lane; j < V; j += 64) m = fmaxf(m, lg[j]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int j = lane; j < V; j += 64) l += expf(lg[j] - m);
-    l = wave_sum(l);
-    const float lse = m + logf(l);
-    const float scale = valid ? inv_ntok : 0.f;
-    for (int j = lane; j < Vp; j += 64) {
-        float g = 0.f;
-        if (j < V) g = (expf(lg[j] - lse) - (j == tgt ? 1.f : 0.f)) * scale;
-        dl[j] = from_f32<CT>(g);
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ce_sum = 0.f, n_sum = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < T * B; row += gridDim.x * 4) {
+        const int t = row / B, b = row - t * B;
+        const float* lg = logits + (long long)row * Vp;
+        CT* dl = dlogits + (long long)row * Vp;
+        const bool valid = t < lengths[b];
+        int tgt = formula[(long long)b * T + t];
+        tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+        float m = -3.0e38f;
+        for (int j = lane; j < V; j += 64) m = fmaxf(m, lg[j]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int j = lane; j < V; j += 64) l += expf(lg[j] - m);
+        l = wave_sum(l);
+        const float lse = m + logf(l);
+        const float scale = valid ? inv_ntok : 0.f;
+        for (int j = lane; j < Vp; j += 64) {
+            float g = 0.f;
+            if (j < V) g = (expf(lg[j] - lse) - (j == tgt ? 1.f : 0.f)) * scale;
+            dl[j] = from_f32<CT>(g);
+        }
+        if (valid) { ce_sum += lse - lg[tgt]; n_sum += 1.0f; }      // wave-uniform values
     }
-    if (lane == 0 && valid) {
-        atomicAdd(&loss_acc[0], lse - lg[tgt]);
-        atomicAdd(&loss_acc[1], 1.0f);
+    if (lane == 0) { red[wave] = ce_sum; red[4 + wave] = n_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float c = red[0] + red[1] + red[2] + red[3], n = red[4] + red[5] + red[6] + red[7];
+        if (n > 0.f) { atomicAdd(&loss_acc[0], c); atomicAdd(&loss_acc[1], n); }
     }
 }
 
@@ -989,7 +1001,8 @@ int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hi
 }
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
                   int B, int T, int V, int Vp, hipStream_t st) {
-    const int g = cdiv(T * B, 4);
+    int g = cdiv(T * B, 4);
+    if (g > 512) g = 512;
     if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, inv_ntok, B, T, V, Vp);
     else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, inv_ntok, B, T, V, Vp);
     DONE;
