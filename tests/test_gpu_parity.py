@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 from gpu_common import *  # noqa
 
 
-def _grads_check(dtype, tol_loss, min_cos, dropout=None, dims=None):
+def _grads_check(dtype, tol_loss, min_cos, dropout=None, dims=None, hw=(32, 128), n=6):
     V = 50
-    img, f, l = batch(6, 32, 128, V, 5, 12, seed=7)
+    img, f, l = batch(n, hw[0], hw[1], V, 5, 12, seed=7)
     eng = Engine(V, dtype=dtype, seed=3, dims=dims)
     P = oracle_params(eng)
     positional = (dims or {}).get("positional", True)
@@ -43,6 +43,15 @@ def test_fwd_bwd_f32():
 
 def test_fwd_bwd_bf16():
     _grads_check("bf16", 1e-3, 0.98)
+
+
+def test_fwd_bwd_odd_image_shape_f32():
+    # SAME pools with odd extents at every level (37 -> 19 -> 10 -> 5, 141 -> 71 -> 36 -> 18), partial conv tiles, batch 3
+    _grads_check("f32", 2e-5, 0.99999, hw=(37, 141), n=3)
+
+
+def test_fwd_bwd_odd_image_shape_bf16():
+    _grads_check("bf16", 1e-3, 0.97, hw=(37, 141), n=3)
 
 
 def test_fwd_bwd_encoder_cnn_f32():
