@@ -27,11 +27,10 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const uint8_t* __re
         for (int e = 0; e < 8; ++e) wr[t][e] = w[t * 64 + cg * 8 + e];
 #pragma unroll
     for (int e = 0; e < 8; ++e) br[e] = bias[cg * 8 + e];
-    const long long npix = (long long)B * Hp * Wp;
-    for (long long pix = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (long long)gridDim.x * 32) {
-        const int px = (int)(pix % Wp);
-        const int py = (int)((pix / Wp) % Hp);
-        const int b = (int)(pix / ((long long)Wp * Hp));
+    const int npix = B * Hp * Wp;               // < 2^31 (validated by the plan)
+    for (int pix = blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += gridDim.x * 32) {
+        const int row = pix / Wp, px = pix - row * Wp;          // 32-bit index arithmetic: the 64-bit div/mod dominated this kernel
+        const int b = row / Hp, py = row - b * Hp;
         const uint8_t* im = img + (long long)b * H * W;
         float patch[4][4];
 #pragma unroll
@@ -39,7 +38,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const uint8_t* __re
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 const int y = 2 * py - 1 + dy, x = 2 * px - 1 + dx;
-                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? ((float)im[(long long)y * W + x] - 128.f) / 128.f : 0.f;
+                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? fmaf((float)im[y * W + x], 0.0078125f, -1.0f) : 0.f;   // (v - 128) / 128, exact
             }
         float best[8];
 #pragma unroll
@@ -59,7 +58,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const uint8_t* __re
                     best[e] = fmaxf(best[e], fmaxf(a, 0.f));
                 }
             }
-        store8(out + pix * 64 + cg * 8, best);
+        store8(out + (long long)pix * 64 + cg * 8, best);
     }
 }
 
@@ -77,15 +76,14 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __re
         for (int e = 0; e < 8; ++e) { wr[t][e] = w[t * 64 + cg * 8 + e]; gw[t][e] = 0.f; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { br[e] = bias[cg * 8 + e]; gb[e] = 0.f; }
-    const long long npix = (long long)B * Hp * Wp;
+    const int npix = B * Hp * Wp;
     // every lane iterates the same number of times so the wave stays convergent
-    const long long iters = (npix + (long long)gridDim.x * 32 - 1) / ((long long)gridDim.x * 32);
-    for (long long it = 0; it < iters; ++it) {
-        const long long pix = (it * gridDim.x + blockIdx.x) * 32 + (threadIdx.x >> 3);
+    const int iters = (npix + (int)gridDim.x * 32 - 1) / ((int)gridDim.x * 32);
+    for (int it = 0; it < iters; ++it) {
+        const int pix = (it * (int)gridDim.x + (int)blockIdx.x) * 32 + (threadIdx.x >> 3);
         if (pix >= npix) continue;
-        const int px = (int)(pix % Wp);
-        const int py = (int)((pix / Wp) % Hp);
-        const int b = (int)(pix / ((long long)Wp * Hp));
+        const int row = pix / Wp, px = pix - row * Wp;
+        const int b = row / Hp, py = row - b * Hp;
         const uint8_t* im = img + (long long)b * H * W;
         float patch[4][4];
 #pragma unroll
@@ -93,10 +91,10 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __re
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 const int y = 2 * py - 1 + dy, x = 2 * px - 1 + dx;
-                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? ((float)im[(long long)y * W + x] - 128.f) / 128.f : 0.f;
+                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? fmaf((float)im[y * W + x], 0.0078125f, -1.0f) : 0.f;
             }
         float g[8];
-        load8(dout + pix * 64 + cg * 8, g);
+        load8(dout + (long long)pix * 64 + cg * 8, g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float best = -3.0e38f; int bq = 0;
@@ -162,11 +160,11 @@ template <typename CT>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const CT* __restrict__ in, CT* __restrict__ out,
                                                          int B, int H, int W, int C, int ph, int pw, int Ho, int Wo) {
     const int cgs = C >> 3;
-    const long long total = (long long)B * Ho * Wo * cgs;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cg = (int)(i % cgs);
-        const long long pix = i / cgs;
-        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+    const int total = B * Ho * Wo * cgs;          // < 2^31 for every shape the plan accepts; 32-bit index arithmetic
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int pix = i / cgs, cg = i - pix * cgs;
+        const int row = pix / Wo, ox = pix - row * Wo;
+        const int b = row / Ho, oy = row - b * Ho;
         float best[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) best[e] = -3.0e38f;
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const CT* __restrict__
 #pragma unroll
                 for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
             }
-        store8(out + pix * C + cg * 8, best);
+        store8(out + (long long)pix * C + cg * 8, best);
     }
 }
 
@@ -194,12 +192,13 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const CT* __restr
     const int cgs = C >> 3;                   // divides 256 (C in {64,128,256,512})
     const int cg = threadIdx.x % cgs;
     const int ppb = 256 / cgs;                // pooled pixels per block per iteration
-    const long long npix = (long long)B * Ho * Wo;
+    const int npix = B * Ho * Wo;
     float gb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gb[e] = 0.f;
-    for (long long pix = (long long)blockIdx.x * ppb + threadIdx.x / cgs; pix < npix; pix += (long long)gridDim.x * ppb) {
-        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+    for (int pix = blockIdx.x * ppb + threadIdx.x / cgs; pix < npix; pix += gridDim.x * ppb) {
+        const int row = pix / Wo, ox = pix - row * Wo;
+        const int b = row / Ho, oy = row - b * Ho;
         float best[8]; int bq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { best[e] = -3.0e38f; bq[e] = 0; }
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const CT* __restr
                     if (v[e] > best[e]) { best[e] = v[e]; bq[e] = qy * pw + qx; }
             }
         float g[8];
-        load8(dp + pix * C + cg * 8, g);
+        load8(dp + (long long)pix * C + cg * 8, g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { g[e] = best[e] > 0.f ? g[e] : 0.f; gb[e] += g[e]; }
         for (int qy = 0; qy < ph; ++qy)
