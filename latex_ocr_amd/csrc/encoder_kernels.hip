@@ -48,14 +48,20 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const uint8_t* __re
 #pragma unroll
             for (int qx = 0; qx < 2; ++qx) {
                 if (2 * py + qy >= H || 2 * px + qx >= W) continue;   // SAME pool ignores padding
+                // channel PAIRS on the packed-f32 FMA (v_pk_fma_f32: two lanes' worth of FMAs per issue slot)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float a = br[e];
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 a = {br[e], br[e + 1]};
 #pragma unroll
                     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) a = fmaf(patch[qy + kh][qx + kw], wr[kh * 3 + kw][e], a);
-                    best[e] = fmaxf(best[e], fmaxf(a, 0.f));
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const f32x2 pp = {patch[qy + kh][qx + kw], patch[qy + kh][qx + kw]};
+                            const f32x2 ww = {wr[kh * 3 + kw][e], wr[kh * 3 + kw][e + 1]};
+                            a = __builtin_elementwise_fma(pp, ww, a);
+                        }
+                    best[e] = fmaxf(best[e], fmaxf(a[0], 0.f));
+                    best[e + 1] = fmaxf(best[e + 1], fmaxf(a[1], 0.f));
                 }
             }
         store8(out + (long long)pix * 64 + cg * 8, best);
@@ -95,33 +101,44 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __re
             }
         float g[8];
         load8(dout + (long long)pix * 64 + cg * 8, g);
+        // channel PAIRS on the packed-f32 FMA; the weight gradient adds d * patch for all four pool positions with d
+        // zeroed outside the winning one (4 packed FMAs instead of one FMA + three selects per tap and channel)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float best = -3.0e38f; int bq = 0;
+        for (int e = 0; e < 8; e += 2) {
+            float best0 = -3.0e38f, best1 = -3.0e38f; int bq0 = 0, bq1 = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int qy = q >> 1, qx = q & 1;
                 if (2 * py + qy >= H || 2 * px + qx >= W) continue;
-                float a = br[e];
+                f32x2 a = {br[e], br[e + 1]};
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) a = fmaf(patch[qy + kh][qx + kw], wr[kh * 3 + kw][e], a);
-                a = fmaxf(a, 0.f);
-                if (a > best) { best = a; bq = q; }
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const f32x2 pp = {patch[qy + kh][qx + kw], patch[qy + kh][qx + kw]};
+                        const f32x2 ww = {wr[kh * 3 + kw][e], wr[kh * 3 + kw][e + 1]};
+                        a = __builtin_elementwise_fma(pp, ww, a);
+                    }
+                const float a0 = fmaxf(a[0], 0.f), a1 = fmaxf(a[1], 0.f);
+                if (a0 > best0) { best0 = a0; bq0 = q; }
+                if (a1 > best1) { best1 = a1; bq1 = q; }
             }
-            const float d = best > 0.f ? g[e] : 0.f;
-            gb[e] += d;
-            const int qy = bq >> 1, qx = bq & 1;
+            const float d0 = best0 > 0.f ? g[e] : 0.f, d1 = best1 > 0.f ? g[e + 1] : 0.f;
+            gb[e] += d0; gb[e + 1] += d1;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+            for (int q = 0; q < 4; ++q) {
+                const int qy = q >> 1, qx = q & 1;
+                const f32x2 dq = {bq0 == q ? d0 : 0.f, bq1 == q ? d1 : 0.f};
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    // select the patch element of the winning position without dynamic register indexing
-                    const float x00 = patch[kh][kw], x01 = patch[kh][kw + 1], x10 = patch[kh + 1][kw], x11 = patch[kh + 1][kw + 1];
-                    const float xv = qy ? (qx ? x11 : x10) : (qx ? x01 : x00);
-                    gw[kh * 3 + kw][e] = fmaf(xv, d, gw[kh * 3 + kw][e]);
-                }
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const f32x2 pp = {patch[qy + kh][qx + kw], patch[qy + kh][qx + kw]};
+                        f32x2 acc2 = {gw[kh * 3 + kw][e], gw[kh * 3 + kw][e + 1]};
+                        acc2 = __builtin_elementwise_fma(pp, dq, acc2);
+                        gw[kh * 3 + kw][e] = acc2[0]; gw[kh * 3 + kw][e + 1] = acc2[1];
+                    }
+            }
         }
     }
     // reduce over the 8 lanes-groups of a wave that share a channel group (lane bits 3..5)
