@@ -27,19 +27,31 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const uint8_t* __re
         for (int e = 0; e < 8; ++e) wr[t][e] = w[t * 64 + cg * 8 + e];
 #pragma unroll
     for (int e = 0; e < 8; ++e) br[e] = bias[cg * 8 + e];
-    const int npix = B * Hp * Wp;               // < 2^31 (validated by the plan)
-    for (int pix = blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += gridDim.x * 32) {
-        const int row = pix / Wp, px = pix - row * Wp;          // 32-bit index arithmetic: the 64-bit div/mod dominated this kernel
+    // A workgroup walks segments of 32 pooled pixels of one pooled row: the 4 x 66 input bytes they touch are staged
+    // ONCE through LDS (normalised to float) instead of 16 predicated byte loads per thread (texture-addresser bound).
+    __shared__ float sp[4][68];
+    const int pl = threadIdx.x >> 3;                               // pooled pixel inside the segment
+    const int segs_x = (Wp + 31) >> 5, nseg = B * Hp * segs_x;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int row = seg / segs_x, xc = seg - row * segs_x;
         const int b = row / Hp, py = row - b * Hp;
+        const int px = xc * 32 + pl;
         const uint8_t* im = img + (long long)b * H * W;
+        __syncthreads();                                           // previous segment's readers are done
+        for (int i = threadIdx.x; i < 4 * 66; i += 256) {
+            const int dy = i / 66, dx = i - dy * 66;
+            const int y = 2 * py - 1 + dy, x = 64 * xc - 1 + dx;
+            sp[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? fmaf((float)im[y * W + x], 0.0078125f, -1.0f) : 0.f;   // (v - 128) / 128, exact
+        }
+        __syncthreads();
+        if (px >= Wp) continue;                                    // (no barrier below this point in the iteration)
+        const int pix = row * Wp + px;
         float patch[4][4];
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const int y = 2 * py - 1 + dy, x = 2 * px - 1 + dx;
-                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? fmaf((float)im[y * W + x], 0.0078125f, -1.0f) : 0.f;   // (v - 128) / 128, exact
-            }
+        for (int dy = 0; dy < 4; ++dy) {
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(&sp[dy][2 * pl]), hi = *reinterpret_cast<const f32x2*>(&sp[dy][2 * pl + 2]);
+            patch[dy][0] = lo[0]; patch[dy][1] = lo[1]; patch[dy][2] = hi[0]; patch[dy][3] = hi[1];
+        }
         float best[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) best[e] = -3.0e38f;
@@ -82,23 +94,29 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __re
         for (int e = 0; e < 8; ++e) { wr[t][e] = w[t * 64 + cg * 8 + e]; gw[t][e] = 0.f; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { br[e] = bias[cg * 8 + e]; gb[e] = 0.f; }
-    const int npix = B * Hp * Wp;
-    // every lane iterates the same number of times so the wave stays convergent
-    const int iters = (npix + (int)gridDim.x * 32 - 1) / ((int)gridDim.x * 32);
-    for (int it = 0; it < iters; ++it) {
-        const int pix = (it * (int)gridDim.x + (int)blockIdx.x) * 32 + (threadIdx.x >> 3);
-        if (pix >= npix) continue;
-        const int row = pix / Wp, px = pix - row * Wp;
+    __shared__ float sp[4][68];
+    const int pl = threadIdx.x >> 3;
+    const int segs_x = (Wp + 31) >> 5, nseg = B * Hp * segs_x;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int row = seg / segs_x, xc = seg - row * segs_x;
         const int b = row / Hp, py = row - b * Hp;
+        const int px = xc * 32 + pl;
         const uint8_t* im = img + (long long)b * H * W;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * 66; i += 256) {
+            const int dy = i / 66, dx = i - dy * 66;
+            const int y = 2 * py - 1 + dy, x = 64 * xc - 1 + dx;
+            sp[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? fmaf((float)im[y * W + x], 0.0078125f, -1.0f) : 0.f;
+        }
+        __syncthreads();
+        if (px >= Wp) continue;
+        const int pix = row * Wp + px;
         float patch[4][4];
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const int y = 2 * py - 1 + dy, x = 2 * px - 1 + dx;
-                patch[dy][dx] = (y >= 0 && y < H && x >= 0 && x < W) ? fmaf((float)im[y * W + x], 0.0078125f, -1.0f) : 0.f;
-            }
+        for (int dy = 0; dy < 4; ++dy) {
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(&sp[dy][2 * pl]), hi = *reinterpret_cast<const f32x2*>(&sp[dy][2 * pl + 2]);
+            patch[dy][0] = lo[0]; patch[dy][1] = lo[1]; patch[dy][2] = hi[0]; patch[dy][3] = hi[1];
+        }
         float g[8];
         load8(dout + (long long)pix * 64 + cg * 8, g);
         // channel PAIRS on the packed-f32 FMA; the weight gradient adds d * patch for all four pool positions with d
@@ -464,7 +482,7 @@ inline int grid_for(long long items, int per_block, int cap = 2048) {
 
 template <typename CT> static void conv1_fwd_t(const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s) {
     const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
-    hipLaunchKernelGGL((conv1_pool_fwd_kernel<CT>), dim3(grid_for((long long)B * Hp * Wp, 32, 4096)), dim3(256), 0, s,
+    hipLaunchKernelGGL((conv1_pool_fwd_kernel<CT>), dim3(grid_for((long long)B * Hp * ((Wp + 31) / 32), 1, 4096)), dim3(256), 0, s,
                        img, w, b, (CT*)out, B, H, W, Hp, Wp);
 }
 int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s) {
@@ -473,7 +491,7 @@ int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float
 }
 template <typename CT> static void conv1_bwd_t(const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s) {
     const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
-    hipLaunchKernelGGL((conv1_pool_bwd_kernel<CT>), dim3(grid_for((long long)B * Hp * Wp, 32 * 16, 512)), dim3(256), 0, s,
+    hipLaunchKernelGGL((conv1_pool_bwd_kernel<CT>), dim3(grid_for((long long)B * Hp * ((Wp + 31) / 32), 16, 512)), dim3(256), 0, s,
                        img, w, b, (const CT*)dout, dw, db, B, H, W, Hp, Wp);
 }
 int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s) {
