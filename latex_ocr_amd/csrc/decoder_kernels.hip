@@ -47,28 +47,30 @@ LXO_DEV f32x4 slab_sum4(const Slabs& sl, long long row, int col) {
 }
 
 // mean over regions: img [B][R][C] -> mean [B][C]   (attention_mechanism.py:148)
+// grid (C / 64, B): a workgroup owns 64 channels of one image (8 lanes x 8 channels) and sums 32 rows at a time, so
+// that B * C / 64 workgroups stream the feature map instead of B (deterministic: no atomics in the forward path)
 template <typename CT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const CT* __restrict__ img, float* __restrict__ mean, int R, int C) {
-    __shared__ float red[4][512];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = lane * 8;
+    __shared__ float red[32][64 + 1];
+    const int b = blockIdx.y, c0 = blockIdx.x * 64 + (threadIdx.x & 7) * 8, rg = threadIdx.x >> 3;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    if (c0 < C)
-        for (int r = wave; r < R; r += 4) {
-            float v[8];
-            load8(img + ((long long)b * R + r) * C + c0, v);
+    for (int r = rg; r < R; r += 32) {
+        float v[8];
+        load8(img + ((long long)b * R + r) * C + c0, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e];
-        }
-    if (c0 < C) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[wave][c0 + e] = acc[e];
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rg][(threadIdx.x & 7) * 8 + e] = acc[e];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256)
-        mean[(long long)b * C + c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)R;
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += red[g][threadIdx.x];
+        mean[(long long)b * C + blockIdx.x * 64 + threadIdx.x] = t / (float)R;
+    }
 }
 
 // teacher-forcing inputs (decoder.py:75-95): row t*B+b = t ? table[formula[b][t-1]] : start_token
@@ -902,8 +904,9 @@ inline int grid1(long long items, int per_block = 256, int cap = 2048) {
 #define DONE return (int)hipGetLastError()
 
 int lxo_k_rowmean(int dt, const void* img, float* mean, int B, int R, int C, hipStream_t st) {
-    if (dt == LXO_BF16) LAUNCH((rowmean_kernel<bf16_t>), B, (const bf16_t*)img, mean, R, C);
-    else LAUNCH((rowmean_kernel<float>), B, (const float*)img, mean, R, C);
+    if (C % 64) return -2;
+    if (dt == LXO_BF16) LAUNCH((rowmean_kernel<bf16_t>), dim3(C / 64, B), (const bf16_t*)img, mean, R, C);
+    else LAUNCH((rowmean_kernel<float>), dim3(C / 64, B), (const float*)img, mean, R, C);
     DONE;
 }
 int lxo_k_embed_gather(int dt, const float* table, const float* start, const int* formula, void* out, int B, int T, int D, int Dp, int V, hipStream_t st) {
