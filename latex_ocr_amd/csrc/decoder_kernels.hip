@@ -371,27 +371,47 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
                                                               int nch, int rows_per) {
     const int v = blockIdx.y, qd = blockIdx.x, tid = threadIdx.x;
     const float* pv = part + (long long)v * nch * (C + 2);
+    // everything this thread needs is requested up front (chunk statistics, its channel's partial contexts, its raw
+    // scores) so that the kernel costs ONE memory round trip, not one for the statistics and a second for the data
+    const int cq = (C + 3) / 4, rq = (R + 3) / 4;
+    const int c = qd * cq + tid, r = qd * rq + tid;           // cq, rq <= 256 for C <= 1024, R <= 1024 (else the loops below)
+    const bool c_ok = tid < cq && c < C, r_ok = tid < rq && r < R;
+    float pcx[8], sraw = 0.f;
+    const bool fast = nch <= 8 && cq <= 256 && rq <= 256;
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pcx[k] = (k < nch && c_ok) ? pv[(long long)k * (C + 2) + 2 + c] : 0.f;
+        if (r_ok) sraw = alpha[(long long)v * Rp + r];
+    }
     float mc[32], lc[32];
     float m = -3.0e38f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        mc[c] = c < nch ? pv[(long long)c * (C + 2)] : -3.0e38f;
-        lc[c] = c < nch ? pv[(long long)c * (C + 2) + 1] : 0.f;
-        if (lc[c] > 0.f) m = fmaxf(m, mc[c]);
+    for (int k = 0; k < 32; ++k) {
+        mc[k] = k < nch ? pv[(long long)k * (C + 2)] : -3.0e38f;
+        lc[k] = k < nch ? pv[(long long)k * (C + 2) + 1] : 0.f;
+        if (lc[k] > 0.f) m = fmaxf(m, mc[k]);
     }
     float l = 0.f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) { mc[c] = lc[c] > 0.f ? expf(mc[c] - m) : 0.f; l += lc[c] * mc[c]; }
+    for (int k = 0; k < 32; ++k) { mc[k] = lc[k] > 0.f ? expf(mc[k] - m) : 0.f; l += lc[k] * mc[k]; }
     const float inv = 1.0f / l;
-    const int cq = (C + 3) / 4;
-    for (int c = qd * cq + tid; c < min(C, (qd + 1) * cq); c += 256) {
-        float t = 0.f;
-        for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + c], mc[k], t);
-        ctx[(long long)v * ldctx + c] = t * inv;
+    if (fast) {
+        if (c_ok) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t = fmaf(pcx[k], mc[k], t);
+            ctx[(long long)v * ldctx + c] = t * inv;
+        }
+        if (r_ok) alpha[(long long)v * Rp + r] = expf(sraw - m) * inv;
+        return;
     }
-    const int rq = (R + 3) / 4;
-    for (int r = qd * rq + tid; r < min(R, (qd + 1) * rq); r += 256)
-        alpha[(long long)v * Rp + r] = expf(alpha[(long long)v * Rp + r] - m) * inv;
+    for (int cc = qd * cq + tid; cc < min(C, (qd + 1) * cq); cc += 256) {
+        float t = 0.f;
+        for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + cc], mc[k], t);
+        ctx[(long long)v * ldctx + cc] = t * inv;
+    }
+    for (int rr = qd * rq + tid; rr < min(R, (qd + 1) * rq); rr += 256)
+        alpha[(long long)v * Rp + rr] = expf(alpha[(long long)v * Rp + rr] - m) * inv;
 }
 
 // ---- attention backward (per step): d_e and d_att_h in one pass; d_img / d_att_img are deferred ----
