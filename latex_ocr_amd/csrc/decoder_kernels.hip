@@ -128,38 +128,44 @@ __device__ __forceinline__ float drop_scale(const Drop& d, unsigned which, int r
     return ((unsigned)(z >> 40) < d.thr) ? d.inv_keep : 0.f;
 }
 
-// TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71); 4 units per thread
+// TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71).  A group of 4 threads owns 4 units of
+// one row: thread q sums gate q's pre-activations for the 4 units (z + the K1 slabs: one round trip of 16-byte loads),
+// activates them and hands them over through LDS; then thread q finishes unit u + q.  B*U threads (128 workgroups at
+// B = 64) instead of B*U/4: the step kernels are latency-bound, so the wider launch is the faster one.
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__ z, Slabs zs, const float* __restrict__ c_prev,
                                                       float* __restrict__ gates, float* __restrict__ c_out,
                                                       float* __restrict__ h_out, float* __restrict__ ht_out, int ldh, Drop dr,
                                                       int B, int U) {
-    const int total = B * (U >> 2);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int b = i / (U >> 2), u = (i - b * (U >> 2)) << 2;
-        const float* zr = z + (long long)b * 4 * U + u;
-        f32x4 zz[4];
+    __shared__ float act[64][4][4 + 1];
+    const int total = B * (U >> 2);                       // unit groups
+    const int q = threadIdx.x & 3, ugl = threadIdx.x >> 2;
+    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+        const int ug = base + ugl;
+        const bool ok = ug < total;
+        const int b = ok ? ug / (U >> 2) : 0, u = ok ? (ug - b * (U >> 2)) << 2 : 0;
+        float cp = 0.f;
+        if (ok) {
+            cp = c_prev[(long long)b * U + u + q];
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + (long long)b * 4 * U + q * U + u) + slab_sum4(zs, b, q * U + u);
+            f32x4 a;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) zz[g] = *reinterpret_cast<const f32x4*>(zr + g * U) + slab_sum4(zs, b, g * U + u);
-        const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + (long long)b * U + u);
-        f32x4 gi, gj, gf, go, c, h;
+            for (int e = 0; e < 4; ++e)
+                a[e] = (q == 1) ? tanhf(zz[e]) : sigmoidf_(q == 2 ? zz[e] + 1.0f : zz[e]);
+            if (gates) *reinterpret_cast<f32x4*>(gates + (long long)b * 4 * U + q * U + u) = a;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            gi[e] = sigmoidf_(zz[0][e]); gj[e] = tanhf(zz[1][e]);
-            gf[e] = sigmoidf_(zz[2][e] + 1.0f); go[e] = sigmoidf_(zz[3][e]);
-            c[e] = gf[e] * cp[e] + gi[e] * gj[e];
-            h[e] = go[e] * tanhf(c[e]);
+            for (int e = 0; e < 4; ++e) act[ugl][q][e] = a[e];
         }
-        if (gates) {
-            float* gr = gates + (long long)b * 4 * U + u;
-            *reinterpret_cast<f32x4*>(gr) = gi; *reinterpret_cast<f32x4*>(gr + U) = gj;
-            *reinterpret_cast<f32x4*>(gr + 2 * U) = gf; *reinterpret_cast<f32x4*>(gr + 3 * U) = go;
+        __syncthreads();
+        if (ok) {
+            const float gi = act[ugl][0][q], gj = act[ugl][1][q], gf = act[ugl][2][q], go = act[ugl][3][q];
+            const float c = gf * cp + gi * gj;
+            const float h = go * tanhf(c);
+            c_out[(long long)b * U + u + q] = c;
+            h_out[(long long)b * ldh + u + q] = h;
+            // h~ = dropout(h): what attention and the o projection read; the LSTM carries the un-dropped h (attention_cell.py:71-72)
+            ht_out[(long long)b * ldh + u + q] = h * drop_scale(dr, 1u, b, u + q, U);
         }
-        *reinterpret_cast<f32x4*>(c_out + (long long)b * U + u) = c;
-        *reinterpret_cast<f32x4*>(h_out + (long long)b * ldh + u) = h;
-        // h~ = dropout(h): what attention and the o projection read; the LSTM carries the un-dropped h (attention_cell.py:71-72)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] *= drop_scale(dr, 1u, b, u + e, U);
-        *reinterpret_cast<f32x4*>(ht_out + (long long)b * ldh + u) = h;
+        __syncthreads();
     }
 }
 
@@ -942,7 +948,7 @@ int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* 
     DONE;
 }
 int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, float* ht_out, int ldh, Drop dr, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U / 4), z, zs, c_prev, gates, c_out, h_out, ht_out, ldh, dr, B, U);
+    LAUNCH(lstm_fwd_kernel, grid1((long long)B * U), z, zs, c_prev, gates, c_out, h_out, ht_out, ldh, dr, B, U);
     DONE;
 }
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
