@@ -169,38 +169,63 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
     }
 }
 
+// slabs q, q+4, q+8, ... of a split-K product (4 consecutive columns)
+LXO_DEV f32x4 slab_part4(const Slabs& sl, long long row, int col, int q) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* p = sl.p + row * sl.ld + col;
+    for (int s0 = q; s0 < sl.n; s0 += 32) {               // 8 loads in flight per round (one round up to 32 slabs)
+        f32x4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            t[j] = (s0 + 4 * j < sl.n) ? *reinterpret_cast<const f32x4*>(p + (long long)(s0 + 4 * j) * sl.stride) : z;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    return v;
+}
+
+// Backward of the LSTM cell.  As in lstm_fwd, 4 threads share a group of 4 units: thread q adds every fourth slab of
+// the three split-K products that make up d_h (B1: o projection, B3: attention, B4: the next step's LSTM carry), the
+// partial sums meet in LDS, and thread q finishes unit u + q with scalar accesses.  B*U threads, <= 8 loads each.
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                       const float* __restrict__ c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                                                       float* __restrict__ dcc, float* __restrict__ dz, Drop dr, int carry_rows,
                                                       int B, int U) {
+    __shared__ float ex[64][4][8 + 1];
     const int total = B * (U >> 2);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int b = i / (U >> 2), u = (i - b * (U >> 2)) << 2;
-        const float* gr = gates + (long long)b * 4 * U + u;
-        const f32x4 gi = *reinterpret_cast<const f32x4*>(gr), gj = *reinterpret_cast<const f32x4*>(gr + U);
-        const f32x4 gf = *reinterpret_cast<const f32x4*>(gr + 2 * U), go = *reinterpret_cast<const f32x4*>(gr + 3 * U);
-        f32x4 dh = slab_sum4(s1, b, u) + slab_sum4(s3, b, u);          // d_h~ (o projection + attention)
+    const int q = threadIdx.x & 3, ugl = threadIdx.x >> 2;
+    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+        const int ug = base + ugl;
+        const bool ok = ug < total;
+        const int b = ok ? ug / (U >> 2) : 0, u = ok ? (ug - b * (U >> 2)) << 2 : 0;
+        float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f, cc = 0.f, cp = 0.f, dci = 0.f;
+        if (ok) {
+            const float* gr = gates + (long long)b * 4 * U + u + q;
+            gi = gr[0]; gj = gr[U]; gf = gr[2 * U]; go = gr[3 * U];
+            cc = c_cur[(long long)b * U + u + q]; cp = c_prev[(long long)b * U + u + q]; dci = dcc[(long long)b * U + u + q];
+            const f32x4 pm = slab_part4(s1, b, u, q) + slab_part4(s3, b, u, q);          // d_h~ (o projection + attention)
+            f32x4 pc = {0.f, 0.f, 0.f, 0.f};
+            if (b < carry_rows) pc = slab_part4(s4, b, off4 + u, q);                    // d_h carried by the next step's LSTM
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dh[e] *= drop_scale(dr, 1u, b, u + e, U);
-        if (b < carry_rows) dh += slab_sum4(s4, b, off4 + u);          // d_h carried by the next step's LSTM (rows that ran it)
-        const f32x4 cc = *reinterpret_cast<const f32x4*>(c_cur + (long long)b * U + u);
-        const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + (long long)b * U + u);
-        const f32x4 dci = *reinterpret_cast<const f32x4*>(dcc + (long long)b * U + u);
-        f32x4 di, dj, df, dg, dco;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float tc = tanhf(cc[e]);
-            const float dc = dci[e] + dh[e] * go[e] * (1.f - tc * tc);
-            di[e] = dc * gj[e] * gi[e] * (1.f - gi[e]);
-            dj[e] = dc * gi[e] * (1.f - gj[e] * gj[e]);
-            df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
-            dg[e] = dh[e] * tc * go[e] * (1.f - go[e]);
-            dco[e] = dc * gf[e];
+            for (int e = 0; e < 4; ++e) { ex[ugl][q][e] = pm[e]; ex[ugl][q][4 + e] = pc[e]; }
         }
-        float* dr = dz + (long long)b * 4 * U + u;
-        *reinterpret_cast<f32x4*>(dr) = di; *reinterpret_cast<f32x4*>(dr + U) = dj;
-        *reinterpret_cast<f32x4*>(dr + 2 * U) = df; *reinterpret_cast<f32x4*>(dr + 3 * U) = dg;
-        *reinterpret_cast<f32x4*>(dcc + (long long)b * U + u) = dco;
+        __syncthreads();
+        if (ok) {
+            const float dhm = ex[ugl][0][q] + ex[ugl][1][q] + ex[ugl][2][q] + ex[ugl][3][q];
+            const float dhc = ex[ugl][0][4 + q] + ex[ugl][1][4 + q] + ex[ugl][2][4 + q] + ex[ugl][3][4 + q];
+            const float dh = dhm * drop_scale(dr, 1u, b, u + q, U) + dhc;
+            const float tc = tanhf(cc);
+            const float dc = dci + dh * go * (1.f - tc * tc);
+            float* dzr = dz + (long long)b * 4 * U + u + q;
+            dzr[0] = dc * gj * gi * (1.f - gi);
+            dzr[U] = dc * gi * (1.f - gj * gj);
+            dzr[2 * U] = dc * cp * gf * (1.f - gf);
+            dzr[3 * U] = dh * tc * go * (1.f - go);
+            dcc[(long long)b * U + u + q] = dc * gf;
+        }
+        __syncthreads();
     }
 }
 
@@ -953,7 +978,7 @@ int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, 
 }
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                    float* dcc, float* dz, Drop dr, int carry_rows, int B, int U, hipStream_t st) {
-    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U / 4), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, dr, carry_rows, B, U);
+    LAUNCH(lstm_bwd_kernel, grid1((long long)B * U), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, dr, carry_rows, B, U);
     DONE;
 }
 int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, Drop dr, int carry_rows, int rows, int cols, hipStream_t st) {
