@@ -567,7 +567,7 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
 }
 
 // deferred: d_att_img[b][r][k] = beta_k sum_t de[t][b][r] (1 - tau^2),  d_beta_k += sum de * tau
-template <typename CT>
+template <typename CT, int KCT>
 __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ att_img, const float* __restrict__ att_h,
                                                       const float* __restrict__ beta, const float* __restrict__ de,
                                                       CT* __restrict__ dout, float* __restrict__ dbeta,
@@ -576,9 +576,9 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KC = (E + 255) >> 8;
-    float bt[4][4], db[4][4];
+    float bt[KCT][4], db[KCT][4];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
+    for (int kc = 0; kc < KCT; ++kc) {
         const int k0 = kc * 256 + lane * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { bt[kc][j] = (kc < KC && k0 + j < E) ? beta[k0 + j] : 0.f; db[kc][j] = 0.f; }
@@ -586,9 +586,9 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
     for (int rr = 0; rr < 4; ++rr) {
         const int r = blockIdx.x * 16 + wave * 4 + rr;
         if (r >= R) continue;                       // wave-uniform
-        float x[4][4], acc[4][4];
+        float x[KCT][4], acc[KCT][4];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < KCT; ++kc) {
             const int k0 = kc * 256 + lane * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { x[kc][j] = 0.f; acc[kc][j] = 0.f; }
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
         }
         for (int t0 = 0; t0 < T; t0 += 8) {
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
+            for (int kc = 0; kc < KCT; ++kc) {
                 const int k0 = kc * 256 + lane * 4;
                 if (kc < KC && k0 < E) {
                     float a[8][4], d[8];
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
             }
         }
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < KCT; ++kc) {
             const int k0 = kc * 256 + lane * 4;
             if (kc < KC && k0 < E) {
                 float o[4];
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
         }
     }
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
+    for (int kc = 0; kc < KCT; ++kc) {
         const int k0 = kc * 256 + lane * 4;
         if (kc < KC && k0 < E) {
 #pragma unroll
@@ -1045,8 +1045,14 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
                    int T, int B, int R, int Rp, int E, hipStream_t st) {
     dim3 grid(cdiv(R, 16), B);
-    if (dt == LXO_BF16) hipLaunchKernelGGL((datt_img_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, T, B, R, Rp, E);
-    else hipLaunchKernelGGL((datt_img_kernel<float>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, T, B, R, Rp, E);
+    if (E > 1024) return -2;
+    if (dt == LXO_BF16) {
+        if (E <= 256) hipLaunchKernelGGL((datt_img_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, T, B, R, Rp, E);
+        else hipLaunchKernelGGL((datt_img_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, T, B, R, Rp, E);
+    } else {
+        if (E <= 256) hipLaunchKernelGGL((datt_img_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, T, B, R, Rp, E);
+        else hipLaunchKernelGGL((datt_img_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, T, B, R, Rp, E);
+    }
     DONE;
 }
 int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st) {
