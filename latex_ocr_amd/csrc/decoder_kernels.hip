@@ -612,11 +612,24 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
                         // the whole gradient flow of those steps): their 256 tanh evaluations contribute nothing
                         const float dd = d[tt];
                         if (dd == 0.f) continue;            // same value in every lane: the branch skips the whole wave
+                        if constexpr (is_bf16<CT>::value) {
+                            // with r = 1 / (1 + e^{2s}):  tau = 1 - 2r,  1 - tau^2 = 4 r (1 - r).  The kernel is VALU-bound
+                            // (two quarter-rate transcendentals per element), so the plain ops around them are kept to six:
+                            // db collects sum(d) - 2 sum(d r) and the 4 is folded into d.
+                            const float d4 = 4.f * dd;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float tau = tanh_ct<CT>(x[kc][j] + a[tt][j]);
-                            acc[kc][j] = fmaf(dd, 1.f - tau * tau, acc[kc][j]);
-                            db[kc][j] = fmaf(dd, tau, db[kc][j]);
+                            for (int j = 0; j < 4; ++j) {
+                                const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f((x[kc][j] + a[tt][j]) * 2.8853900817779268f) + 1.f);
+                                acc[kc][j] = fmaf(d4, fmaf(-r, r, r), acc[kc][j]);
+                                db[kc][j] = fmaf(dd, fmaf(-2.f, r, 1.f), db[kc][j]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float tau = tanh_ct<CT>(x[kc][j] + a[tt][j]);
+                                acc[kc][j] = fmaf(dd, 1.f - tau * tau, acc[kc][j]);
+                                db[kc][j] = fmaf(dd, tau, db[kc][j]);
+                            }
                         }
                     }
                 }

@@ -138,6 +138,8 @@ inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.0f / a; }
 inline float __builtin_amdgcn_rcpf_sim(float a) { return 1.0f / a; }
 #define __builtin_amdgcn_rcpf(a) __builtin_amdgcn_rcpf_sim(a)
+inline float __builtin_amdgcn_exp2f_sim(float a) { return exp2f(a); }
+#define __builtin_amdgcn_exp2f(a) __builtin_amdgcn_exp2f_sim(a)
 inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
