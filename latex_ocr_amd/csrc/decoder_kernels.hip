@@ -583,51 +583,60 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
 #pragma unroll
         for (int j = 0; j < 4; ++j) { bt[kc][j] = (kc < KC && k0 + j < E) ? beta[k0 + j] : 0.f; db[kc][j] = 0.f; }
     }
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = blockIdx.x * 16 + wave * 4 + rr;
-        if (r >= R) continue;                       // wave-uniform
-        float x[KCT][4], acc[KCT][4];
+    // a wave owns 4 regions and walks the T steps ONCE for all of them: the att_h row of a step is loaded once per
+    // 4 regions (re-reading it per region made the kernel L2-bandwidth-bound: B*R*T KB = 5.6 GB per launch)
+    const int rbase = blockIdx.x * 16 + wave * 4;
+    float x[4][KCT][4], acc[4][KCT][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int kc = 0; kc < KCT; ++kc) {
             const int k0 = kc * 256 + lane * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { x[kc][j] = 0.f; acc[kc][j] = 0.f; }
-            if (kc < KC && k0 < E) load4(att_img + ((long long)b * R + r) * E + k0, x[kc]);
+            for (int j = 0; j < 4; ++j) { x[rr][kc][j] = 0.f; acc[rr][kc][j] = 0.f; }
+            if (rbase + rr < R && kc < KC && k0 < E) load4(att_img + ((long long)b * R + rbase + rr) * E + k0, x[rr][kc]);
         }
-        for (int t0 = 0; t0 < T; t0 += 8) {
+    if (rbase < R)
+    for (int t0 = 0; t0 < T; t0 += 4) {
 #pragma unroll
-            for (int kc = 0; kc < KCT; ++kc) {
-                const int k0 = kc * 256 + lane * 4;
-                if (kc < KC && k0 < E) {
-                    float a[8][4], d[8];
+        for (int kc = 0; kc < KCT; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            if (kc < KC && k0 < E) {
+                float a[4][4], d[4][4];
 #pragma unroll
-                    for (int tt = 0; tt < 8; ++tt) {          // 8 time steps of loads in flight
-                        const int t = t0 + tt;
-                        if (t < T) { load4(att_h + ((long long)t * B + b) * E + k0, a[tt]); d[tt] = de[((long long)t * B + b) * Rp + r]; }
-                        else { a[tt][0] = a[tt][1] = a[tt][2] = a[tt][3] = 0.f; d[tt] = 0.f; }
+                for (int tt = 0; tt < 4; ++tt) {          // 4 time steps of loads in flight
+                    const int t = t0 + tt;
+                    if (t < T) {
+                        load4(att_h + ((long long)t * B + b) * E + k0, a[tt]);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) d[tt][rr] = (rbase + rr < R) ? de[((long long)t * B + b) * Rp + rbase + rr] : 0.f;
+                    } else {
+                        a[tt][0] = a[tt][1] = a[tt][2] = a[tt][3] = 0.f;
+                        d[tt][0] = d[tt][1] = d[tt][2] = d[tt][3] = 0.f;
                     }
+                }
 #pragma unroll
-                    for (int tt = 0; tt < 8; ++tt) {
-                        // d_e is wave-uniform and exactly 0 for every padded (sample, step) pair (the loss mask zeroes
-                        // the whole gradient flow of those steps): their 256 tanh evaluations contribute nothing
-                        const float dd = d[tt];
-                        if (dd == 0.f) continue;            // same value in every lane: the branch skips the whole wave
+                for (int tt = 0; tt < 4; ++tt) {
+                    // d_e is wave-uniform and exactly 0 for every padded (sample, step) pair (the loss mask zeroes the whole
+                    // gradient flow of those steps) -- all four regions belong to the same sample, so they vanish together
+                    if (d[tt][0] == 0.f && d[tt][1] == 0.f && d[tt][2] == 0.f && d[tt][3] == 0.f) continue;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float dd = d[tt][rr];
                         if constexpr (is_bf16<CT>::value) {
-                            // with r = 1 / (1 + e^{2s}):  tau = 1 - 2r,  1 - tau^2 = 4 r (1 - r).  The kernel is VALU-bound
-                            // (two quarter-rate transcendentals per element), so the plain ops around them are kept to six:
-                            // db collects sum(d) - 2 sum(d r) and the 4 is folded into d.
+                            // with r = 1 / (1 + e^{2s}):  tau = 1 - 2r,  1 - tau^2 = 4 r (1 - r)
                             const float d4 = 4.f * dd;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f((x[kc][j] + a[tt][j]) * 2.8853900817779268f) + 1.f);
-                                acc[kc][j] = fmaf(d4, fmaf(-r, r, r), acc[kc][j]);
+                                const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f((x[rr][kc][j] + a[tt][j]) * 2.8853900817779268f) + 1.f);
+                                acc[rr][kc][j] = fmaf(d4, fmaf(-r, r, r), acc[rr][kc][j]);
                                 db[kc][j] = fmaf(dd, fmaf(-2.f, r, 1.f), db[kc][j]);
                             }
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float tau = tanh_ct<CT>(x[kc][j] + a[tt][j]);
-                                acc[kc][j] = fmaf(dd, 1.f - tau * tau, acc[kc][j]);
+                                const float tau = tanh_ct<CT>(x[rr][kc][j] + a[tt][j]);
+                                acc[rr][kc][j] = fmaf(dd, 1.f - tau * tau, acc[rr][kc][j]);
                                 db[kc][j] = fmaf(dd, tau, db[kc][j]);
                             }
                         }
@@ -635,17 +644,19 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
                 }
             }
         }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int kc = 0; kc < KCT; ++kc) {
             const int k0 = kc * 256 + lane * 4;
-            if (kc < KC && k0 < E) {
+            if (rbase + rr < R && kc < KC && k0 < E) {
                 float o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = acc[kc][j] * bt[kc][j];
-                store4(dout + ((long long)b * R + r) * E + k0, o);
+                for (int j = 0; j < 4; ++j) o[j] = acc[rr][kc][j] * bt[kc][j];
+                store4(dout + ((long long)b * R + rbase + rr) * E + k0, o);
             }
         }
-    }
 #pragma unroll
     for (int kc = 0; kc < KCT; ++kc) {
         const int k0 = kc * 256 + lane * 4;
