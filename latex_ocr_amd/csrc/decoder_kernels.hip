@@ -265,11 +265,10 @@ __global__ __launch_bounds__(256) void tanh_finalize_kernel(Slabs sl, float* __r
 
 // ---- attention stream ----
 // The R regions of a sample are split into NCH chunks, one workgroup (8 waves) per
-// (chunk, sample), so that B*NCH >= ~2 workgroups per CU and every wave keeps 8 row
-// loads in flight (the stream is latency-bound otherwise: one 512-B row per wave per
+// (chunk, sample), so that B*NCH >= ~2 workgroups per CU and every wave keeps 4 rows of
+// both streams in flight (the stream is latency-bound otherwise: one 512-B row per wave per
 // round trip measured 5 GB/s per workgroup).  Each chunk produces flash-style partials
 // (max, sum, unnormalised context); attn_fwd_combine normalises.
-constexpr int ATT_ROWS = 1 << 20;  // no per-chunk LDS row buffer any more
 constexpr int ATT_W = 8;        // waves per workgroup
 
 template <typename CT> LXO_DEV float tanh_ct(float x);
@@ -1033,7 +1032,6 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
                    float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
-    if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
 #define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per
     if (dt == LXO_BF16) {
@@ -1053,7 +1051,6 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
                    int nv, int R, int Rp, int E, int C, int nch, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
-    if (rows_per > ATT_ROWS) return -2;
     dim3 grid(nch, nv);
 #define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per
     if (dt == LXO_BF16) {
