@@ -218,8 +218,10 @@ constexpr int HPATCH = HPSLOTS * 16, HB_STAGE = CBN * CBK * 2;                  
 
 #define LXO_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
-template <typename OT>
+// NJ = 32-channel blocks per wave: 2 -> 128-channel tiles, 1 -> 64-channel tiles (layers with Cout <= 64: conv2's dgrad)
+template <typename OT, int NJ>
 __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
+    constexpr int BN = 64 * NJ, HBS = BN * CBK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nblk = gridDim.x, bid = blockIdx.x;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
     const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
     const int tx_i = mt % tiles_x, ty_i = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
-    const int oy0 = ty_i * HTH, ox0 = tx_i * HTW, n0 = nt * CBN;
+    const int oy0 = ty_i * HTH, ox0 = tx_i * HTW, n0 = nt * BN;
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
     const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
@@ -248,9 +250,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
         a_gch[j] = (sch ^ ((prow >> 1) & 7)) << 3;
     }
     const int srow = tid >> 3;
-    const bf16_t* b_ptr[2]; bool b_ok[2];
+    const bf16_t* b_ptr[NJ]; bool b_ok[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int n = n0 + srow + 64 * j;
         b_ok[j] = n < p.N;
         b_ptr[j] = Bp + (long long)(b_ok[j] ? n : 0) * p.ldb + ((sch ^ ((srow >> 1) & 7)) << 3);
@@ -263,22 +265,22 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
             glds16(src, dst + (wave * 64 + 512 * j) * 16);
         }
     };
-    auto issue_b = [&](int t, int stage) {             // 2 LDS-DMA per thread; K index of tile t = tap*Cin + c*64
+    auto issue_b = [&](int t, int stage) {             // NJ LDS-DMA per thread; K index of tile t = tap*Cin + c*64
         const int c = t / 9, tap = t - 9 * c;
         const int k0 = tap * p.Cin + c * CBK;
-        char* dst = bst0 + stage * HB_STAGE;
+        char* dst = bst0 + stage * HBS;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const void* src = b_ok[j] ? (const void*)(b_ptr[j] + k0) : (const void*)zline;
             glds16(src, dst + (wave * 64 + 512 * j) * 16);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -289,9 +291,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
         const int rr = wm * 64 + i * 32 + (lane & 31);
         a_prow[i] = (rr >> 6) * HPW + (rr & 63);
     }
-    int b_row[2];
+    int b_row[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b_row[j] = wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) b_row[j] = wn * 32 * NJ + j * 32 + (lane & 31);
 
     const int nchunk = p.Cin / CBK, nk = nchunk * 9;
     issue_patch(0, 0);
@@ -301,10 +303,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
         // loads issued after B(t): B(t+1) [2] and the next patch [7] when it was issued at step t-2 or t-1
         const int tm = t % 9;
         const bool patch_after = (tm == 5 || tm == 6) && (t / 9 + 1 < nchunk);
-        const int nafter = ((t + 1 < nk) ? 2 : 0) + (patch_after ? 7 : 0);
-        if (nafter == 9) LXO_VMCNT(9);
+        const int nafter = ((t + 1 < nk) ? NJ : 0) + (patch_after ? 7 : 0);
+        if (nafter == NJ + 7) LXO_VMCNT(NJ + 7);
         else if (nafter == 7) LXO_VMCNT(7);
-        else if (nafter == 2) LXO_VMCNT(2);
+        else if (nafter == NJ) LXO_VMCNT(NJ);
         else LXO_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         if (t + 2 < nk) issue_b(t + 2, (t + 2) % 3);
@@ -312,24 +314,24 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
         const int c = t / 9, tap = t - 9 * c;
         const int kh = tap / 3, kw = tap - 3 * kh;
         const char* ps = patch0 + (c & 1) * HPATCH;
-        const char* bs = bst0 + (t % 3) * HB_STAGE;
+        const char* bs = bst0 + (t % 3) * HBS;
         const int shift = kh * HPW + kw;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int kc = ks * 2 + (lane >> 5);
-            u32x4 af[2], bfr[2];
+            u32x4 af[2], bfr[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int prow = a_prow[i] + shift;
                 af[i] = *reinterpret_cast<const u32x4*>(ps + prow * 128 + ((kc ^ ((prow >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
                 bfr[j] = *reinterpret_cast<const u32x4*>(bs + b_row[j] * 128 + ((kc ^ ((b_row[j] >> 1) & 7)) << 4));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]),
                                                                         acc[i][j], 0, 0, 0);
         }
@@ -341,10 +343,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
     if (plain) {
         __syncthreads();
         bf16_t* ot = reinterpret_cast<bf16_t*>(lxo_conv_lds);
-        constexpr int OP = CBN + 8;
+        constexpr int OP = BN + 8;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nl = wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int nl = wn * 32 * NJ + j * 32 + (lane & 31);
             const int n = n0 + nl;
             const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
@@ -360,8 +362,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = tid + 512 * it, row = idx >> 4, c8 = (idx & 15) * 8;
+        for (int it = 0; it < 4 * NJ; ++it) {
+            const int idx = tid + 512 * it, row = idx / (BN / 8), c8 = (idx % (BN / 8)) * 8;
             const int oy = oy0 + (row >> 6), ox = ox0 + (row & 63), n = n0 + c8;
             if (oy < p.Ho && ox < p.Wo && n < p.N)
                 *reinterpret_cast<u32x4*>(C + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.ldc + n) = *reinterpret_cast<const u32x4*>(ot + row * OP + c8);
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
     OT* __restrict__ Cpre = reinterpret_cast<OT*>(p.out_pre);
     const bf16_t* __restrict__ ref = reinterpret_cast<const bf16_t*>(p.relu_ref);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * 32 * NJ + j * 32 + (lane & 31);
         const bool n_ok = n < p.N;
         const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
         float csum = 0.f;
@@ -619,14 +621,21 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     }
     if (use_halo) {
         static bool halo_attr = false;
-        constexpr int LDSB = 2 * HPATCH + 3 * HB_STAGE;
+        constexpr int LDSB = 2 * HPATCH + 3 * HB_STAGE, LDSB64 = 2 * HPATCH + 3 * (HB_STAGE / 2);
         if (!halo_attr) {
-            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<bf16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB64));
             halo_attr = true;
         }
         const int B = p.M / (p.Ho * p.Wo);
-        const int tiles_n = cdiv(p.N, CBN), tiles_x = cdiv(p.Wo, HTW), tiles_y = cdiv(p.Ho, HTH);
-        hipLaunchKernelGGL((conv_halo_kernel<bf16_t>), dim3(B * tiles_x * tiles_y * tiles_n), dim3(CTH), LDSB, s, p, tiles_n, tiles_x, tiles_y);
+        const int tiles_x = cdiv(p.Wo, HTW), tiles_y = cdiv(p.Ho, HTH);
+        if (p.N <= 64) {     // a 64-channel-wide tile: no MFMA work on padding channels (conv2's dgrad)
+            const int tiles_n = cdiv(p.N, 64);
+            hipLaunchKernelGGL((conv_halo_kernel<bf16_t, 1>), dim3(B * tiles_x * tiles_y * tiles_n), dim3(CTH), LDSB64, s, p, tiles_n, tiles_x, tiles_y);
+            return (int)hipGetLastError();
+        }
+        const int tiles_n = cdiv(p.N, CBN);
+        hipLaunchKernelGGL((conv_halo_kernel<bf16_t, 2>), dim3(B * tiles_x * tiles_y * tiles_n), dim3(CTH), LDSB, s, p, tiles_n, tiles_x, tiles_y);
         return (int)hipGetLastError();
     }
     static bool attr_set = false;

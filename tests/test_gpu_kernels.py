@@ -120,7 +120,7 @@ def test_conv3x3_fwd_and_wgrad_bf16(B, H, W, Cin, Cout, valid):
     assert errw < 2e-5, errw
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,pad", [(2, 16, 64, 256, 256, 1), (3, 14, 62, 128, 512, 2), (2, 9, 37, 64, 256, 0), (2, 12, 70, 128, 128, 1)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pad", [(2, 16, 64, 256, 256, 1), (3, 14, 62, 128, 512, 2), (2, 9, 37, 64, 256, 0), (2, 12, 70, 128, 128, 1), (2, 20, 66, 128, 64, 1)])
 def test_conv3x3_ex_full_epilogue_bf16(B, H, W, Cin, Cout, pad):
     """fused epilogue of the conv kernels (bias, ReLU, pre-addend copy, f32 addend, ReLU mask, column sums) on the
     8x32x256 (Cout % 256 == 0) and 4x64x128 halo tiles; pad 2 = the dgrad geometry of the VALID layer."""

@@ -214,10 +214,10 @@ def _conv_ex_ref(x, w, bias, pad, relu, addend, mask):
     return pre, y, y.reshape(-1, Cout).sum(0)
 
 
-@pytest.mark.parametrize("Cout,H,W,pad", [(256, 9, 35, 1), (256, 10, 34, 0), (128, 6, 70, 1)])
+@pytest.mark.parametrize("Cout,H,W,pad", [(256, 9, 35, 1), (256, 10, 34, 0), (128, 6, 70, 1), (64, 5, 67, 1)])
 def test_conv3x3_ex_full_epilogue_bf16(Cout, H, W, pad):
     """fused conv epilogue (bias, ReLU, pre-addend copy, timing-signal addend, ReLU mask, bias-gradient column sums)
-    on the 8x32x256 and 4x64x128 halo kernels."""
+    on the 8x32x256, 4x64x128 and 4x64x64 halo kernels."""
     L = lib()
     rng = np.random.RandomState(Cout + H)
     B, Cin = 2, 64
