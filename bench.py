@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.dtype != "bf16":
+        ap.error("bench.py measures the bf16 path (the metric's dtype); f32 is the parity mode exercised by tests/")
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
