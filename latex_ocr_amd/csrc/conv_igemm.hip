@@ -365,31 +365,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
         for (int it = 0; it < 4 * NJ; ++it) {
             const int idx = tid + 512 * it, row = idx / (BN / 8), c8 = (idx % (BN / 8)) * 8;
             const int oy = oy0 + (row >> 6), ox = ox0 + (row & 63), n = n0 + c8;
-            if (oy < p.Ho && ox < p.Wo && n < p.N) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OP + c8);
-                *reinterpret_cast<u32x4*>(C + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.ldc + n) = v;
-                // fused SAME max-pool: the window leader (tiles start on even coordinates) reduces its window from LDS
-                if (p.pool_out && (oy % p.pool_h) == 0 && (ox % p.pool_w) == 0) {
-                    float best[8];
-                    {
-                        const u32x4 t = v;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) { best[2 * w] = __uint_as_float(t[w] << 16); best[2 * w + 1] = __uint_as_float(t[w] & 0xffff0000u); }
-                    }
-                    for (int dy = 0; dy < p.pool_h; ++dy)
-                        for (int dx = 0; dx < p.pool_w; ++dx) {
-                            if ((dy | dx) == 0 || oy + dy >= p.Ho || ox + dx >= p.Wo) continue;
-                            const u32x4 t = *reinterpret_cast<const u32x4*>(ot + (row + dy * HTW + dx) * OP + c8);
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                best[2 * w] = fmaxf(best[2 * w], __uint_as_float(t[w] << 16));
-                                best[2 * w + 1] = fmaxf(best[2 * w + 1], __uint_as_float(t[w] & 0xffff0000u));
-                            }
-                        }
-                    const int Hq = (p.Ho + p.pool_h - 1) / p.pool_h, Wq = (p.Wo + p.pool_w - 1) / p.pool_w;
-                    store8(reinterpret_cast<bf16_t*>(p.pool_out) + (((long long)b * Hq + oy / p.pool_h) * Wq + ox / p.pool_w) * p.N + n, best);
-                }
-            }
+            if (oy < p.Ho && ox < p.Wo && n < p.N)
+                *reinterpret_cast<u32x4*>(C + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.ldc + n) = *reinterpret_cast<const u32x4*>(ot + row * OP + c8);
         }
         return;
     }
@@ -605,25 +582,6 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
                 for (int e = 0; e < 8; ++e) v[e] += cv[e];
             }
             store8(C + m * p.ldc + n, v);
-            // fused SAME max-pool (plain forward layers only: bias + activation are monotone, so the window leader
-            // re-applies them to its partners' raw accumulators, which are still in this half's LDS tile)
-            if (p.pool_out && (oy % p.pool_h) == 0 && (ox % p.pool_w) == 0) {
-                for (int dy = 0; dy < p.pool_h; ++dy)
-                    for (int dx = 0; dx < p.pool_w; ++dx) {
-                        if ((dy | dx) == 0 || oy + dy >= p.Ho || ox + dx >= p.Wo) continue;
-                        const float* q = ot + (row + dy * QTW + dx) * OP + c8;
-                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(q), w1 = *reinterpret_cast<const f32x4*>(q + 4);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float t = p.alpha * (e < 4 ? w0[e] : w1[e - 4]) + bias8[e];
-                            if (p.act == 1) t = fmaxf(t, 0.f);
-                            else if (p.act == 2) t = tanhf(t);
-                            v[e] = fmaxf(v[e], t);
-                        }
-                    }
-                const int Hq = (p.Ho + p.pool_h - 1) / p.pool_h, Wq = (p.Wo + p.pool_w - 1) / p.pool_w;
-                store8(reinterpret_cast<bf16_t*>(p.pool_out) + (((long long)b * Hq + oy / p.pool_h) * Wq + ox / p.pool_w) * p.N + n, v);
-            }
         }
     }
     if (p.colsum) {
@@ -643,23 +601,12 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
 
 }  // namespace
 
-bool lxo_conv_pool_fusion() {
-    const char* e = getenv("LXO_CONV_HALO");
-    const char* f = getenv("LXO_POOL_FUSE");
-    return !(e && e[0] == '0') && !(f && f[0] == '0');
-}
-
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
-    if (p.pool_out) {   // fused pooling needs a window that divides the tile and an epilogue without the backward-only terms
-        if (p.pool_h < 1 || p.pool_h > 2 || p.pool_w < 1 || p.pool_w > 2 || p.out_pre || p.addend || p.relu_ref || p.colsum || p.accumulate ||
-            p.ldc != p.N || (p.N & 7)) return -2;
-    }
     static int use_halo = -1;
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
     static int use_256 = -1;
     if (use_256 < 0) { const char* e = getenv("LXO_CONV_256"); use_256 = (e && e[0] == '0') ? 0 : 1; }
-    if (p.pool_out && !use_halo) return -2;
     if (use_halo && use_256 && (p.N % QBN) == 0) {
         static bool q_attr = false;
         constexpr int LDSQ = 2 * QPATCH + 2 * QB_STAGE;

@@ -21,9 +21,6 @@ struct GemmNT {
     int accumulate;
     float* colsum;
     float alpha;
-    // bf16 halo-tile convolutions only: also write max_pool(C, (pool_h, pool_w), SAME) -- tf.layers.max_pooling2d of
-    // model/encoder.py:34-52 -- to pool_out [B, ceil(Ho/pool_h), ceil(Wo/pool_w), N] from the tile still in LDS
-    void* pool_out; int pool_h, pool_w;
 };
 
 // C[I,J] (+)= sum_m A[m,I] * B[m,J]      ("TN": reduction over rows)
@@ -50,8 +47,6 @@ int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_st
 
 // bf16 3x3 implicit-GEMM convolution, 256x128x64 tiles, LDS-DMA double buffering (conv_igemm.hip)
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s);
-// true when the halo-tile kernels (which can fuse the max-pool into their epilogue) are the ones dispatched
-bool lxo_conv_pool_fusion();
 
 // bf16 3x3 weight gradient with tap reuse and transposing LDS reads (conv_wgrad.hip)
 int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s);

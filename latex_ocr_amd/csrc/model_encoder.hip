@@ -60,7 +60,7 @@ int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t
 // fwd: out[b,oy,ox,:] = relu(sum in[b,oy+kh-pad,ox+kw-pad,:] * W + bias)
 static int conv_fwd(const Plan& P, const void* in, const void* wpk, const float* bias, void* out,
                     int H, int W, int Cin, int Cout, bool valid, const float* addend, int addend_rows,
-                    void* out_pre, hipStream_t st, void* pool_out = nullptr, int ph = 1, int pw = 1) {
+                    void* out_pre, hipStream_t st) {
     GemmNT g; memset(&g, 0, sizeof(g));
     g.A = in; g.Bp = wpk; g.C = out;
     g.conv = 1; g.H = H; g.W = W; g.Cin = Cin;
@@ -69,7 +69,6 @@ static int conv_fwd(const Plan& P, const void* in, const void* wpk, const float*
     g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
     g.bias = bias; g.act = 1; g.alpha = 1.f;
     g.addend = addend; g.addend_rows = addend_rows > 0 ? addend_rows : 1; g.out_pre = out_pre;
-    g.pool_out = pool_out; g.pool_h = ph; g.pool_w = pw;
     return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
 }
 // dgrad: d_in[b,y,x,ci] = sum d_out[b,y+a-padd,x+b-padd,co] * Wd[ci][(a,b,co)], optional ReLU mask of the
@@ -107,20 +106,14 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
     const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
     void* p1 = P.ws<void>(ws, W_P1);
     RC(lxo_k_conv1_pool_fwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], p1, B, P.s.H, P.s.W, st));
-    // bf16: the SAME max-pools are fused into the producing conv's epilogue (the tile is still in LDS); f32: separate kernel
-    const bool fuse = P.bf && lxo_conv_pool_fusion();
-    RC(conv_fwd(P, p1, P.pk(wp, K_CONV2_F), prm + P.poff[P_CONV2_B], P.ws<void>(ws, W_Y2), P.H1, P.W1, 64, 128, false, nullptr, 0, nullptr, st,
-                fuse ? P.ws<void>(ws, W_P2) : nullptr, 2, 2));
-    if (!fuse) RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y2), P.ws<void>(ws, W_P2), B, P.H1, P.W1, 128, 2, 2, st));
+    RC(conv_fwd(P, p1, P.pk(wp, K_CONV2_F), prm + P.poff[P_CONV2_B], P.ws<void>(ws, W_Y2), P.H1, P.W1, 64, 128, false, nullptr, 0, nullptr, st));
+    RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y2), P.ws<void>(ws, W_P2), B, P.H1, P.W1, 128, 2, 2, st));
     RC(conv_fwd(P, P.ws<void>(ws, W_P2), P.pk(wp, K_CONV3_F), prm + P.poff[P_CONV3_B], P.ws<void>(ws, W_Y3), P.H2, P.W2, 128, 256, false, nullptr, 0, nullptr, st));
-    const bool f4 = fuse && !P.cnn;
-    RC(conv_fwd(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.ws<void>(ws, W_Y4), P.H2, P.W2, 256, 256, false, nullptr, 0, nullptr, st,
-                f4 ? P.ws<void>(ws, W_P4) : nullptr, 2, 1));
+    RC(conv_fwd(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.ws<void>(ws, W_Y4), P.H2, P.W2, 256, 256, false, nullptr, 0, nullptr, st));
     if (!P.cnn) {
-        if (!f4) RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y4), P.ws<void>(ws, W_P4), B, P.H2, P.W2, 256, 2, 1, st));
-        RC(conv_fwd(P, P.ws<void>(ws, W_P4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st,
-                    fuse ? P.ws<void>(ws, W_P5) : nullptr, 1, 2));
-        if (!fuse) RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_P5), B, P.H4, P.W2, C, 1, 2, st));
+        RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y4), P.ws<void>(ws, W_P4), B, P.H2, P.W2, 256, 2, 1, st));
+        RC(conv_fwd(P, P.ws<void>(ws, W_P4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
+        RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_P5), B, P.H4, P.W2, C, 1, 2, st));
     } else {
         // encoder.py:54-56: conv5 on the un-pooled conv4 output, then the (2,4) stride-2 SAME conv (no activation)
         RC(conv_fwd(P, P.ws<void>(ws, W_Y4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
