@@ -135,6 +135,10 @@ int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, 
  * stream (fork/join by events), so the launch- and latency-bound step kernels of one half overlap the
  * other half's.  The only per-thread state the library keeps. */
 int lxo_set_side_stream(void* stream);
+/* Optional second HIP stream for lxo_encoder_bwd (NULL disables): the conv weight-gradient kernels run on it, beside
+ * the data-gradient / pool-backward chain of the main stream (three rotating gradient buffers; fork/join by events;
+ * every call returns with the main stream ordered after all of its weight gradients). */
+int lxo_set_encoder_side_stream(void* stream);
 
 /* Decoder.__call__ training branch (model/decoder.py:41-57): AttentionMechanism
  * set-up (attention_mechanism.py:19-43,124-153), T steps of AttentionCell.step

@@ -209,6 +209,10 @@ extern "C" int lxo_set_side_stream(void* stream) {
     CHECK_LAUNCH(lxo_impl_set_side_stream((hipStream_t)stream), "lxo_set_side_stream");
     return 0;
 }
+extern "C" int lxo_set_encoder_side_stream(void* stream) {
+    CHECK_LAUNCH(lxo_impl_set_encoder_side_stream((hipStream_t)stream), "lxo_set_encoder_side_stream");
+    return 0;
+}
 
 extern "C" int lxo_optimizer_step(int method, long long n, float* params, const float* grads, float* slot, float lr,
                                   const float* scale_dev, void* stream) {

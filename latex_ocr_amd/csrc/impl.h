@@ -12,3 +12,4 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
 int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, float* alpha_out, int* steps_out, hipStream_t st);
 int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, int* parents_out, int* steps_out, hipStream_t st);
 int lxo_impl_set_side_stream(hipStream_t s);
+int lxo_impl_set_encoder_side_stream(hipStream_t s);

@@ -131,72 +131,123 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
     return 0;
 }
 
-// Layers are numbered 1..6.  Layer 6 reads d_img (f32); each layer leaves the gradient of its
-// input in the ping-pong scratch for the next (lower) layer.
+// ---- optional second stream for the weight gradients -------------------------------------------------
+// Per layer, conv_wgrad and conv_dgrad both read d_y and are otherwise independent.  With a side stream bound
+// (lxo_set_encoder_side_stream) every conv_wgrad goes there, so that the unoverlapped prologue / epilogue
+// phases of one kernel family fall under the MFMA phases of the other and the memory-bound pool-backward
+// kernels run beside a weight-gradient kernel.  Three gradient buffers rotate (table below) so that the
+// buffer a weight gradient reads is not rewritten for a whole layer; one event per buffer orders the rewrite.
+static thread_local hipStream_t g_enc_side = nullptr;
+static thread_local hipEvent_t g_ev_x = nullptr, g_ev_free[3] = {nullptr, nullptr, nullptr}, g_ev_done = nullptr;
+int lxo_impl_set_encoder_side_stream(hipStream_t s) {
+    g_enc_side = s;
+    if (s && !g_ev_x) {
+        HIPRC(hipEventCreateWithFlags(&g_ev_x, hipEventDisableTiming));
+        HIPRC(hipEventCreateWithFlags(&g_ev_done, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) HIPRC(hipEventCreateWithFlags(&g_ev_free[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// Layers are numbered 1..6.  Layer 6 reads d_img (f32).  X[l] = buffer holding d_y of layer l (read by its weight
+// and data gradients), Y[l] = buffer receiving the gradient of its input.  Index 0/1/2 = ws regions g0/g1/g2.
+//            layer:        -  -  2  3  4  5  6
+static const int XV[7] = {0, 0, 0, 1, 0, 2, 0}, YV[7] = {0, 0, 2, 2, 1, 1, 1};     // vanilla (pools after 2, 4, 5)
+static const int XC[7] = {0, 0, 1, 0, 1, 2, 0}, YC[7] = {0, 0, 2, 2, 0, 1, 1};     // "cnn" (no pools after 4, 5)
+
 int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, float* grads,
                          int last_layer, int first_layer, hipStream_t st) {
     const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
-    void* const GA = P.ws<void>(ws, W_G0); void* const GB = P.ws<void>(ws, W_G1);
+    void* const G[3] = {P.ws<void>(ws, W_G0), P.ws<void>(ws, W_G1), P.ws<void>(ws, W_G2)};
+    const int* XB = P.cnn ? XC : XV; const int* YB = P.cnn ? YC : YV;
     auto gw = [&](int pid) { return grads + P.poff[pid]; };
+    hipStream_t side = g_enc_side;
+    bool pending[3] = {false, false, false};
+    // main is about to WRITE buffer i: wait for the weight gradient that still reads it
+    auto acquire = [&](int i) -> int {
+        if (side && pending[i]) { HIPRC(hipStreamWaitEvent(st, g_ev_free[i], 0)); pending[i] = false; }
+        return 0;
+    };
+    // weight gradient of a layer whose d_y sits in buffer xi (just produced on the main stream)
+    auto wgrad = [&](const void* in, int xi, float* dw, int H, int W, int Cin, int Cout, bool valid) -> int {
+        if (!side) return conv_wgrad(P, in, G[xi], dw, H, W, Cin, Cout, valid, st);
+        HIPRC(hipEventRecord(g_ev_x, st));
+        HIPRC(hipStreamWaitEvent(side, g_ev_x, 0));
+        RC(conv_wgrad(P, in, G[xi], dw, H, W, Cin, Cout, valid, side));
+        HIPRC(hipEventRecord(g_ev_free[xi], side));
+        pending[xi] = true;
+        return 0;
+    };
     for (int l = last_layer; l >= first_layer; --l) {
-        // "cnn" has no pool between conv4 and conv5, so from layer 3 down the ping-pong roles are swapped
-        const bool swapped = P.cnn && l <= 3;
-        void* const G0 = swapped ? GB : GA; void* const G1 = swapped ? GA : GB;
+        void* const X = l >= 2 ? G[XB[l]] : nullptr;
+        void* const Y = l >= 2 ? G[YB[l]] : nullptr;
+        void* const Yup = l <= 5 ? G[YB[l + 1]] : nullptr;      // gradient handed down by the layer above
         switch (l) {
-        case 6:   // d_y6 = d_img * (y6>0) -> G0 ; wgrad6 ; d_p5 = dgrad6 -> G1
-            RC(lxo_k_mask_convert(dt, P.ws<float>(ws, W_DIMG), P.ws<void>(ws, W_Y6), G0, gw(P_CONV6_B), (long long)B * P.R, C, st));
-            RC(conv_wgrad(P, P.ws<void>(ws, W_P5), G0, gw(P_CONV6_W), P.H6, P.W5, C, C, true, st));
-            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV6_D), G1, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, st));
+        case 6:   // d_y6 = d_img * (y6>0) -> X ; wgrad6 ; d_p5 = dgrad6 -> Y
+            RC(acquire(XB[6]));
+            RC(lxo_k_mask_convert(dt, P.ws<float>(ws, W_DIMG), P.ws<void>(ws, W_Y6), X, gw(P_CONV6_B), (long long)B * P.R, C, st));
+            RC(wgrad(P.ws<void>(ws, W_P5), XB[6], gw(P_CONV6_W), P.H6, P.W5, C, C, true));
+            RC(acquire(YB[6]));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, st));
             break;
-        case 5:   // d_y5 = route(d_p5 in G1) -> G0 ; wgrad5 ; d_p4 = dgrad5 -> G1
+        case 5:   // d_y5 = route(d_p5) -> X ; wgrad5 ; d_p4 = dgrad5 -> Y
+            RC(acquire(XB[5]));
             if (P.cnn) {
-                // strided conv backward: db = colsum(d_p5), dW = cols^T d_p5, d_cols = d_p5 W^T, d_y5 = col2im(d_cols) * (y5 > 0) -> G0
+                // strided conv backward: db = colsum(d_p5), dW = cols^T d_p5, d_cols = d_p5 W^T, d_y5 = col2im(d_cols) * (y5 > 0) -> X
                 const int M = B * P.H6 * P.W5;
-                RC(lxo_k_colsum_ct(dt, G1, gw(P_CONVS_B), M, C, st));
+                RC(lxo_k_colsum_ct(dt, Yup, gw(P_CONVS_B), M, C, st));
                 GemmTN t; memset(&t, 0, sizeof(t));
-                t.A = P.ws<void>(ws, W_COLS); t.B = G1; t.C = gw(P_CONVS_W); t.M = M; t.I = 8 * C; t.J = C;
+                t.A = P.ws<void>(ws, W_COLS); t.B = Yup; t.C = gw(P_CONVS_W); t.M = M; t.I = 8 * C; t.J = C;
                 t.lda = 8 * C; t.ldb = C; t.ldc = C;
                 { int ns = M / 2048; if (ns < 1) ns = 1; if (ns > 16) ns = 16; t.nsplit = ns; }
                 t.nbatch = 1; t.atomic = 1;
                 RC(lxo_launch_gemm_tn(dt, 0, 0, t, st));
                 GemmNT g; memset(&g, 0, sizeof(g));
-                g.A = G1; g.Bp = P.pk(wp, K_CONVS_D); g.C = P.ws<void>(ws, W_COLS);
+                g.A = Yup; g.Bp = P.pk(wp, K_CONVS_D); g.C = P.ws<void>(ws, W_COLS);
                 g.M = M; g.N = 8 * C; g.K = C; g.lda = C; g.ldb = C; g.ldc = 8 * C; g.alpha = 1.f; g.addend_rows = 1;
                 RC(lxo_launch_gemm_nt(dt, 0, 0, 0, g, st));
-                RC(lxo_k_col2im_s2_relu(dt, P.ws<void>(ws, W_COLS), P.ws<void>(ws, W_Y5), G0, gw(P_CONV5_B), B, P.H4, P.W2, P.H6, P.W5, C, st));
-                // conv5 at H2 x W2 on the un-pooled y4: d_y4 = dgrad5 * (y4 > 0) -> G1 (+ db4)
-                RC(conv_wgrad(P, P.ws<void>(ws, W_Y4), G0, gw(P_CONV5_W), P.H4, P.W2, 256, C, false, st));
-                RC(conv_dgrad(P, G0, P.pk(wp, K_CONV5_D), G1, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), st));
+                RC(lxo_k_col2im_s2_relu(dt, P.ws<void>(ws, W_COLS), P.ws<void>(ws, W_Y5), X, gw(P_CONV5_B), B, P.H4, P.W2, P.H6, P.W5, C, st));
+                // conv5 at H2 x W2 on the un-pooled y4: d_y4 = dgrad5 * (y4 > 0) -> Y (+ db4)
+                RC(wgrad(P.ws<void>(ws, W_Y4), XB[5], gw(P_CONV5_W), P.H4, P.W2, 256, C, false));
+                RC(acquire(YB[5]));
+                RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), st));
                 break;
             }
-            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), G1, G0, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
-            RC(conv_wgrad(P, P.ws<void>(ws, W_P4), G0, gw(P_CONV5_W), P.H4, P.W2, 256, C, false, st));
-            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV5_D), G1, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, st));
+            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            RC(wgrad(P.ws<void>(ws, W_P4), XB[5], gw(P_CONV5_W), P.H4, P.W2, 256, C, false));
+            RC(acquire(YB[5]));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, st));
             break;
-        case 4:   // d_y4 = route(d_p4 in G1) -> G0 ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> G1 (+ db3)
-            if (P.cnn) {     // d_y4 already masked, in G1: wgrad4 ; d_y3 -> G0 (layer 3 reads it as its G1: roles swap below)
-                RC(conv_wgrad(P, P.ws<void>(ws, W_Y3), G1, gw(P_CONV4_W), P.H2, P.W2, 256, 256, false, st));
-                RC(conv_dgrad(P, G1, P.pk(wp, K_CONV4_D), G0, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), st));
-                break;
+        case 4:   // d_y4 = route(d_p4) -> X (cnn: already there, masked) ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> Y (+ db3)
+            if (!P.cnn) {
+                RC(acquire(XB[4]));
+                RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
             }
-            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), G1, G0, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
-            RC(conv_wgrad(P, P.ws<void>(ws, W_Y3), G0, gw(P_CONV4_W), P.H2, P.W2, 256, 256, false, st));
-            RC(conv_dgrad(P, G0, P.pk(wp, K_CONV4_D), G1, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), st));
+            RC(wgrad(P.ws<void>(ws, W_Y3), XB[4], gw(P_CONV4_W), P.H2, P.W2, 256, 256, false));
+            RC(acquire(YB[4]));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV4_D), Y, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), st));
             break;
-        case 3:   // d_y3 in G1 ; wgrad3 ; d_p2 = dgrad3 -> G0
-            RC(conv_wgrad(P, P.ws<void>(ws, W_P2), G1, gw(P_CONV3_W), P.H2, P.W2, 128, 256, false, st));
-            RC(conv_dgrad(P, G1, P.pk(wp, K_CONV3_D), G0, P.H2, P.W2, 256, P.H2, P.W2, 128, false, nullptr, nullptr, st));
+        case 3:   // d_y3 = Y[4] (no pool) ; wgrad3 ; d_p2 = dgrad3 -> Y
+            RC(wgrad(P.ws<void>(ws, W_P2), XB[3], gw(P_CONV3_W), P.H2, P.W2, 128, 256, false));
+            RC(acquire(YB[3]));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV3_D), Y, P.H2, P.W2, 256, P.H2, P.W2, 128, false, nullptr, nullptr, st));
             break;
-        case 2:   // d_y2 = route(d_p2 in G0) -> G1 ; wgrad2 ; d_p1 = dgrad2 -> G0
-            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), G0, G1, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
-            RC(conv_wgrad(P, P.ws<void>(ws, W_P1), G1, gw(P_CONV2_W), P.H1, P.W1, 64, 128, false, st));
-            RC(conv_dgrad(P, G1, P.pk(wp, K_CONV2_D), G0, P.H1, P.W1, 128, P.H1, P.W1, 64, false, nullptr, nullptr, st));
+        case 2:   // d_y2 = route(d_p2) -> X ; wgrad2 ; d_p1 = dgrad2 -> Y
+            RC(acquire(XB[2]));
+            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            RC(wgrad(P.ws<void>(ws, W_P1), XB[2], gw(P_CONV2_W), P.H1, P.W1, 64, 128, false));
+            RC(acquire(YB[2]));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV2_D), Y, P.H1, P.W1, 128, P.H1, P.W1, 64, false, nullptr, nullptr, st));
             break;
-        case 1:   // d_p1 in G0 ; recompute conv1, route through pool+ReLU, dW1, db1
-            RC(lxo_k_conv1_pool_bwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], G0, gw(P_CONV1_W), gw(P_CONV1_B), B, P.s.H, P.s.W, st));
+        case 1:   // d_p1 = Y[2] ; recompute conv1, route through pool+ReLU, dW1, db1
+            RC(lxo_k_conv1_pool_bwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], G[YB[2]], gw(P_CONV1_W), gw(P_CONV1_B), B, P.s.H, P.s.W, st));
             break;
         default: return -4;
         }
+    }
+    if (side) {      // every weight gradient of this call is complete before the caller reduces / applies the gradients
+        HIPRC(hipEventRecord(g_ev_done, side));
+        HIPRC(hipStreamWaitEvent(st, g_ev_done, 0));
     }
     return 0;
 }

@@ -41,7 +41,7 @@ enum WsId {
     W_P1, W_Y2, W_P2, W_Y3, W_Y4, W_P4, W_Y5, W_P5, W_Y6, W_IMG, W_POS,
     W_ATT_IMG, W_APART, W_MEAN, W_EMB_IN, W_ZX, W_REC, W_CS, W_GATES, W_ATTH, W_ALPHA, W_LOGITS,
     W_DLOGITS, W_LOSS, W_DOLOG, W_G, W_DHC, W_DE, W_DATTH, W_DZ, W_DXH, W_DCC, W_DIMG, W_DATTIMG,
-    W_DEMB, W_DPRE0, W_DMEAN, W_G0, W_G1, W_GNORM,
+    W_DEMB, W_DPRE0, W_DMEAN, W_G0, W_G1, W_G2, W_GNORM,
     W_S_K1, W_S_K2, W_S_K4, W_S_B1, W_S_B3, W_S_B4,   // split-K slabs of the recurrent GEMMs
     // decode-only
     W_DEC_IDS, W_DEC_FLAGS, W_DEC_EMB, W_DEC_ZX, W_DEC_LOGITS, W_BEAM_LP, W_BEAM_PAR, W_BEAM_TMP,

@@ -41,7 +41,7 @@ static const char* kWsNames[W_COUNT] = {
     "p1", "y2", "p2", "y3", "y4", "p4", "y5", "p5", "y6", "img", "pos",
     "att_img", "att_part", "mean", "emb_in", "zx", "rec", "cs", "gates", "att_h", "alpha", "logits",
     "dlogits", "loss", "do_log", "g", "dhc", "de", "datth", "dz", "dxh", "dcc", "d_img", "d_att_img",
-    "d_emb", "dpre0", "dmean", "g0", "g1", "gnorm",
+    "d_emb", "dpre0", "dmean", "g0", "g1", "g2", "gnorm",
     "s_k1", "s_k2", "s_k4", "s_b1", "s_b3", "s_b4",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
     "cols",
@@ -144,7 +144,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     size_t gmax = wb[W_Y2];
     const size_t cand[] = {wb[W_P1], wb[W_P2], wb[W_Y3], wb[W_Y4], wb[W_P4], wb[W_Y5], wb[W_P5], wb[W_Y6]};
     for (size_t c : cand) if (c > gmax) gmax = c;
-    wb[W_G0] = gmax; wb[W_G1] = gmax;
+    wb[W_G0] = gmax; wb[W_G1] = gmax; wb[W_G2] = gmax;
     wb[W_GNORM] = 64;
     wb[W_S_K1] = (size_t)(XH / 128) * BK_ * 4 * U * f4;
     wb[W_S_K2] = (size_t)(U / 128) * BK_ * E * f4;

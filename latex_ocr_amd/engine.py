@@ -72,6 +72,10 @@ class Engine(object):
         self.side_stream = None
         if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "0") == "1":
             self.side_stream = torch.cuda.Stream(self.device)
+        # second stream for the encoder's weight-gradient kernels (overlaps them with the data-gradient chain)
+        self.enc_side = None
+        if self.device.type == "cuda" and os.environ.get("LXO_ENC_OVERLAP", "1") != "0":
+            self.enc_side = torch.cuda.Stream(self.device)
         self.load_params(PP.init_params(self.n_tok, seed, self.dims))
 
     # ------------------------------------------------------------ plumbing --
@@ -182,6 +186,9 @@ class Engine(object):
     def _bind_side(self):
         side = ctypes.c_void_p(self.side_stream.cuda_stream) if self.side_stream is not None else ctypes.c_void_p(0)
         self._ck(self.lib.lxo_set_side_stream(side), "set_side_stream")
+        es = getattr(self, "enc_side", None)
+        self._ck(self.lib.lxo_set_encoder_side_stream(ctypes.c_void_p(es.cuda_stream) if es is not None else ctypes.c_void_p(0)),
+                 "set_encoder_side_stream")
 
     def loss(self, lengths, inv_ntok):
         self._lengths = self._to_dev(lengths, torch.int32)
