@@ -72,9 +72,11 @@ class Engine(object):
         self.side_stream = None
         if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "0") == "1":
             self.side_stream = torch.cuda.Stream(self.device)
-        # second stream for the encoder's weight-gradient kernels (overlaps them with the data-gradient chain)
+        # optional second stream for the encoder's weight-gradient kernels (LXO_ENC_OVERLAP=1).  Measured slower in
+        # round 1 (15.9 vs 15.5 ms/step: both kernel families want a whole CU's LDS, so they only take CUs from each
+        # other), so it is off by default.
         self.enc_side = None
-        if self.device.type == "cuda" and os.environ.get("LXO_ENC_OVERLAP", "1") != "0":
+        if self.device.type == "cuda" and os.environ.get("LXO_ENC_OVERLAP", "0") == "1":
             self.enc_side = torch.cuda.Stream(self.device)
         self.load_params(PP.init_params(self.n_tok, seed, self.dims))
 
