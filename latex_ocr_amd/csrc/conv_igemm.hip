@@ -599,12 +599,211 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU variant (LXO_CONV_2WG=1; layers with Cout % 128 == 0): the same 8 x 32
+// pixel halo tile, but 128 channels wide, FOUR waves (each 2 tile rows x 128 channels = 2 x 4 MFMA
+// blocks, the same 0.75 ds_read_b128 per MFMA and 32 MFMAs per barrier) and 76 KB of LDS (ONE patch
+// buffer + two 128 x 64 weight stages), so that two workgroups share a CU: the prologue, the patch
+// reload between 64-channel slices and the epilogue of one workgroup run under the MFMAs of the other
+// instead of stalling a lone 160 KB workgroup.
+constexpr int WTHR = 256, WPSLOTS = 11 * WTHR;                        // 2816 slots >= 340 * 8
+constexpr int WPATCHB = WPSLOTS * 16, WBN = 128, WBSTAGE = WBN * CBK * 2;   // 45056, 16384
+constexpr int W2_LDS = WPATCHB + 2 * WBSTAGE;                          // 77824
+
+__global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    const int tx_i = mt % tiles_x, ty_i = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
+    const int oy0 = ty_i * QTH, ox0 = tx_i * QTW, n0 = nt * WBN;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + (long long)b * p.H * p.W * p.Cin;
+    const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
+    const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
+    char* patch0 = lxo_conv_lds;
+    char* bst0 = lxo_conv_lds + WPATCHB;
+
+    const int sch = tid & 7;
+    int a_src[11];
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+        const int prow = (tid >> 3) + 32 * j;
+        const int py = prow / QPW, px = prow - py * QPW;
+        const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+        const bool ok = prow < QPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        a_src[j] = ok ? (iy * p.W + ix) * p.Cin + ((sch ^ ((prow >> 1) & 7)) << 3) : -1;
+    }
+    const int srow = tid >> 3;                                     // weight rows srow + 32 j, j < 4 (all < N: N % 128 == 0)
+    const bf16_t* b_base = Bp + (long long)(n0 + srow) * p.ldb + ((sch ^ ((srow >> 1) & 7)) << 3);
+    const long long b_step = 32ll * p.ldb;                        // (srow + 32 j) >> 1 & 7 == srow >> 1 & 7
+    auto issue_patch = [&](int c) {                                // 11 LDS-DMA per thread
+        char* dst = patch0 + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const void* src = a_src[j] >= 0 ? (const void*)(A + a_src[j] + c * CBK) : (const void*)zline;
+            glds16(src, dst + 4096 * j);
+        }
+    };
+    auto issue_b = [&](int t, int stage) {                         // 4 LDS-DMA per thread
+        const int c = t / 9, tap = t - 9 * c;
+        const bf16_t* src = b_base + tap * p.Cin + c * CBK;
+        char* dst = bst0 + stage * WBSTAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(src + j * b_step, dst + 4096 * j);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int a_prow0 = (wave * 2) * QPW + (lane & 31);             // this wave's two tile rows
+    const int b_row0 = lane & 31;
+    const int khalf = lane >> 5;
+
+    const int nchunk = p.Cin / CBK, nk = nchunk * 9;
+    issue_patch(0);
+    issue_b(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        const int c = t / 9, tap = t - 9 * c;
+        LXO_VMCNT(0);                                              // B(t) (and, at t == 0, the first patch) have landed
+        __builtin_amdgcn_s_barrier();
+        if (tap == 0 && t > 0) {
+            // new 64-channel slice: every wave is past the old patch, so the single buffer can be refilled; the other
+            // workgroup of this CU computes while this one waits for it
+            issue_patch(c);
+            if (t + 1 < nk) { issue_b(t + 1, (t + 1) & 1); LXO_VMCNT(4); } else LXO_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+        } else if (t + 1 < nk) issue_b(t + 1, (t + 1) & 1);
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const char* bs = bst0 + (t & 1) * WBSTAGE;
+        const int prow_t = a_prow0 + kh * QPW + kw;
+        u32x4 af[2][2], bfr[2][4];
+        auto ldfrag = [&](int ks, u32x4 (&a2)[2], u32x4 (&b4)[4]) {
+            const int kc = ks * 2 + khalf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int br = b_row0 + 32 * j;
+                b4[j] = *reinterpret_cast<const u32x4*>(bs + br * 128 + ((kc ^ ((br >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int prow = prow_t + i * QPW;
+                a2[i] = *reinterpret_cast<const u32x4*>(patch0 + prow * 128 + ((kc ^ ((prow >> 1) & 7)) << 4));
+            }
+        };
+        ldfrag(0, af[0], bfr[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) ldfrag(ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ks & 1][i]),
+                                                                        __builtin_bit_cast(bf16x8_t, bfr[ks & 1][j]), acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: one wave's 64 pixels x 128 channels at a time through LDS as f32 [64][128 + 4] ----
+    bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(p.C);
+    bf16_t* __restrict__ Cpre = reinterpret_cast<bf16_t*>(p.out_pre);
+    const bf16_t* __restrict__ ref = reinterpret_cast<const bf16_t*>(p.relu_ref);
+    float* ot = reinterpret_cast<float*>(lxo_conv_lds);
+    constexpr int OP = WBN + 4;
+    const int c8 = (tid & 15) * 8, n = n0 + c8;
+    float bias8[8], csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias8[e] = p.bias ? p.bias[n + e] : 0.f; csum[e] = 0.f; }
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        if (wave == pass) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        ot[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf) * OP + j * 32 + (lane & 31)] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < 4; ++it) {
+            const int row = (tid >> 4) + 16 * it;                       // 0..63 within the pass
+            const int oy = oy0 + pass * 2 + (row >> 5), ox = ox0 + (row & 31);
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            const long long m = ((long long)b * p.Ho + oy) * p.Wo + ox;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ot + row * OP + c8), v1 = *reinterpret_cast<const f32x4*>(ot + row * OP + c8 + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = p.alpha * (e < 4 ? v0[e] : v1[e - 4]) + bias8[e];
+                if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+                else if (p.act == 2) v[e] = tanhf(v[e]);
+            }
+            if (Cpre) store8(Cpre + m * p.ldc + n, v);
+            if (p.addend) {
+                const float* ad = p.addend + (m % p.addend_rows) * p.N + n;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ad), a1 = *reinterpret_cast<const f32x4*>(ad + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (e < 4 ? a0[e] : a1[e - 4]);
+            }
+            if (ref) {
+                float rv[8];
+                load8(ref + m * p.ldr + n, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+            if (p.accumulate) {
+                float cv[8];
+                load8(C + m * p.ldc + n, cv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += cv[e];
+            }
+            store8(C + m * p.ldc + n, v);
+        }
+    }
+    if (p.colsum) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ot[(tid >> 4) * OP + c8 + e] = csum[e];
+        __syncthreads();
+        if (tid < WBN) {
+            float sres = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sres += ot[r * OP + tid];
+            atomicAdd(&p.colsum[n0 + tid], sres);
+        }
+    }
+}
+
 }  // namespace
 
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
     static int use_halo = -1;
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
+    static int use_2wg = -1;
+    if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '1') ? 1 : 0; }
+    if (use_halo && use_2wg && (p.N % WBN) == 0) {
+        static bool w_attr = false;
+        if (!w_attr) {
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+            w_attr = true;
+        }
+        const int B = p.M / (p.Ho * p.Wo);
+        const int tiles_n = p.N / WBN, tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
+        hipLaunchKernelGGL(conv_halo2wg_kernel, dim3(B * tiles_x * tiles_y * tiles_n), dim3(WTHR), W2_LDS, s, p, tiles_n, tiles_x, tiles_y);
+        return (int)hipGetLastError();
+    }
     static int use_256 = -1;
     if (use_256 < 0) { const char* e = getenv("LXO_CONV_256"); use_256 = (e && e[0] == '0') ? 0 : 1; }
     if (use_halo && use_256 && (p.N % QBN) == 0) {
