@@ -146,8 +146,8 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # dominant kernel: conv_halo256_kernel (the 8x32-pixel x 256-channel halo tiles; 7 of the 10 conv launches)
-        dom = [x for x in per if x["kernel"] == "conv_halo256_kernel"] or per
+        # dominant kernel: conv_halo2wg_kernel (8x32-pixel x 128-channel halo tiles, two workgroups per CU; 9 of the 10 conv launches)
+        dom = [x for x in per if x["kernel"] == "conv_halo2wg_kernel"] or per
         dflops, dsecs = sum(x["flops"] for x in dom), sum(x["us"] for x in dom) * 1e-6
         for x in per:
             x.pop("flops", None)

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
 
 
 // ------------------------------------------------------------------------------------------
-// Two-workgroups-per-CU variant (LXO_CONV_2WG=1; layers with Cout % 128 == 0): the same 8 x 32
+// Two-workgroups-per-CU variant (the default for layers with Cout % 128 == 0; LXO_CONV_2WG=0 falls back): the same 8 x 32
 // pixel halo tile, but 128 channels wide, FOUR waves (each 2 tile rows x 128 channels = 2 x 4 MFMA
 // blocks, the same 0.75 ds_read_b128 per MFMA and 32 MFMAs per barrier) and 76 KB of LDS (ONE patch
 // buffer + two 128 x 64 weight stages), so that two workgroups share a CU: the prologue, the patch
@@ -792,7 +792,7 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     static int use_halo = -1;
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
     static int use_2wg = -1;
-    if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '1') ? 1 : 0; }
+    if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }
     if (use_halo && use_2wg && (p.N % WBN) == 0) {
         static bool w_attr = false;
         if (!w_attr) {

@@ -19,5 +19,5 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 F=$(ls gpurun_out/${TAG}_pmc_FETCH_SIZE/*/*_results.db | head -1); Wd=$(ls gpurun_out/${TAG}_pmc_WRITE_SIZE/*/*_results.db | head -1)
-python tools/pmc_traffic.py $F $Wd gpurun_out/${TAG}_conv_traffic.json conv_halo256_kernel
+python tools/pmc_traffic.py $F $Wd gpurun_out/${TAG}_conv_traffic.json conv_halo2wg_kernel
 rm -rf gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE

@@ -16,7 +16,7 @@ def avg(dbpath, counter, pat):
 
 def main():
     fdb, wdb, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    pat = sys.argv[4] if len(sys.argv) > 4 else "conv_halo256_kernel"
+    pat = sys.argv[4] if len(sys.argv) > 4 else "conv_halo2wg_kernel"
     nf, f = avg(fdb, "FETCH_SIZE", pat)
     nw, w = avg(wdb, "WRITE_SIZE", pat)
     res = {"kernel": pat, "dispatches": nf, "fetch_size_kb_avg_raw": f, "write_size_kb_avg_raw": w,
