@@ -146,7 +146,7 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # dominant kernel: conv_halo2wg_kernel (8x32-pixel x 128-channel halo tiles, two workgroups per CU; 9 of the 10 conv launches)
+        # dominant kernel: conv_halo2wg_kernel (8x32-pixel halo tiles x 128 / 64 channels, two workgroups per CU; all ten conv launches)
         dom = [x for x in per if x["kernel"] == "conv_halo2wg_kernel"] or per
         dflops, dsecs = sum(x["flops"] for x in dom), sum(x["us"] for x in dom) * 1e-6
         for x in per:

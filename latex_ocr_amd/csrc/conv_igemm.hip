@@ -608,10 +608,12 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
 // reload between 64-channel slices and the epilogue of one workgroup run under the MFMAs of the other
 // instead of stalling a lone 160 KB workgroup.
 constexpr int WTHR = 256, WPSLOTS = 11 * WTHR;                        // 2816 slots >= 340 * 8
-constexpr int WPATCHB = WPSLOTS * 16, WBN = 128, WBSTAGE = WBN * CBK * 2;   // 45056, 16384
-constexpr int W2_LDS = WPATCHB + 2 * WBSTAGE;                          // 77824
+constexpr int WPATCHB = WPSLOTS * 16;                                  // 45056
 
+// NJ = 32-channel blocks per wave: 4 -> 128-channel tiles, 2 -> 64-channel tiles (Cout = 64: conv2's dgrad)
+template <int NJ>
 __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
+    constexpr int WBN = 32 * NJ, WBSTAGE = WBN * CBK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
         const bool ok = prow < QPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         a_src[j] = ok ? (iy * p.W + ix) * p.Cin + ((sch ^ ((prow >> 1) & 7)) << 3) : -1;
     }
-    const int srow = tid >> 3;                                     // weight rows srow + 32 j, j < 4 (all < N: N % 128 == 0)
+    const int srow = tid >> 3;                                     // weight rows srow + 32 j, j < NJ (all < N: N % WBN == 0)
     const bf16_t* b_base = Bp + (long long)(n0 + srow) * p.ldb + ((sch ^ ((srow >> 1) & 7)) << 3);
     const long long b_step = 32ll * p.ldb;                        // (srow + 32 j) >> 1 & 7 == srow >> 1 & 7
     auto issue_patch = [&](int c) {                                // 11 LDS-DMA per thread
@@ -646,19 +648,19 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
             glds16(src, dst + 4096 * j);
         }
     };
-    auto issue_b = [&](int t, int stage) {                         // 4 LDS-DMA per thread
+    auto issue_b = [&](int t, int stage) {                         // NJ LDS-DMA per thread
         const int c = t / 9, tap = t - 9 * c;
         const bf16_t* src = b_base + tap * p.Cin + c * CBK;
         char* dst = bst0 + stage * WBSTAGE + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(src + j * b_step, dst + 4096 * j);
+        for (int j = 0; j < NJ; ++j) glds16(src + j * b_step, dst + 4096 * j);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -677,17 +679,17 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
             // new 64-channel slice: every wave is past the old patch, so the single buffer can be refilled; the other
             // workgroup of this CU computes while this one waits for it
             issue_patch(c);
-            if (t + 1 < nk) { issue_b(t + 1, (t + 1) & 1); LXO_VMCNT(4); } else LXO_VMCNT(0);
+            if (t + 1 < nk) { issue_b(t + 1, (t + 1) & 1); LXO_VMCNT(NJ); } else LXO_VMCNT(0);
             __builtin_amdgcn_s_barrier();
         } else if (t + 1 < nk) issue_b(t + 1, (t + 1) & 1);
         const int kh = tap / 3, kw = tap - 3 * kh;
         const char* bs = bst0 + (t & 1) * WBSTAGE;
         const int prow_t = a_prow0 + kh * QPW + kw;
-        u32x4 af[2][2], bfr[2][4];
-        auto ldfrag = [&](int ks, u32x4 (&a2)[2], u32x4 (&b4)[4]) {
+        u32x4 af[2][2], bfr[2][NJ];
+        auto ldfrag = [&](int ks, u32x4 (&a2)[2], u32x4 (&b4)[NJ]) {
             const int kc = ks * 2 + khalf;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int br = b_row0 + 32 * j;
                 b4[j] = *reinterpret_cast<const u32x4*>(bs + br * 128 + ((kc ^ ((br >> 1) & 7)) << 4));
             }
@@ -705,19 +707,19 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ks & 1][i]),
                                                                         __builtin_bit_cast(bf16x8_t, bfr[ks & 1][j]), acc[i][j], 0, 0, 0);
         }
     }
 
-    // ---- epilogue: one wave's 64 pixels x 128 channels at a time through LDS as f32 [64][128 + 4] ----
+    // ---- epilogue: one wave's 64 pixels x WBN channels at a time through LDS as f32 [64][WBN + 4] ----
     bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(p.C);
     bf16_t* __restrict__ Cpre = reinterpret_cast<bf16_t*>(p.out_pre);
     const bf16_t* __restrict__ ref = reinterpret_cast<const bf16_t*>(p.relu_ref);
     float* ot = reinterpret_cast<float*>(lxo_conv_lds);
-    constexpr int OP = WBN + 4;
-    const int c8 = (tid & 15) * 8, n = n0 + c8;
+    constexpr int OP = WBN + 4, CH = 4 * NJ, RPI = 256 / CH;          // 16-byte chunks per row, rows per iteration
+    const int c8 = (tid % CH) * 8, n = n0 + c8;
     float bias8[8], csum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bias8[e] = p.bias ? p.bias[n + e] : 0.f; csum[e] = 0.f; }
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
         __syncthreads();
         if (wave == pass) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -734,8 +736,8 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
         }
         __syncthreads();
 #pragma unroll 2
-        for (int it = 0; it < 4; ++it) {
-            const int row = (tid >> 4) + 16 * it;                       // 0..63 within the pass
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = tid / CH + RPI * it;                        // 0..63 within the pass
             const int oy = oy0 + pass * 2 + (row >> 5), ox = ox0 + (row & 31);
             if (oy >= p.Ho || ox >= p.Wo) continue;
             const long long m = ((long long)b * p.Ho + oy) * p.Wo + ox;
@@ -774,12 +776,12 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
     if (p.colsum) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ot[(tid >> 4) * OP + c8 + e] = csum[e];
+        for (int e = 0; e < 8; ++e) ot[(tid / CH) * OP + c8 + e] = csum[e];
         __syncthreads();
         if (tid < WBN) {
             float sres = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sres += ot[r * OP + tid];
+            for (int r = 0; r < RPI; ++r) sres += ot[r * OP + tid];
             atomicAdd(&p.colsum[n0 + tid], sres);
         }
     }
@@ -793,15 +795,20 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
     static int use_2wg = -1;
     if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }
-    if (use_halo && use_2wg && (p.N % WBN) == 0) {
+    if (use_halo && use_2wg && (p.N % 64) == 0) {
         static bool w_attr = false;
+        constexpr int LDS4 = WPATCHB + 2 * 128 * CBK * 2, LDS2 = WPATCHB + 2 * 64 * CBK * 2;     // 77824, 61440
         if (!w_attr) {
-            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
             w_attr = true;
         }
         const int B = p.M / (p.Ho * p.Wo);
-        const int tiles_n = p.N / WBN, tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
-        hipLaunchKernelGGL(conv_halo2wg_kernel, dim3(B * tiles_x * tiles_y * tiles_n), dim3(WTHR), W2_LDS, s, p, tiles_n, tiles_x, tiles_y);
+        const int tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
+        if (p.N % 128 == 0)
+            hipLaunchKernelGGL(conv_halo2wg_kernel<4>, dim3(B * tiles_x * tiles_y * (p.N / 128)), dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL(conv_halo2wg_kernel<2>, dim3(B * tiles_x * tiles_y * (p.N / 64)), dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
         return (int)hipGetLastError();
     }
     static int use_256 = -1;

@@ -357,7 +357,7 @@ class Engine(object):
                 e1.record(torch.cuda.current_stream(self.device))
                 e1.synchronize()
                 sec = e0.elapsed_time(e1) * 1e-3 / reps
-                out.append({"launch": name + "_" + kind, "kernel": "conv_halo2wg_kernel" if n_out % 128 == 0 else "conv_halo_kernel",
+                out.append({"launch": name + "_" + kind, "kernel": "conv_halo2wg_kernel" if n_out % 64 == 0 else "conv_halo_kernel",
                             "us": round(sec * 1e6, 1), "tflops": round(flops / sec / 1e12, 1), "flops": flops})
                 flops_tot += flops; t_tot += sec
         return flops_tot, t_tot, out
