@@ -149,116 +149,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// Two-workgroups-per-CU variant (LXO_WGRAD_2WG=1): 4 waves own a (64 ci) x (64 co) tile of all nine taps and stage
-// ONE 2 x 64 pixel block at a time (52 KB), so that two workgroups share a CU: the block loads and the 36,864 f32
-// atomics of one workgroup's epilogue run under the MFMAs of the other.  d_out rows are 128 bytes here and use the
-// patch's swizzle (key = (pixel >> 1) & 7).
-constexpr int W2THR = 256;
-constexpr int W2PATCH = 9 * W2THR * 16;             // 36864 B: 2304 slots >= 264 * 8
-constexpr int W2DY = WTH * WTW * 128;               // 16384 B: 128 pixels x 64 co
-constexpr int W2STAGE = W2PATCH + W2DY;             // 53248 B
-constexpr int W2CO = 64;
-
-__global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(GemmTN p, int tiles_co, int tiles_x, int tiles_y, int nblocks, int per_split) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wci = wave >> 1, wco = wave & 1;            // 2 x 2 waves: 32 ci x 32 co each (x 9 taps)
-    const int tile = blockIdx.x, split = blockIdx.y;
-    const int ci0 = (tile / tiles_co) * WCI, co0 = (tile % tiles_co) * W2CO;
-    const int Cout = p.J;
-    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.A);
-    const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(p.B);
-    const char* zline = reinterpret_cast<const char*>(lxo_wg_zero_line);
-    const int pb_beg = split * per_split, pb_end = min(nblocks, pb_beg + per_split);
-    if (pb_beg >= pb_end) return;
-    char* ps = lxo_wgrad_lds;
-    char* ds = ps + W2PATCH;
-    const int sch = tid & 7;                               // 16-byte chunk (8 channels) of a 64-channel row (patch and d_out alike)
-    auto issue = [&](int pb) {
-        const int tx_i = pb % tiles_x, ty_i = (pb / tiles_x) % tiles_y, b = pb / (tiles_x * tiles_y);
-        const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {                      // 9 LDS-DMA: patch pixel prow = (tid >> 3) + 32 j
-            const int prow = (tid >> 3) + 32 * j;
-            const int py = prow / WPW, px = prow - py * WPW;
-            const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
-            const bool ok = prow < WPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const int gch = (sch ^ ((prow >> 1) & 7)) << 3;
-            const void* src = ok ? (const void*)(X + (((long long)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + gch) : (const void*)zline;
-            glds16(src, ps + (wave * 64 + 256 * j) * 16);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                      // 4 LDS-DMA: block pixel k = (tid >> 3) + 32 j
-            const int k = (tid >> 3) + 32 * j;
-            const int oy = oy0 + (k >> 6), ox = ox0 + (k & 63);
-            const int gch = (sch ^ ((k >> 1) & 7)) << 3;
-            const bool ok = oy < p.Ho && ox < p.Wo && (co0 + gch) < Cout;
-            const void* src = ok ? (const void*)(DY + (((long long)b * p.Ho + oy) * p.Wo + ox) * Cout + co0 + gch) : (const void*)zline;
-            glds16(src, ds + (wave * 64 + 256 * j) * 16);
-        }
-    };
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    const int h = lane >> 5, g = (lane >> 4) & 1, qj = (lane & 15) >> 2, qc = lane & 3;
-    const int a_ch = wci * 32 + 16 * g + 4 * qc;
-    const int a_chunk = a_ch >> 3, a_sub = (a_ch & 7) * 2;
-    const int b_ch = wco * 32 + 16 * g + 4 * qc;           // channel within the 64
-    const int b_chunk = b_ch >> 3, b_sub = (b_ch & 7) * 2;
-
-    for (int pb = pb_beg; pb < pb_end; ++pb) {
-        __builtin_amdgcn_s_barrier();                       // every wave is done reading the previous block
-        issue(pb);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
-        __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-        for (int ks = 0; ks < 8; ++ks) {
-            const int ty = ks >> 2, xk = (ks & 3) * 16 + 8 * h;
-            u32x4 bfr;
-            {
-                const int k0 = ty * 64 + xk;
-                const int ka = k0 + qj, kb = k0 + 4 + qj;
-                const u32x2 lo = tr_read(ds + ka * 128 + ((b_chunk ^ ((ka >> 1) & 7)) << 4) + b_sub);
-                const u32x2 hi = tr_read(ds + kb * 128 + ((b_chunk ^ ((kb >> 1) & 7)) << 4) + b_sub);
-                bfr = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int pr0 = (ty + kh) * WPW + xk;
-                unsigned d[6];
-#pragma unroll
-                for (int q3 = 0; q3 < 3; ++q3) {
-                    const int prow = pr0 + 4 * q3 + qj;
-                    const u32x2 v = tr_read(ps + prow * 128 + ((a_chunk ^ ((prow >> 1) & 7)) << 4) + a_sub);
-                    d[2 * q3] = v[0]; d[2 * q3 + 1] = v[1];
-                }
-                const u32x4 a0 = {d[0], d[1], d[2], d[3]};
-                const u32x4 a1 = {__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
-                                  __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16)};
-                const u32x4 a2 = {d[1], d[2], d[3], d[4]};
-                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 0], 0, 0, 0);
-                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 1], 0, 0, 0);
-                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 2], 0, 0, 0);
-            }
-        }
-    }
-    const int co = co0 + wco * 32 + (lane & 31);
-    if (co < Cout) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ci = ci0 + wci * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (ci < p.Cin) atomicAdd(&p.C[((long long)t * p.Cin + ci) * p.ldc + co], acc[t][e]);
-            }
-    }
-}
-
 }  // namespace
 
 // bf16 only; Cin % 64 == 0, Cout % 8 == 0
@@ -273,19 +163,6 @@ int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     const int tiles_ci = p.Cin / WCI, tiles_co = cdiv(p.J, WCO);
     const int tiles_x = cdiv(p.Wo, WTW), tiles_y = cdiv(p.Ho, WTH);
     const int nblocks = B * tiles_x * tiles_y;
-    static int use2 = -1;
-    if (use2 < 0) { const char* e = getenv("LXO_WGRAD_2WG"); use2 = (e && e[0] == '1') ? 1 : 0; }
-    if (use2) {
-        static bool attr2 = false;
-        if (!attr2) { HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2STAGE)); attr2 = true; }
-        const int tco = cdiv(p.J, W2CO), tiles2 = tiles_ci * tco;
-        int ns = cdiv(512, tiles2);
-        if (ns > nblocks) ns = nblocks;
-        const int per = cdiv(nblocks, ns);
-        ns = cdiv(nblocks, per);
-        hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(tiles2, ns), dim3(W2THR), W2STAGE, s, p, tco, tiles_x, tiles_y, nblocks, per);
-        return (int)hipGetLastError();
-    }
     const int tiles = tiles_ci * tiles_co;
     int nsplit = cdiv(256, tiles);
     if (nsplit > nblocks) nsplit = nblocks;
