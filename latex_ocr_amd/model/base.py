@@ -13,6 +13,31 @@ import numpy as np
 from .utils.general import get_logger, init_dir
 
 
+def adam_steps_from_powers(beta1_power, beta2_power=None, beta1=0.9, beta2=0.999):
+    """Steps taken by a tf.train.AdamOptimizer from its saved accumulators.  TF creates `beta1_power` = beta1 and
+    multiplies it by beta1 AFTER every update, so after t steps it holds beta1^(t+1) (same for beta2_power).  In float32
+    0.9^t underflows to 0 after ~1000 steps, so a realistically trained checkpoint has beta1_power == 0: fall back to
+    beta2_power (0.999^t is representable up to ~87k steps), and past that to a large t whose bias corrections are 1.
+    Never raises: a weights restore must not fail on optimizer metadata."""
+    def steps(p, beta):
+        try:
+            p = float(np.asarray(p).reshape(-1)[0])
+        except Exception:
+            return None
+        if not np.isfinite(p) or p <= 0.0 or p >= 1.0:
+            return None
+        return max(0, int(round(np.log(p) / np.log(beta))) - 1)
+    t1 = steps(beta1_power, beta1) if beta1_power is not None else None
+    t2 = steps(beta2_power, beta2) if beta2_power is not None else None
+    if t1 is not None and t1 < 600:           # float32 0.9^t still carries >= 3 significant digits here
+        return t1
+    if t2 is not None:
+        return t2
+    if t1 is not None:
+        return t1
+    return 1000000
+
+
 class BaseModel(object):
     def __init__(self, config, dir_output):
         """Reference: model/base.py:12-23."""
@@ -86,8 +111,8 @@ class BaseModel(object):
                 off += n
             if "optimize/adam_t" in z:
                 t = int(np.asarray(z["optimize/adam_t"]).reshape(-1)[0])
-            else:       # tf.train.AdamOptimizer keeps beta1^t in `beta1_power` (default beta1 = 0.9)
-                t = int(round(np.log(float(np.asarray(z["optimize/beta1_power"]).reshape(-1)[0])) / np.log(0.9)))
+            else:
+                t = adam_steps_from_powers(z.get("optimize/beta1_power"), z.get("optimize/beta2_power"))
             sd.update(adam_m=m, adam_v=v, adam_t=t)
         self._lr_state = {k[len("lxo/lr_schedule/"):]: z[k] for k in z if k.startswith("lxo/lr_schedule/")}
         self.engine.load_state_dict(sd)

@@ -67,7 +67,10 @@ def test_convert_between_containers(tmp_path):
     for k, v in P.items():
         assert np.array_equal(back[k], np.asarray(v, np.float32))
         assert np.array_equal(back["optimize/" + k + "/Adam_1"], arrays["optimize/" + k + "/Adam_1"])
-    assert int(round(np.log(float(back["optimize/beta1_power"])) / np.log(0.9))) == 7
+    from latex_ocr_amd.model.base import adam_steps_from_powers
+    # TF convention: beta^(t+1) after t steps
+    assert abs(float(back["optimize/beta1_power"]) - 0.9 ** 8) < 1e-7
+    assert adam_steps_from_powers(back["optimize/beta1_power"], back["optimize/beta2_power"]) == 7
     w = CC.main([src, str(tmp_path / "w.npz"), "--weights-only"])
     assert set(w) == set(P)
 
@@ -84,3 +87,16 @@ def test_lr_schedule_state_round_trip():
         a.update(batch_no=i); b.update(batch_no=i)
     a.update(score=-5.0); b.update(score=-5.0)
     assert b.lr == a.lr and b.stop_training == a.stop_training
+
+
+def test_adam_steps_from_tf_powers_survive_underflow():
+    """A realistically trained reference checkpoint: float32 0.9^(t+1) has underflowed to 0."""
+    from latex_ocr_amd.model.base import adam_steps_from_powers as f
+    assert f(np.float32(0.9), np.float32(0.999)) == 0                       # freshly initialised optimizer
+    assert f(np.float32(0.9 ** 11), np.float32(0.999 ** 11)) == 10
+    t = 20000
+    assert f(np.float32(0.0), np.float32(0.999 ** (t + 1))) in range(t - 2, t + 3)
+    assert f(np.float32(0.9 ** (t + 1)), np.float32(0.999 ** (t + 1))) in range(t - 2, t + 3)
+    assert f(np.float32(0.0), np.float32(0.0)) >= 100000                     # both gone: bias corrections ~ 1
+    assert f(np.float32(0.0), None) >= 100000
+    assert f(np.float32(np.nan), np.float32(np.inf)) >= 100000

@@ -125,16 +125,29 @@ def test_loss_trajectory_bf16():
 
 
 def test_greedy_bf16_agreement():
+    """bf16 decode against the f32 oracle: >= 99 % of the ids identical; every mismatch is reported with the oracle's
+    top1 - top2 logit margin at that step (a bf16 flip needs a near-tie; rows are compared up to their first
+    divergence, later ids of that row follow a different input history)."""
     V = 50
     imgs, _ = synthetic.config1()
     img = pad_batch_images(imgs[:40])
     eng = Engine(V, dtype="bf16", seed=5)
     ids = eng.greedy_decode(img, V - 1, max_iter=20)
-    ref = R.greedy_decode(oracle_params(eng), torch.from_numpy(img), V - 1, max_iter=20).numpy()
+    ref, logits = R.greedy_decode(oracle_params(eng), torch.from_numpy(img), V - 1, max_iter=20, return_logits=True)
+    ref = ref.numpy()
     T = min(ids.shape[1], ref.shape[1])
     agree = float((ids[:, :T] == ref[:, :T]).mean())
-    print("bf16 greedy id agreement vs f32 oracle: %.4f" % agree)
-    assert agree > 0.5
+    n_div = 0
+    for b in range(ids.shape[0]):
+        d = np.nonzero(ids[b, :T] != ref[b, :T])[0]
+        if len(d):
+            n_div += 1
+            t = int(d[0])
+            top2 = torch.topk(logits[b, t], 2).values
+            print("row %d diverges at step %d: hip %d oracle %d, oracle top1-top2 margin %.3e" % (b, t, ids[b, t], ref[b, t], float(top2[0] - top2[1])))
+    print("bf16 greedy id agreement vs f32 oracle: %.4f (%d of %d rows diverge)" % (agree, n_div, ids.shape[0]))
+    assert ids.shape[1] == ref.shape[1]
+    assert agree >= 0.99
 
 
 def test_beam_f32():

@@ -1,7 +1,9 @@
-"""CPU: the oracle itself.  PARITY UNPINNED against the reference (TF-1.12 graph cannot run,
-no golden vectors ship with it), so the oracle is held to: the geometry known-answers of
-SURVEY.md section 4, an independent float64 NumPy restatement, committed golden outputs
-(drift), and closed-form checks of the TF-specific semantics it encodes."""
+"""CPU: the oracle itself.  The ENCODER half is pinned to reference code run in the build container
+(tests/golden/ref_encoder.npz, written by tests/golden/make_ref_encoder_golden.py from the reference's
+own torch conv stack + positional signal, model/components/seq2seq_torch.py:24-55,113-156).  The DECODER
+half stays unpinned (the TF-1.12 graph cannot run, no golden vectors ship with it) and is held to: the
+geometry known-answers of SURVEY.md section 4, an independent float64 NumPy restatement, committed
+golden outputs (drift), and closed-form checks of the TF-specific semantics it encodes."""
 import os
 
 import numpy as np
@@ -12,6 +14,37 @@ from oracle import np_micro as M
 from oracle import ref_model as R
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_small.npz"))
+
+
+REFENC = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_encoder.npz"))
+
+
+def _pinned_params():
+    """Oracle seed-0 weights with the non-zero conv biases make_ref_encoder_golden.py used."""
+    P = R.init_params(50, seed=0)
+    rng = np.random.Generator(np.random.PCG64(int(REFENC["bias_seed"])))
+    for k in list(P):
+        if k.startswith("Encoder") and k.endswith("/bias"):
+            P[k] = torch.from_numpy(rng.uniform(-0.05, 0.05, size=tuple(P[k].shape)).astype(np.float32))
+    return P
+
+
+def test_encoder_pinned_to_reference_torch_stack():
+    """oracle encoder() == the reference's own EncoderCNN("vanilla") (+ its add_timing_signal_nd_torch) on the
+    same weights and crops: 32x128 in full, 128x512 on a strided sample plus per-channel sums of the whole map."""
+    P = _pinned_params()
+    s = torch.from_numpy(REFENC["img_32x128"]); b = torch.from_numpy(REFENC["img_128x512"])
+    for pos, tag in ((False, "nopos"), (True, "pos")):
+        got = R.encoder(P, s, positional=pos).numpy()
+        want = REFENC["feat_32x128_" + tag]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (tag, np.abs(got - want).max())
+        gb = R.encoder(P, b, positional=pos).numpy()
+        assert gb.shape == (1, 14, 62, 512)
+        ws = REFENC["feat_128x512_%s_sample" % tag]
+        assert np.abs(gb[:, ::3, ::5, ::4] - ws).max() <= 2e-5 * max(1.0, np.abs(ws).max())
+        cs = REFENC["feat_128x512_%s_chansum" % tag]
+        assert np.abs(gb.astype(np.float64).sum(axis=(0, 1, 2)) - cs).max() <= 1e-5 * max(1.0, np.abs(cs).max())
 
 
 def test_geometry_known_answers():

@@ -33,8 +33,8 @@ def save_any(arrays, dst, kind):
         out = dict(arrays)
         if "optimize/adam_t" in out:         # tf.train.AdamOptimizer stores the powers, not the step count
             t = int(np.asarray(out.pop("optimize/adam_t")).reshape(-1)[0])
-            out["optimize/beta1_power"] = np.float32(0.9 ** t)
-            out["optimize/beta2_power"] = np.float32(0.999 ** t)
+            out["optimize/beta1_power"] = np.float32(0.9 ** (t + 1))      # TF holds beta^(t+1) after t steps
+            out["optimize/beta2_power"] = np.float32(0.999 ** (t + 1))
         write_bundle(dst, {k: v for k, v in out.items() if not k.startswith("lxo/")})
     else:
         raise ValueError(kind)
