@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=500)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline timing only (for profiler runs): no roofline micro-timings, no secondary keys")
     args = ap.parse_args()
     if args.dtype != "bf16":
         ap.error("bench.py measures the bf16 path (the metric's dtype); f32 is the parity mode exercised by tests/")
@@ -136,7 +137,10 @@ def main():
     value = B * world / (dt / args.steps)
 
     out = None
-    if rank == 0:
+    if rank == 0 and args.no_extras:
+        print(json.dumps({"metric": "formula-images/sec training step (batch 64, 128x512)", "value": round(value, 2), "unit": "img/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3)}), flush=True)
+    elif rank == 0:
         # ---- roofline of the dominant kernel family: the implicit-GEMM conv (MFMA bound) ----
         flops, secs, per = eng.time_conv_gemms(B, H, W)
         traffic = None

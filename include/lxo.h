@@ -72,6 +72,16 @@ int lxo_attention_fwd(int dt, const void* att_img, const void* img, const float*
                       float* alpha, float* part, float* ctx, int ldctx, int nv, int R, int E, int C, int beam,
                       void* stream);
 
+/* Measurement aid (off by default, per host thread): with timing enabled every implicit-GEMM conv launch (forward,
+ * data gradient, weight gradient) and every attention launch of the lxo_encoder_* / lxo_decoder_train_* calls is
+ * bracketed by HIP events on the stream it is launched on, so that bench.py's roofline comes from kernel durations
+ * INSIDE a real training step.  lxo_timing_enable(1) clears the records; lxo_timing_get synchronises record i and returns
+ * its family ("conv_fwd", "conv_dgrad", "conv_wgrad", "attn_fwd", "attn_bwd"), name, algorithmic work (FLOPs or bytes)
+ * and duration in milliseconds. */
+int lxo_timing_enable(int on);
+int lxo_timing_count(void);
+int lxo_timing_get(int i, const char** family, const char** name, double* work, float* ms);
+
 /* ---- the hot path proper ---- */
 
 /* Shape of one call.  H, W are the batch-max image extents after white padding
@@ -98,6 +108,10 @@ typedef struct lxo_shape {
      * no_positional != 0 = positional_embeddings false (encoder.py:60-65 skipped) */
     int encoder_cnn;
     int no_positional;
+    /* decoder step decomposition: 0 (default) = full-K workgroups with the cell's point-wise stages fused into the GEMM
+     * epilogues (csrc/rstep.hip: 9 dependent launches per training step pair); 1 = the split-K slab GEMMs + separate
+     * point-wise kernels of round 1 (13 launches; also what the *_active entry points and the side-stream interleave use) */
+    int step_kernels;
 } lxo_shape;
 
 /* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF
@@ -158,10 +172,20 @@ int lxo_decoder_train_bwd_active(const lxo_shape* s, const float* params, const 
  * unmasked tokens in the GLOBAL batch).  ws region "loss" = {sum CE, token count}. */
 int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula,
                         const int32_t* lengths, float inv_ntok, void* stream);
+/* The same with the GLOBAL token count read from device memory (*ntok_dev, a float): under data parallelism the count is
+ * the sum over ranks of host-known integers, all-reduced on a side stream while the forward runs, so no host
+ * synchronisation sits between forward and backward (img2seq.py:69-71 takes the mean over all tokens of the batch). */
+int lxo_ce_loss_fwd_bwd_dev(const lxo_shape* s, void* ws, const int32_t* formula,
+                            const int32_t* lengths, const float* ntok_dev, void* stream);
 /* BPTT through the decoder (what TF autodiff does for img2seq.py:119-123);
  * accumulates decoder gradients into grads and leaves d(enc) in ws region "d_img". */
 int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                           const int32_t* formula, float* grads, void* stream);
+/* The same in two parts so that a data-parallel caller can start reducing gradients before the recurrence has run:
+ * parts bit 0 = d_o from the logits for every step + the y_W_o gradient (final after this part);
+ * parts bit 1 = BPTT, every other decoder gradient and d(enc).  active_rows = NULL or as in the _active calls. */
+int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                               const int32_t* formula, float* grads, const int32_t* active_rows, int parts, void* stream);
 
 /* tf.clip_by_global_norm scale (img2seq.py:119-121): scale_out[0] = clip / max(||g||, clip),
  * scale_out[1] = ||g|| ; device memory, no host sync.  clip <= 0 -> scale 1. */

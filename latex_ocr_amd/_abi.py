@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")
 class LxoShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("B", "H", "W", "T", "V", "C", "E", "U", "O", "D", "dtype", "beam", "max_steps")] + \
                [("keep_prob", c_float), ("dropout_seed", c_int), ("div_gamma", c_float), ("div_prob", c_float), ("div_seed", c_int),
-                ("encoder_cnn", c_int), ("no_positional", c_int)]
+                ("encoder_cnn", c_int), ("no_positional", c_int), ("step_kernels", c_int)]
 
 
 def bind(lib):
@@ -32,6 +32,9 @@ def bind(lib):
         "lxo_conv3x3_wgrad": (c_int, [c_int, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
         "lxo_gemm_slab": (c_int, [c_int, c_void, c_void, c_void] + [c_int] * 6 + [c_ll, c_void]),
         "lxo_attention_fwd": (c_int, [c_int] + [c_void] * 7 + [c_int] * 6 + [c_void]),
+        "lxo_timing_enable": (c_int, [c_int]),
+        "lxo_timing_count": (c_int, []),
+        "lxo_timing_get": (c_int, [c_int, P(ctypes.c_char_p), P(ctypes.c_char_p), P(ctypes.c_double), P(c_float)]),
         "lxo_param_num": (c_int, []),
         "lxo_param_name": (ctypes.c_char_p, [c_int]),
         "lxo_param_name_for": (ctypes.c_char_p, [S, c_int]),
@@ -49,6 +52,8 @@ def bind(lib):
         "lxo_decoder_train_fwd_active": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void]),
         "lxo_decoder_train_bwd_active": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
         "lxo_ce_loss_fwd_bwd": (c_int, [S, c_void, c_void, c_void, c_float, c_void]),
+        "lxo_ce_loss_fwd_bwd_dev": (c_int, [S, c_void, c_void, c_void, c_void, c_void]),
+        "lxo_decoder_train_bwd_part": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_void]),
         "lxo_decoder_train_bwd": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void]),
         "lxo_global_norm_scale": (c_int, [c_ll, c_void, c_float, c_void, c_void]),
         "lxo_adam_step": (c_int, [c_ll, c_void, c_void, c_void, c_void, c_float, c_float, c_float, c_float, c_void, c_void]),
@@ -69,10 +74,10 @@ def bind(lib):
     return lib
 
 
-ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name", "lxo_param_name_for",
+ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_timing_enable", "lxo_timing_count", "lxo_timing_get", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name", "lxo_param_name_for",
                 "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
                 "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_set_side_stream", "lxo_set_encoder_side_stream", "lxo_decoder_train_fwd", "lxo_decoder_train_fwd_active", "lxo_decoder_train_bwd_active",
-                "lxo_ce_loss_fwd_bwd", "lxo_decoder_train_bwd", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",
+                "lxo_ce_loss_fwd_bwd", "lxo_ce_loss_fwd_bwd_dev", "lxo_decoder_train_bwd", "lxo_decoder_train_bwd_part", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",
                 "lxo_greedy_decode", "lxo_greedy_decode_attn", "lxo_beam_decode"]
 
 _lib = None

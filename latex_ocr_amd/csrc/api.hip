@@ -106,20 +106,35 @@ extern "C" int lxo_decoder_train_fwd_active(const lxo_shape* s, const float* par
 extern "C" int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula, const int32_t* lengths,
                                    float inv_ntok, void* stream) {
     MAKE_PLAN(P, s);
-    CHECK_LAUNCH(lxo_impl_ce_loss(P, ws, formula, lengths, inv_ntok, (hipStream_t)stream), "lxo_ce_loss_fwd_bwd");
+    CHECK_LAUNCH(lxo_impl_ce_loss(P, ws, formula, lengths, inv_ntok, nullptr, (hipStream_t)stream), "lxo_ce_loss_fwd_bwd");
+    return 0;
+}
+extern "C" int lxo_ce_loss_fwd_bwd_dev(const lxo_shape* s, void* ws, const int32_t* formula, const int32_t* lengths,
+                                       const float* ntok_dev, void* stream) {
+    MAKE_PLAN(P, s);
+    if (!ntok_dev) return fail(-1, "lxo_ce_loss_fwd_bwd_dev: null token count");
+    CHECK_LAUNCH(lxo_impl_ce_loss(P, ws, formula, lengths, 0.f, ntok_dev, (hipStream_t)stream), "lxo_ce_loss_fwd_bwd_dev");
     return 0;
 }
 extern "C" int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                                      const int32_t* formula, float* grads, void* stream) {
     MAKE_PLAN(P, s);
-    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, nullptr, (hipStream_t)stream), "lxo_decoder_train_bwd");
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, nullptr, 3, (hipStream_t)stream), "lxo_decoder_train_bwd");
+    return 0;
+}
+extern "C" int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                          const int32_t* formula, float* grads, const int32_t* active_rows, int parts, void* stream) {
+    MAKE_PLAN(P, s);
+    if (parts < 1 || parts > 3) return fail(-1, "lxo_decoder_train_bwd_part: parts must be 1, 2 or 3");
+    if (active_rows) { if (int rc = check_active(s, active_rows)) return rc; }
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, active_rows, parts, (hipStream_t)stream), "lxo_decoder_train_bwd_part");
     return 0;
 }
 extern "C" int lxo_decoder_train_bwd_active(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                                             const int32_t* formula, float* grads, const int32_t* active_rows, void* stream) {
     MAKE_PLAN(P, s);
     if (int rc = check_active(s, active_rows)) return rc;
-    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, active_rows, (hipStream_t)stream), "lxo_decoder_train_bwd_active");
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, active_rows, 3, (hipStream_t)stream), "lxo_decoder_train_bwd_active");
     return 0;
 }
 extern "C" int lxo_global_norm_scale(long long n, const float* grads, float clip, float* scale_out, void* stream) {
@@ -179,7 +194,7 @@ extern "C" int lxo_attention_fwd(int dt, const void* att_img, const void* img, c
     const int by_rows = R / 32 > 0 ? R / 32 : 1; if (nch > by_rows) nch = by_rows;
     const int need = (R + 1023) / 1024; if (nch < need) nch = need;
     Slabs none = {nullptr, 0, 0, 0};
-    CHECK_LAUNCH(lxo_k_attn_fwd(dt, att_img, img, att_h, none, nullptr, beta, alpha, part, ctx, ldctx, nv, R, (R + 7) / 8 * 8, E, C, beam < 1 ? 1 : beam,
+    CHECK_LAUNCH(lxo_k_attn_fwd(dt, att_img, img, att_h, none, nullptr, beta, alpha, part, ctx, ldctx, nullptr, 0, nv, R, (R + 7) / 8 * 8, E, C, beam < 1 ? 1 : beam,
                                 nch, (hipStream_t)stream), "lxo_attention_fwd");
     return 0;
 }

@@ -13,19 +13,21 @@ int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* 
 int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, float* ht_out, int ldh, Drop dr, int B, int U, hipStream_t st);
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                    float* dcc, float* dz, Drop dr, int carry_rows, int B, int U, hipStream_t st);
-int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, Drop dr, int carry_rows, int rows, int cols, hipStream_t st);
+// gb (nullable): bf16 copy of g [rows][ldg] (A operand of the fused [d_h~|d_ctx] GEMM)
+int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, void* gb, int ldgb, Drop dr, int carry_rows, int rows, int cols, hipStream_t st);
 int lxo_k_slab_reduce(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st);
 int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, Drop dr, int rows, int cols, hipStream_t st);
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
-                   float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st);
+                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st);   // ctxb (nullable): bf16 copy of ctx, pitch ldcb
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
                    Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
                    int nv, int R, int Rp, int E, int C, int nch, hipStream_t st);
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
                    int T, int B, int R, int Rp, int E, hipStream_t st);
 int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st);
+// ntok_dev (nullable): device scalar holding the global token count; when set the kernel uses 1 / *ntok_dev instead of inv_ntok
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
-                  int B, int T, int V, int Vp, hipStream_t st);
+                  const float* ntok_dev, int B, int T, int V, int Vp, hipStream_t st);
 int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t st);
 int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st);
 int lxo_k_init_bwd(const float* dcc, Slabs dxh, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st);

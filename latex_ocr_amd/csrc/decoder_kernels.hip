@@ -3,6 +3,7 @@
 // and the context sum in ONE launch, att_img and img each read exactly once.
 #include "decoder_kernels.h"
 #include "api_util.h"
+#include "drop.h"
 #include <stdlib.h>
 
 namespace {
@@ -117,17 +118,6 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     }
 }
 
-// dropout mask bit: splitmix64 of the element counter (oracle/ref_model.py drop_mask is the same arithmetic)
-__device__ __forceinline__ float drop_scale(const Drop& d, unsigned which, int r, int c, int width) {
-    if (d.thr == 0u) return 1.f;
-    unsigned long long z = ((unsigned long long)((long long)d.t * d.rows_total + d.row0 + r)) * (unsigned long long)width + (unsigned long long)c;
-    z += 0x9E3779B97F4A7C15ull * ((((unsigned long long)d.seed) << 2) | which);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return ((unsigned)(z >> 40) < d.thr) ? d.inv_keep : 0.f;
-}
-
 // TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71).  A group of 4 threads owns 4 units of
 // one row: thread q sums gate q's pre-activations for the 4 units (z + the K1 slabs: one round trip of 16-byte loads),
 // activates them and hands them over through LDS; then thread q finishes unit u + q.  B*U threads (128 workgroups at
@@ -232,7 +222,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
 // g = (d_o from the logits + d_o carry) * (1 - o^2)      (backward through o = tanh(.), attention_cell.py:82)
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ a, int lda, Slabs carry,
                                                       const float* __restrict__ o, int ldo, float* __restrict__ g, int ldg,
-                                                      Drop dr, int carry_rows, int rows, int cols) {
+                                                      bf16_t* __restrict__ gb, int ldgb, Drop dr, int carry_rows, int rows, int cols) {
     const int total = rows * (cols >> 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int r = i / (cols >> 2), c = (i - r * (cols >> 2)) << 2;
@@ -248,6 +238,7 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
             out[e] = d[e] * sc * (1.f - th * th);
         }
         *reinterpret_cast<f32x4*>(g + (long long)r * ldg + c) = out;
+        if (gb) { u32x2 pk = {pack_bf2(out[0], out[1]), pack_bf2(out[2], out[3])}; *reinterpret_cast<u32x2*>(gb + (long long)r * ldgb + c) = pk; }
     }
 }
 // o = tanh(sum of the K4 slabs) -> rec      (attention_cell.py:82)
@@ -397,7 +388,7 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
 // grid (4, nv): every workgroup recomputes the (tiny) chunk scales in registers, then handles a
 // quarter of the channels and a quarter of the regions -- no serial phase, no barrier.
 __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __restrict__ part, float* __restrict__ alpha,
-                                                              float* __restrict__ ctx, int ldctx, int R, int Rp, int C,
+                                                              float* __restrict__ ctx, int ldctx, bf16_t* __restrict__ ctxb, int ldcb, int R, int Rp, int C,
                                                               int nch, int rows_per) {
     const int v = blockIdx.y, qd = blockIdx.x, tid = threadIdx.x;
     const float* pv = part + (long long)v * nch * (C + 2);
@@ -431,6 +422,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
 #pragma unroll
             for (int k = 0; k < 8; ++k) t = fmaf(pcx[k], mc[k], t);
             ctx[(long long)v * ldctx + c] = t * inv;
+            if (ctxb) ctxb[(long long)v * ldcb + c] = f2bf(t * inv);      // bf16 mirror: A operand of the fused o projection
         }
         if (r_ok) alpha[(long long)v * Rp + r] = expf(sraw - m) * inv;
         return;
@@ -439,6 +431,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
         float t = 0.f;
         for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + cc], mc[k], t);
         ctx[(long long)v * ldctx + cc] = t * inv;
+        if (ctxb) ctxb[(long long)v * ldcb + cc] = f2bf(t * inv);
     }
     for (int rr = qd * rq + tid; rr < min(R, (qd + 1) * rq); rr += 256)
         alpha[(long long)v * Rp + rr] = expf(alpha[(long long)v * Rp + rr] - m) * inv;
@@ -466,7 +459,7 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
     float s = 0.f;
     for (int c = tid; c < C; c += 512) {
         const float d = slab_sum(dcs, v, dcoff + c);
-        if (ch == 0) dctx_out[(long long)v * lddc + c] = d;          // summed d_ctx, kept for the deferred d_img GEMM
+        if (ch == 0 && dctx_out) dctx_out[(long long)v * lddc + c] = d;          // summed d_ctx, kept for the deferred d_img GEMM
         s = fmaf(ctx[(long long)v * ldctx + c], d, s);
     }
     s = wave_sum(s);
@@ -685,8 +678,10 @@ __global__ __launch_bounds__(256) void add_mean_grad_kernel(float* __restrict__ 
 template <typename CT>
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int* __restrict__ formula,
                                                      const int* __restrict__ lengths, CT* __restrict__ dlogits,
-                                                     float* __restrict__ loss_acc, float inv_ntok, int B, int T, int V, int Vp) {
+                                                     float* __restrict__ loss_acc, float inv_ntok, const float* __restrict__ ntok_dev,
+                                                     int B, int T, int V, int Vp) {
     __shared__ float red[8];
+    if (ntok_dev) inv_ntok = 1.0f / ntok_dev[0];      // data parallel: the global token count arrives by all-reduce, never through the host
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ce_sum = 0.f, n_sum = 0.f;
     for (int row = blockIdx.x * 4 + wave; row < T * B; row += gridDim.x * 4) {
@@ -1004,8 +999,8 @@ int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, 
     LAUNCH(lstm_bwd_kernel, grid1((long long)B * U), gates, c_prev, c_cur, s1, s3, s4, off4, dcc, dz, dr, carry_rows, B, U);
     DONE;
 }
-int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, Drop dr, int carry_rows, int rows, int cols, hipStream_t st) {
-    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, dr, carry_rows, rows, cols);
+int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo, float* g, int ldg, void* gb, int ldgb, Drop dr, int carry_rows, int rows, int cols, hipStream_t st) {
+    LAUNCH(tanh_bwd_kernel, grid1((long long)rows * cols / 4), a, lda, carry, o, ldo, g, ldg, (bf16_t*)gb, ldgb, dr, carry_rows, rows, cols);
     DONE;
 }
 __global__ __launch_bounds__(256) static void slab_reduce_kernel(Slabs sl, float* __restrict__ o, int ldo, int rows, int cols) {
@@ -1029,7 +1024,7 @@ static int att_u() {
     return u;
 }
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
-                   float* ctx, int ldctx, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st) {
+                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     dim3 grid(nch, nv);
@@ -1042,7 +1037,7 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
         else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
     }
 #undef AF_ARGS
-    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, R, Rp, C, nch, rows_per);
+    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, nch, rows_per);
     DONE;
 }
 // datth must be zero on entry (chunks accumulate with atomics)
@@ -1081,11 +1076,11 @@ int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hi
     DONE;
 }
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
-                  int B, int T, int V, int Vp, hipStream_t st) {
+                  const float* ntok_dev, int B, int T, int V, int Vp, hipStream_t st) {
     int g = cdiv(T * B, 4);
     if (g > 512) g = 512;
-    if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, inv_ntok, B, T, V, Vp);
-    else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, inv_ntok, B, T, V, Vp);
+    if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, inv_ntok, ntok_dev, B, T, V, Vp);
+    else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, inv_ntok, ntok_dev, B, T, V, Vp);
     DONE;
 }
 int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t st) {

@@ -5,7 +5,9 @@
 #include "plan.h"
 #include "gemm.h"
 #include "decoder_kernels.h"
+#include "rstep.h"
 #include "api_util.h"
+#include "timing.h"
 
 namespace {
 // dense C = act(A * Bp^T + bias) on the compute dtype `dt`
@@ -105,17 +107,67 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
     const char* img = (const char*)P.ws<void>(ws, W_IMG) + (r / beam) * P.R * C * P.esz;
     float* part = P.ws<float>(ws, W_APART) + r * 32 * (C + 2);
     // z = zx + [o_prev, h_prev] K[D:]            (attention_cell.py:70-71)
-    RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.XH, s1, nr, 4 * U, P.XH, st));
+    RC(slab(P, rec_prev, P.REC, P.pk(wp, K_LSTM_RT), P.ldRT, s1, nr, 4 * U, P.XH, st));
     RC(lxo_k_lstm_fwd(zx_t, view(s1, P.XH, nr, 4 * U), cs_prev, gates_t, cs_cur, rec_cur + O, rec_cur + P.OFF_HT, P.REC, dr, nr, U, st));
     // att_h = h~ W                                (attention_mechanism.py:79)
-    RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_ATT_H_T), U, s2, nr, E, U, st));
+    RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_ATT_H_T), P.ldAHT, s2, nr, E, U, st));
     RC(lxo_k_attn_fwd(P.s.dtype, att_img, img, nullptr, view(s2, U, nr, E), atth_t,
-                      prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.OFF_CTX, P.REC, nr, P.R, P.Rp, E, C, beam,
+                      prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.OFF_CTX, P.REC, nullptr, 0, nr, P.R, P.Rp, E, C, beam,
                       P.attn_chunks(nr), st));
     // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
-    RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_OW_T), P.HC, s4, nr, O, P.HC, st));
+    RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_OW_T), P.ldOWT, s4, nr, O, P.HC, st));
     RC(lxo_k_tanh_finalize(view(s4, P.HC, nr, O), rec_cur, P.REC, dr, nr, O, st));
     return 0;
+}
+
+// The same step on the fused full-K kernels (rstep.hip): 5 dependent launches instead of 7, no split-K slabs.
+// bf16 mode reads the GEMM A operands from the bf16 mirror of the record (recb_*), which every producer writes next
+// to its f32 value; in the f32 parity mode the mirrors are null and A is the f32 record itself.
+static int cell_step_fused(const Plan& P, const float* prm, const void* wp, void* ws, int nr, int beam,
+                           const float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
+                           const bf16_t* recb_prev, bf16_t* recb_cur,
+                           float* gates_t, float* atth_t, float* alpha_t, Drop dr, hipStream_t st) {
+    const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
+    const bool bf = P.bf;
+    const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG);
+    const char* img = (const char*)P.ws<void>(ws, W_IMG);
+    float* part = P.ws<float>(ws, W_APART);
+    RStep a; memset(&a, 0, sizeof(a));
+    a.M = nr; a.U = U; a.O = O; a.dr = dr;
+    // z = zx + [o_prev, h_prev] K[D:] -> gates, c, h, h~        (attention_cell.py:70-72)
+    RStep k1 = a;
+    k1.A = bf ? (const void*)recb_prev : (const void*)rec_prev; k1.lda = bf ? P.RECB : P.REC;
+    k1.W = P.pk(wp, K_LSTM_RT); k1.ldw = P.ldRT; k1.N = 4 * U; k1.K = P.XH; k1.epi = RS_LSTM_FWD;
+    k1.zx = zx_t; k1.c_prev = cs_prev; k1.gates = gates_t; k1.c_out = cs_cur;
+    k1.out = rec_cur + O; k1.out2 = rec_cur + P.OFF_HT; k1.ldo = P.REC;
+    if (bf) { k1.outb = recb_cur + O; k1.out2b = recb_cur + P.OFF_HT; k1.ldob = P.RECB; }
+    RC(lxo_launch_rstep(P.s.dtype, bf, k1, st));
+    // att_h = h~ W                                                (attention_mechanism.py:79)
+    RStep k2 = a;
+    k2.A = bf ? (const void*)(recb_cur + P.OFF_HT) : (const void*)(rec_cur + P.OFF_HT); k2.lda = bf ? P.RECB : P.REC;
+    k2.W = P.pk(wp, K_ATT_H_T); k2.ldw = P.ldAHT; k2.N = E; k2.K = U; k2.epi = RS_PLAIN;
+    k2.out = atth_t; k2.ldo = E;
+    RC(lxo_launch_rstep(P.s.dtype, bf, k2, st));
+    {
+    LxoTimed tm("attn_fwd", "part+combine", (double)nr * P.R * (E + C) * P.esz, st);
+    RC(lxo_k_attn_fwd(P.s.dtype, att_img, img, atth_t, kNoSlabs, nullptr,
+                      prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.OFF_CTX, P.REC, bf ? recb_cur + P.OFF_CTX : nullptr, P.RECB, nr, P.R, P.Rp, E, C, beam,
+                      P.attn_chunks(nr), st));
+    }
+    // o = dropout(tanh([h~, ctx] [o_W_h; o_W_c]))                  (attention_cell.py:82-83)
+    RStep k4 = a;
+    k4.A = bf ? (const void*)(recb_cur + P.OFF_HT) : (const void*)(rec_cur + P.OFF_HT); k4.lda = bf ? P.RECB : P.REC;
+    k4.W = P.pk(wp, K_OW_T); k4.ldw = P.ldOWT; k4.N = O; k4.K = P.HC; k4.epi = RS_TANH_O;
+    k4.out = rec_cur; k4.ldo = P.REC;
+    if (bf) { k4.outb = recb_cur; k4.ldob = P.RECB; }
+    RC(lxo_launch_rstep(P.s.dtype, bf, k4, st));
+    return 0;
+}
+static bool fused_steps(const Plan& P) { return P.s.step_kernels == 0; }
+// bf16 mirror of the [o | h] columns of `rows` records (initial state; beam re-ordering)
+static int mirror_oh(const Plan& P, void* ws, size_t slot_rows, int rows, hipStream_t st) {
+    if (!P.bf) return 0;
+    return lxo_k_mirror(P.ws<float>(ws, W_REC) + slot_rows * P.REC, P.REC, P.ws<bf16_t>(ws, W_RECB) + slot_rows * P.RECB, P.RECB, rows, P.XH, st);
 }
 
 // active (host, T entries, non-increasing, may be null): rows [0, active[t]) are the samples whose formula is longer
@@ -132,8 +184,21 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
     const int nh = dual ? 2 : 1;
+    const bool fused = fused_steps(P) && !dual && !active;
+    if (fused) {
+        bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
+        RC(mirror_oh(P, ws, 0, B, st));
+        for (int t = 0; t < T; ++t)
+            RC(cell_step_fused(P, prm, wp, ws, B, 1, zx + (size_t)t * B * 4 * U,
+                               rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
+                               rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
+                               recb + (size_t)t * B * P.RECB, recb + (size_t)(t + 1) * B * P.RECB,
+                               P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
+                               P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
+                               P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, P.drop(t, 0), st));
+    }
     if (dual) RC(fork_side(st));
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T && !fused; ++t)
         for (int h = 0; h < nh; ++h) {
             const int hb = active ? active[t] : B / nh;
             if (hb <= 0) continue;
@@ -151,15 +216,15 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     return 0;
 }
 
-int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, hipStream_t st) {
+int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, const float* ntok_dev, hipStream_t st) {
     HIPRC(hipMemsetAsync(P.ws<float>(ws, W_LOSS), 0, 64, st));
     RC(lxo_k_ce_loss(P.s.dtype, P.ws<float>(ws, W_LOGITS), formula, lengths, P.ws<void>(ws, W_DLOGITS), P.ws<float>(ws, W_LOSS),
-                     inv_ntok, P.s.B, P.s.T, P.s.V, P.Vp, st));
+                     inv_ntok, ntok_dev, P.s.B, P.s.T, P.s.V, P.Vp, st));
     return 0;
 }
 
 int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads,
-                               const int* active, hipStream_t st) {
+                               const int* active, int parts, hipStream_t st) {
     const int B = P.s.B, T = P.s.T, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
     const int TB = T * B;
     auto gw = [&](int pid) { return grads + P.poff[pid]; };
@@ -171,8 +236,11 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     const void* dlog = P.ws<void>(ws, W_DLOGITS);
 
     // d_o (from logits) for every step, and dy_W_o
-    RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
-    RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
+    if (parts & 1) {
+        RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
+        RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
+    }
+    if (!(parts & 2)) return 0;
 
     HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
     HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));     // attention chunks accumulate d_att_h with atomics
@@ -184,8 +252,64 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     }
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
     const int nh = dual ? 2 : 1;
+    const bool fused = fused_steps(P) && !dual && !active;
+    float* dxh = P.ws<float>(ws, W_DXH);
+    if (fused) {
+        // 4 dependent launches per step: [d_h~|d_ctx] GEMM, attention backward, d_att_h GEMM + LSTM backward,
+        // d_z K^T GEMM + the tanh' of step t-1.  All operands are final values (no split-K slabs).
+        const bool bf = P.bf;
+        bf16_t* gb = P.ws<bf16_t>(ws, W_GB); bf16_t* dzb = P.ws<bf16_t>(ws, W_DZB);
+        float* carry_h = P.ws<float>(ws, W_CARRYH);
+        const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG);
+        const char* img = (const char*)P.ws<void>(ws, W_IMG);
+        const int nchb = P.attn_chunks(B);
+        // g_{T-1} = d_o(logits) * tanh'   (no carry yet)
+        RC(lxo_k_tanh_bwd(dolog + (size_t)(T - 1) * B * O, O, kNoSlabs, rec + (size_t)T * B * P.REC, P.REC,
+                          gall + (size_t)(T - 1) * B * O, O, bf ? gb : nullptr, P.GBP, P.drop(T - 1, 0), 0, B, O, st));
+        RStep a; memset(&a, 0, sizeof(a));
+        a.M = B; a.U = U; a.O = O;
+        for (int t = T - 1; t >= 0; --t) {
+            const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
+            float* g_t = gall + (size_t)t * B * O;
+            float* dhc_t = dhc + (size_t)t * B * P.HC;
+            float* datth_t = datth + (size_t)t * B * E;
+            float* dz_t = dz + (size_t)t * B * 4 * U;
+            // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
+            RStep b1 = a;
+            b1.A = bf ? (const void*)gb : (const void*)g_t; b1.lda = bf ? P.GBP : O;
+            b1.W = P.pk(wp, K_OW); b1.ldw = P.ldOW; b1.N = P.HC; b1.K = O; b1.epi = RS_PLAIN;
+            b1.out = dhc_t; b1.ldo = P.HC;
+            RC(lxo_launch_rstep(P.s.dtype, bf, b1, st));
+            const Slabs dc1 = {dhc_t, 1, 0, P.HC};
+            {
+            LxoTimed tm("attn_bwd", "part", (double)B * P.R * (E + C) * P.esz, st);
+            RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + (size_t)t * B * E, prm + P.poff[P_BETA],
+                              alpha + (size_t)t * B * P.Rp, dc1, U, nullptr, P.HC, rec_cur + P.OFF_CTX, P.REC,
+                              de + (size_t)t * B * P.Rp, datth_t, B, P.R, P.Rp, E, C, nchb, st));
+            }
+            // d_h = (d_h~(o projection) + d_att_h W_att_h^T) * mask + carry -> d_z, d_c
+            RStep b3 = a;
+            b3.A = datth_t; b3.lda = E;                                  // f32 (atomically accumulated), converted on load
+            b3.W = P.pk(wp, K_ATT_H); b3.ldw = P.ldAH; b3.N = U; b3.K = E; b3.epi = RS_LSTM_BWD;
+            b3.dhm = dhc_t; b3.lddhm = P.HC; b3.carry_h = carry_h; b3.carry_rows = (t == T - 1) ? 0 : B;
+            b3.gates_in = gates + (size_t)t * B * 4 * U; b3.c_prev = cs + (size_t)t * B * U; b3.c_cur = cs + (size_t)(t + 1) * B * U;
+            b3.dcc = dcc; b3.out = dz_t; b3.outb = bf ? dzb : nullptr; b3.ldob = P.DZBP; b3.dr = P.drop(t, 0);
+            RC(lxo_launch_rstep(P.s.dtype, 0, b3, st));
+            // [d_o carry | d_h carry] = d_z K[D:]^T ; g_{t-1} = (d_o(logits) + d_o carry) * tanh'
+            RStep b4 = a;
+            b4.A = bf ? (const void*)dzb : (const void*)dz_t; b4.lda = bf ? P.DZBP : 4 * U;
+            b4.W = (const char*)P.pk(wp, K_LSTM) + (size_t)D * P.ldK * P.esz; b4.ldw = P.ldK; b4.N = P.XH; b4.K = 4 * U; b4.epi = RS_CARRY;
+            if (t == 0) { b4.first = 1; b4.out = dxh; b4.ldo = P.XH; }
+            else {
+                b4.out = gall + (size_t)(t - 1) * B * O; b4.outb = bf ? gb : nullptr; b4.ldob = P.GBP; b4.out2 = carry_h;
+                b4.dolog = dolog + (size_t)(t - 1) * B * O; b4.o_prev = rec + (size_t)t * B * P.REC; b4.ldoprev = P.REC;
+                b4.dr = P.drop(t - 1, 0);
+            }
+            RC(lxo_launch_rstep(P.s.dtype, bf, b4, st));
+        }
+    }
     if (dual) RC(fork_side(st));
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = T - 1; t >= 0 && !fused; --t) {
         for (int h = 0; h < nh; ++h) {
             const int hb = active ? active[t] : B / nh;
             if (hb <= 0) continue;
@@ -206,25 +330,24 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             const Slabs carry = (crows <= 0) ? kNoSlabs : view(sb4, 4 * U, crows, P.XH);
             // g = (d_o_logits + d_o_carry) * (1 - o^2)
             const Drop dr = P.drop(t, (int)r0);
-            RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, dr, crows, hb, O, sh));
+            RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, nullptr, 0, dr, crows, hb, O, sh));
             // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
-            RC(slab(P, g_t, O, P.pk(wp, K_OW), O, sb1, hb, P.HC, O, sh));
+            RC(slab(P, g_t, O, P.pk(wp, K_OW), P.ldOW, sb1, hb, P.HC, O, sh));
             RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + ((size_t)t * B + r0) * E, prm + P.poff[P_BETA],
                               alpha + ((size_t)t * B + r0) * P.Rp, view(sb1, O, hb, P.HC), U, dhc_t + U, P.HC, rec_cur + P.OFF_CTX, P.REC,
                               de + ((size_t)t * B + r0) * P.Rp, datth + ((size_t)t * B + r0) * E, hb, P.R, P.Rp, E, C, nchb, sh));
             // d_h += d_att_h W_att_h^T
-            RC(slab(P, datth + ((size_t)t * B + r0) * E, E, P.pk(wp, K_ATT_H), E, sb3, hb, U, E, sh));
+            RC(slab(P, datth + ((size_t)t * B + r0) * E, E, P.pk(wp, K_ATT_H), P.ldAH, sb3, hb, U, E, sh));
             RC(lxo_k_lstm_bwd(gates + ((size_t)t * B + r0) * 4 * U, cs + ((size_t)t * B + r0) * U, cs + ((size_t)(t + 1) * B + r0) * U,
                               view(sb1, O, hb, P.HC), view(sb3, E, hb, U), carry, O, dcc + r0 * U, dz + ((size_t)t * B + r0) * 4 * U, dr, crows, hb, U, sh));
             // [d_o carry | d_h carry] = d_z K[D:]^T
-            RC(slab(P, dz + ((size_t)t * B + r0) * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * 4 * U * P.esz, 4 * U,
+            RC(slab(P, dz + ((size_t)t * B + r0) * 4 * U, 4 * U, (const char*)P.pk(wp, K_LSTM) + (size_t)D * P.ldK * P.esz, P.ldK,
                     sb4, hb, P.XH, 4 * U, sh));
         }
     }
     if (dual) RC(join_side(st));
     // the final carries of the two halves are separate slab sets; gather them into one [B][XH] buffer
-    float* dxh = P.ws<float>(ws, W_DXH);
-    for (int h = 0; h < nh; ++h) {
+    for (int h = 0; h < nh && !fused; ++h) {
         const int hb = active ? active[0] : B / nh;       // every formula has at least its END token: step 0 runs all rows
         const size_t r0 = (size_t)h * hb;
         float* sb4 = P.ws<float>(ws, W_S_B4) + r0 * (4 * U / 128) * P.XH;
@@ -238,7 +361,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, st));
     // embeddings
     float* demb = P.ws<float>(ws, W_DEMB);
-    RC(nt(P, true, true, false, dz, 4 * U, P.pk(wp, K_LSTM), 4 * U, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
+    RC(nt(P, true, true, false, dz, 4 * U, P.pk(wp, K_LSTM), P.ldK, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
     RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, st));
     // ---- initial states ----
     float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
@@ -281,6 +404,13 @@ static int decode_common_step(const Plan& P, const float* prm, const void* wp, v
     RC(nt(P, false, true, false, P.ws<void>(ws, W_DEC_EMB), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, nv, 4 * U, P.Dp,
           prm + P.poff[P_LSTM_B], 0, false, st));
     const int prev = cur ^ 1;
+    if (fused_steps(P)) {
+        bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
+        RC(cell_step_fused(P, prm, wp, ws, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
+                           rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U,
+                           recb + (size_t)prev * nv * P.RECB, recb + (size_t)cur * nv * P.RECB, nullptr,
+                           P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st));
+    } else
     RC(cell_step(P, prm, wp, ws, 0, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
                  rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U, nullptr,
                  P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st));
@@ -295,6 +425,7 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
     const int B = P.s.B, ms = P.s.max_steps;
     if (ms < max_iter + 1) return -5;
     RC(attention_prepare(P, prm, wp, ws, 1, st));
+    if (fused_steps(P)) RC(mirror_oh(P, ws, 0, B, st));
     int* flags = P.ws<int>(ws, W_DEC_FLAGS);          // [0..63]: per-step unfinished counters ; [64..]: finished[B]
     int* finished = flags + 64;
     int* ids_step = P.ws<int>(ws, W_DEC_IDS);
@@ -334,6 +465,7 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
     const int B = P.s.B, k = P.s.beam, ms = P.s.max_steps, nv = B * k, U = P.s.U;
     if (ms < max_iter + 1 || k < 1 || k > 16) return -5;
     RC(attention_prepare(P, prm, wp, ws, k, st));
+    if (fused_steps(P)) RC(mirror_oh(P, ws, 0, nv, st));
     int* flags = P.ws<int>(ws, W_DEC_FLAGS);
     int* finished = flags + 64;
     int* ids_step = P.ws<int>(ws, W_DEC_IDS);
@@ -359,6 +491,7 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
                                ids_out, parents_out, ms, flags + c, st));
             RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
                                  tmp, tmp + (size_t)nv * P.XH, nv, st));
+            if (fused_steps(P)) RC(mirror_oh(P, ws, (size_t)cur * nv, nv, st));    // the re-ordered [o | h] rows feed the next LSTM GEMM
             ++issued;
         }
         HIPRC(hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -4,6 +4,7 @@
 #include "gemm.h"
 #include "encoder_kernels.h"
 #include "api_util.h"
+#include "timing.h"
 
 // ---------------------------------------------------------------- pack ----
 int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t st) {
@@ -43,20 +44,27 @@ int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t
     }
     const long long K = P.poff[P_LSTM_K];
     tr(K, P.koff[K_LSTM_XT], D, 4 * U, P.Dp, 0, P.Dp);
-    tr(K + (long long)D * 4 * U, P.koff[K_LSTM_RT], P.XH, 4 * U, P.XH, 0, P.XH);
-    cp(K, P.koff[K_LSTM], D + P.XH, 4 * U, 4 * U, 4 * U);
-    tr(P.poff[P_ATT_H], P.koff[K_ATT_H_T], U, E, U, 0, U);
-    cp(P.poff[P_ATT_H], P.koff[K_ATT_H], U, E, E, E);
-    tr(P.poff[P_OWH], P.koff[K_OW_T], U, O, P.HC, 0, U);
-    tr(P.poff[P_OWC], P.koff[K_OW_T], C, O, P.HC, U, C);
-    cp(P.poff[P_OWH], P.koff[K_OW], U, O, O, O);
-    cp(P.poff[P_OWC], P.koff[K_OW] + (size_t)U * O * P.esz, C, O, O, O);
+    tr(K + (long long)D * 4 * U, P.koff[K_LSTM_RT], P.XH, 4 * U, P.ldRT, 0, P.XH);
+    cp(K, P.koff[K_LSTM], D + P.XH, 4 * U, P.ldK, 4 * U);
+    tr(P.poff[P_ATT_H], P.koff[K_ATT_H_T], U, E, P.ldAHT, 0, U);
+    cp(P.poff[P_ATT_H], P.koff[K_ATT_H], U, E, P.ldAH, E);
+    tr(P.poff[P_OWH], P.koff[K_OW_T], U, O, P.ldOWT, 0, U);
+    tr(P.poff[P_OWC], P.koff[K_OW_T], C, O, P.ldOWT, U, C);
+    cp(P.poff[P_OWH], P.koff[K_OW], U, O, P.ldOW, O);
+    cp(P.poff[P_OWC], P.koff[K_OW] + (size_t)U * P.ldOW * P.esz, C, O, P.ldOW, O);
     tr(P.poff[P_YWO], P.koff[K_YWO_T], O, V, O, 0, O);
     cp(P.poff[P_YWO], P.koff[K_YWO], O, V, P.Vp, P.Vp);
     return lxo_k_pack_batch(dt, tab, blocks, prm, wp, st);
 }
 
 // -------------------------------------------------------------- conv ------
+// layer label of the timing records (the 3x3 layers are told apart by their channel counts; conv6 is the VALID one)
+static const char* conv_name(int Cin, int Cout, bool valid) {
+    if (valid) return "conv6";
+    if (Cin == 64) return "conv2";
+    if (Cin == 128) return "conv3";
+    return Cin == Cout ? "conv4" : "conv5";
+}
 // fwd: out[b,oy,ox,:] = relu(sum in[b,oy+kh-pad,ox+kw-pad,:] * W + bias)
 static int conv_fwd(const Plan& P, const void* in, const void* wpk, const float* bias, void* out,
                     int H, int W, int Cin, int Cout, bool valid, const float* addend, int addend_rows,
@@ -69,6 +77,7 @@ static int conv_fwd(const Plan& P, const void* in, const void* wpk, const float*
     g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
     g.bias = bias; g.act = 1; g.alpha = 1.f;
     g.addend = addend; g.addend_rows = addend_rows > 0 ? addend_rows : 1; g.out_pre = out_pre;
+    LxoTimed tm("conv_fwd", conv_name(Cin, Cout, valid), 2.0 * g.M * g.N * g.K, st);
     return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
 }
 // dgrad: d_in[b,y,x,ci] = sum d_out[b,y+a-padd,x+b-padd,co] * Wd[ci][(a,b,co)], optional ReLU mask of the
@@ -83,6 +92,8 @@ static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din
     g.lda = Cout; g.ldb = 9 * Cout; g.ldc = Cin;
     g.act = 0; g.alpha = 1.f; g.addend_rows = 1;
     g.relu_ref = relu_ref; g.ldr = Cin; g.colsum = colsum;
+    // algorithmic FLOPs of a data gradient = those of the layer's forward, whatever grid the kernel pads to
+    LxoTimed tm("conv_dgrad", conv_name(Cin, Cout, valid), 2.0 * P.s.B * Hout * Wout * 9.0 * Cin * Cout, st);
     return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
 }
 // wgrad: dW[(kh,kw,ci)][co] += sum_m in[m shifted][ci] * d_out[m][co]
@@ -99,6 +110,7 @@ static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw
     const int maxs = g.M / 256 > 0 ? g.M / 256 : 1;
     if (ns > maxs) ns = maxs;
     g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
+    LxoTimed tm("conv_wgrad", conv_name(Cin, Cout, valid), 2.0 * g.M * g.I * g.J, st);
     return lxo_launch_gemm_tn(P.s.dtype, 0, 0, g, st);
 }
 

@@ -42,7 +42,8 @@ enum WsId {
     W_ATT_IMG, W_APART, W_MEAN, W_EMB_IN, W_ZX, W_REC, W_CS, W_GATES, W_ATTH, W_ALPHA, W_LOGITS,
     W_DLOGITS, W_LOSS, W_DOLOG, W_G, W_DHC, W_DE, W_DATTH, W_DZ, W_DXH, W_DCC, W_DIMG, W_DATTIMG,
     W_DEMB, W_DPRE0, W_DMEAN, W_G0, W_G1, W_G2, W_GNORM,
-    W_S_K1, W_S_K2, W_S_K4, W_S_B1, W_S_B3, W_S_B4,   // split-K slabs of the recurrent GEMMs
+    W_S_K1, W_S_K2, W_S_K4, W_S_B1, W_S_B3, W_S_B4,   // split-K slabs of the recurrent GEMMs (step_kernels == 1 only)
+    W_RECB, W_GB, W_DZB, W_CARRYH,                    // fused step kernels: bf16 mirrors of rec / g_t / d_z_t, carried d_h
     // decode-only
     W_DEC_IDS, W_DEC_FLAGS, W_DEC_EMB, W_DEC_ZX, W_DEC_LOGITS, W_BEAM_LP, W_BEAM_PAR, W_BEAM_TMP,
     W_COLS,        // cnn encoder only: im2col of the strided conv [B*H6*W5][8C], reused for its column gradient
@@ -59,6 +60,11 @@ struct Plan {
     int convCin[6], convCout[6], convW[6], convB[6];   // per 3x3 layer: channels and ParamIds
     int Vp, Dp, Rp, XH, HC, REC;   // padded V / D / R (row pitches), O+U, U+C, record width O+2U+C
     int OFF_HT, OFF_CTX;           // record = [o | h | h~ | ctx]: [o|h] feeds the LSTM, [h~|ctx] the attention and o projection
+    // Row pitches of the operands the step GEMMs read with many rows in flight.  A pitch that is a multiple of 4 KB puts
+    // the same 128-byte piece of EVERY row on one L2 channel (256-byte interleave over 16 channels): in-kernel stamps
+    // showed the fetch phase of a step GEMM at half the rate of a contiguous read.  +128 elements walks the channels.
+    int ldRT, ldAHT, ldOWT, ldOW, ldAH, ldK;     // packed recurrent weights K_LSTM_RT, K_ATT_H_T, K_OW_T, K_OW, K_ATT_H, K_LSTM
+    int RECB, GBP, DZBP;                         // bf16 mirrors: record, g_t, d_z_t
     Drop drop(int t, int row0) const;   // dropout descriptor of decoder step t for rows row0.. (off when keep_prob is 0 or >= 1)
     // flat parameter buffer
     long long poff[P_COUNT], pcount[P_COUNT], ptotal;

@@ -43,6 +43,7 @@ static const char* kWsNames[W_COUNT] = {
     "dlogits", "loss", "do_log", "g", "dhc", "de", "datth", "dz", "dxh", "dcc", "d_img", "d_att_img",
     "d_emb", "dpre0", "dmean", "g0", "g1", "g2", "gnorm",
     "s_k1", "s_k2", "s_k4", "s_b1", "s_b3", "s_b4",
+    "recb", "gb", "dzb", "carry_h",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
     "cols",
 };
@@ -70,6 +71,9 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     Dp = (D + 31) / 32 * 32;
     Rp = (R + 7) / 8 * 8;
     XH = O + U; HC = U + C; OFF_HT = O + U; OFF_CTX = O + 2 * U; REC = O + 2 * U + C;
+    const int WPAD = 128;
+    ldRT = XH + WPAD; ldAHT = U + WPAD; ldOWT = HC + WPAD; ldOW = O + WPAD; ldAH = E + WPAD; ldK = 4 * U + WPAD;
+    RECB = REC + WPAD; GBP = O + WPAD; DZBP = 4 * U + WPAD;
 
     long long cnt[P_COUNT];
     for (int i = 0; i < 6; ++i) { cnt[convW[i]] = 9LL * ci[i] * co[i]; cnt[convB[i]] = co[i]; }
@@ -90,10 +94,10 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     }
     kb[K_ATT_IMG_T] = (size_t)E * C * esz; kb[K_ATT_IMG] = (size_t)C * E * esz;
     kb[K_INIT_T] = (size_t)(2 * U + O) * C * esz; kb[K_INIT] = (size_t)C * (2 * U + O) * esz;
-    kb[K_LSTM_XT] = (size_t)4 * U * Dp * esz; kb[K_LSTM_RT] = (size_t)4 * U * XH * esz;
-    kb[K_LSTM] = (size_t)(D + O + U) * 4 * U * esz;
-    kb[K_ATT_H_T] = (size_t)E * U * esz; kb[K_ATT_H] = (size_t)U * E * esz;
-    kb[K_OW_T] = (size_t)O * HC * esz; kb[K_OW] = (size_t)HC * O * esz;
+    kb[K_LSTM_XT] = (size_t)4 * U * Dp * esz; kb[K_LSTM_RT] = (size_t)4 * U * ldRT * esz;
+    kb[K_LSTM] = (size_t)(D + O + U) * ldK * esz;
+    kb[K_ATT_H_T] = (size_t)E * ldAHT * esz; kb[K_ATT_H] = (size_t)U * ldAH * esz;
+    kb[K_OW_T] = (size_t)O * ldOWT * esz; kb[K_OW] = (size_t)HC * ldOW * esz;
     kb[K_YWO_T] = (size_t)V * O * esz; kb[K_YWO] = (size_t)O * Vp * esz;
     kb[K_CONVS_F] = cnn ? (size_t)8 * C * C * esz : 0; kb[K_CONVS_D] = kb[K_CONVS_F];
     ktotal = 0;
@@ -152,6 +156,10 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_S_B1] = (size_t)(O / 128) * BL * HC * f4;
     wb[W_S_B3] = (size_t)(E / 128) * BL * U * f4;
     wb[W_S_B4] = (size_t)(4 * U / 128) * BL * XH * f4;
+    wb[W_RECB] = bf ? (size_t)(T + 1) * B * RECB * 2 : 0;
+    wb[W_GB] = bf ? BL * GBP * 2 : 0;
+    wb[W_DZB] = bf ? BL * DZBP * 2 : 0;
+    wb[W_CARRYH] = BL * U * f4;
     const int ms = s.max_steps > 0 ? s.max_steps : 0;
     if (ms > 0) {
         wb[W_DEC_IDS] = BK_ * ms * 4;
@@ -166,6 +174,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
         // decode reuses rec / cs / att_h / alpha with (T = 2 ping-pong) rows per beam
         const size_t recd = 2 * BK_ * REC * f4, csd = 2 * BK_ * U * f4;
         if (wb[W_REC] < recd) wb[W_REC] = recd;
+        if (bf && wb[W_RECB] < 2 * BK_ * RECB * 2) wb[W_RECB] = 2 * BK_ * RECB * 2;
         if (wb[W_CS] < csd) wb[W_CS] = csd;
         if (wb[W_GATES] < BK_ * 4 * U * f4) wb[W_GATES] = BK_ * 4 * U * f4;
         if (wb[W_ATTH] < BK_ * E * f4) wb[W_ATTH] = BK_ * E * f4;

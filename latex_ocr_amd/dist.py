@@ -5,6 +5,10 @@ loss (model/img2seq.py:69-71 takes the mean over ALL unmasked tokens of the batc
 the gradient sum.  Gradients are all-reduced in three buckets on a side HIP stream as soon
 as backward has finalised them (decoder first, then conv6-5, then conv4-1), overlapping the
 remaining encoder backward; Adam is replicated.
+
+The step never synchronises the host: the token count is a sum of host-known integers, so each rank
+uploads its own count at the START of the step and all-reduces it on a dedicated stream while the forward
+runs; the loss kernel reads the global count from device memory (lxo_ce_loss_fwd_bwd_dev).
 """
 import torch
 import torch.distributed as td
@@ -18,6 +22,27 @@ class DataParallel(object):
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(self.device) if self.cuda else None
         self._pending = False
+        # token-count exchange: its own stream (never queued behind gradient buckets), pinned staging ring
+        self.cnt_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self._cnt_pin = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(4)] if self.cuda else None
+        self._cnt_i = 0
+
+    def sum_count_async(self, n_local):
+        """-> (device float32 tensor [1] holding the sum of n_local over ranks, event or None).  Asynchronous w.r.t. the
+        host and the compute stream: the consumer makes its stream wait for the event (Engine.loss)."""
+        if not self.cuda:
+            t = torch.tensor([float(n_local)], dtype=torch.float32)
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            return t, None
+        pin = self._cnt_pin[self._cnt_i % len(self._cnt_pin)]
+        self._cnt_i += 1
+        pin[0] = float(n_local)
+        with torch.cuda.stream(self.cnt_stream):
+            t = pin.to(self.device, non_blocking=True)
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            ev = torch.cuda.Event()
+            ev.record(self.cnt_stream)
+        return t, ev
 
     def sum_scalar(self, x):
         t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)

@@ -35,6 +35,8 @@ class Engine(object):
         # each decoder step only for the samples still inside their formula (lxo_decoder_train_*_active); same loss and gradients
         self.skip_padded = (os.environ.get("LXO_SKIP_PADDED", "0") == "1") if skip_padded is None else bool(skip_padded)
         self._active = None
+        # decoder step decomposition (lxo_shape.step_kernels): 0 = fused full-K step kernels, 1 = round 1's split-K slab path
+        self.step_kernels = 1 if os.environ.get("LXO_STEP_KERNELS", "0") == "1" else 0
         self.specs = PP.param_specs(self.n_tok, self.dims)
         self.n_params = PP.n_params(self.n_tok, self.dims)
         probe = self._shape(1, 32, 32, 1)
@@ -65,7 +67,8 @@ class Engine(object):
                 name = self.lib.lxo_param_name_for(ctypes.byref(probe), i).decode()
                 assert self._offsets[name][:2] == (o.value, c.value), (name, self._offsets[name], o.value, c.value)
         c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]
-        self.buckets = [(first_dec, self.n_params), (c5, first_dec), (0, c5)]
+        ywo = self._offsets["Decoder/AttentionCell/rnn/y_W_o"][0]        # the last variable: final before the recurrence runs
+        self.buckets = [(ywo, self.n_params), (first_dec, ywo), (c5, first_dec), (0, c5)]
         # optional second stream for the half-batch interleave of the recurrent loop (LXO_DUAL_STREAM=1).
         # Measured slower than one stream in round 1 (18.8 vs 17.3 ms/step: twice the launches make the
         # eager host loop the bottleneck), so it is off by default until the loop is graph-captured.
@@ -87,6 +90,7 @@ class Engine(object):
                            self.beam, self.max_steps)
         sh.encoder_cnn = 1 if d.get("cnn") else 0                 # configs/model.json encoder_cnn (encoder.py:46-56)
         sh.no_positional = 0 if d.get("positional", True) else 1  # positional_embeddings (encoder.py:60-65)
+        sh.step_kernels = self.step_kernels
         return sh
 
     def _stream(self):
@@ -192,10 +196,19 @@ class Engine(object):
         self._ck(self.lib.lxo_set_encoder_side_stream(ctypes.c_void_p(es.cuda_stream) if es is not None else ctypes.c_void_p(0)),
                  "set_encoder_side_stream")
 
-    def loss(self, lengths, inv_ntok):
+    def loss(self, lengths, inv_ntok=None, ntok_dev=None, ntok_event=None):
+        """Loss statistics + d(logits).  Either inv_ntok (host float) or ntok_dev (device float32 [1] = the global token count,
+        e.g. from DataParallel.sum_count_async; the compute stream waits for ntok_event, the host does not)."""
         self._lengths = self._to_dev(lengths, torch.int32)
-        self._ck(self.lib.lxo_ce_loss_fwd_bwd(self.sref(), _p(self.ws), _p(self._formula), _p(self._lengths),
-                                              ctypes.c_float(inv_ntok), self._stream()), "ce_loss")
+        if ntok_dev is not None:
+            if ntok_event is not None:
+                torch.cuda.current_stream(self.device).wait_event(ntok_event)
+            self._ntok_dev = ntok_dev          # keep alive until the kernel has run
+            self._ck(self.lib.lxo_ce_loss_fwd_bwd_dev(self.sref(), _p(self.ws), _p(self._formula), _p(self._lengths), _p(ntok_dev),
+                                                      self._stream()), "ce_loss_dev")
+        else:
+            self._ck(self.lib.lxo_ce_loss_fwd_bwd(self.sref(), _p(self.ws), _p(self._formula), _p(self._lengths),
+                                                  ctypes.c_float(inv_ntok), self._stream()), "ce_loss")
         return self.region("loss")[:2]
 
     def backward(self, comm=None):
@@ -204,23 +217,29 @@ class Engine(object):
         st = self._stream()
         self._bind_side()
         self.grads.zero_()
-        if self._active is None:
+        act = None if self._active is None else self._active.ctypes.data_as(ctypes.c_void_p)
+        if comm:
+            # y_W_o's gradient needs only d(logits): reduce it while the recurrence runs
+            self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                         _p(self.grads), act, 1, st), "decoder_train_bwd_part")
+            comm(*self.buckets[0])
+            self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                         _p(self.grads), act, 2, st), "decoder_train_bwd_part")
+            comm(*self.buckets[1])
+        elif self._active is None:
             self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
                                                     _p(self.grads), st), "decoder_train_bwd")
         else:
             self._ck(self.lib.lxo_decoder_train_bwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                           _p(self.grads), self._active.ctypes.data_as(ctypes.c_void_p), st),
-                     "decoder_train_bwd_active")
-        if comm:
-            comm(*self.buckets[0])
+                                                           _p(self.grads), act, st), "decoder_train_bwd_active")
         self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
                                           6, 5, st), "encoder_bwd")
         if comm:
-            comm(*self.buckets[1])
+            comm(*self.buckets[2])
         self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
                                           4, 1, st), "encoder_bwd")
         if comm:
-            comm(*self.buckets[2])
+            comm(*self.buckets[3])
 
     METHODS = {"adam": 0, "sgd": 1, "adagrad": 2, "rmsprop": 3}
 
@@ -269,10 +288,15 @@ class Engine(object):
         active = None
         if self.skip_padded:
             img, formula, lengths, active = self.sort_by_length(img, formula, lengths)
-        self.forward(img, formula, dropout=drop, active_rows=active)
         n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
-        n_global = dist.sum_scalar(n_local) if dist is not None else n_local
-        stats = self.loss(lengths, 1.0 / float(n_global))
+        if dist is not None:
+            # the global token count travels rank -> device -> all-reduce -> loss kernel; no host sync inside the step
+            ntok, ev = dist.sum_count_async(n_local)
+            self.forward(img, formula, dropout=drop, active_rows=active)
+            stats = self.loss(lengths, ntok_dev=ntok, ntok_event=ev)
+        else:
+            self.forward(img, formula, dropout=drop, active_rows=active)
+            stats = self.loss(lengths, 1.0 / float(n_local))
         self.backward(comm=dist.reduce_range_fn(self.grads) if dist is not None else None)
         if dist is not None:
             dist.finish()

@@ -115,6 +115,7 @@ template <class T> inline T __builtin_amdgcn_readfirstlane_sim(T v) {
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_sim(v)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
+#define __builtin_amdgcn_wave_barrier() hipsim::wave_sync()
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_barrier() hipsim::syncthreads()
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
@@ -284,6 +285,9 @@ typedef void* hipEvent_t;
 enum { hipEventDisableTiming = 2 };
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 

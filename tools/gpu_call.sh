@@ -15,6 +15,7 @@ case $what in
             cd $R
             DB=$(ls gpurun_out/${TAG}_prof/*/*_results.db 2>/dev/null | head -1)
             if [ -n "$DB" ]; then python tools/prof_summary.py $DB gpurun_out/${TAG}_kernels.csv "$TAG"; head -24 gpurun_out/${TAG}_kernels.csv | cut -c1-160; python tools/prof_by_grid.py $DB > gpurun_out/${TAG}_bygrid.txt 2>&1; rm -rf gpurun_out/${TAG}_prof; fi;;
+  benchold) LXO_STEP_KERNELS=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_benchold.log 2>&1; echo "benchold rc=$?"; tail -1 gpurun_out/${TAG}_benchold.log | cut -c1-300;;
   *) echo "unknown $what";;
 esac
 done

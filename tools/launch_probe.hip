@@ -34,6 +34,39 @@ __global__ __launch_bounds__(256) void body_kernel(const float* __restrict__ in,
     (void)f;
 }
 
+// H: how fast can N workgroups each pull `shared_bytes` that ALL of them read (an A operand) plus `priv_bytes` of their own
+// (a weight slice)?  All loads of a thread are issued before the first use.
+template <int NSH, int NPR>
+__global__ __launch_bounds__(256) void pull_kernel(const float4* __restrict__ shared, const float4* __restrict__ priv, float* __restrict__ out) {
+    float4 a[NSH > 0 ? NSH : 1], b[NPR > 0 ? NPR : 1];
+#pragma unroll
+    for (int j = 0; j < NSH; ++j) a[j] = shared[j * 256 + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) b[j] = priv[((long long)blockIdx.x * NPR + j) * 256 + threadIdx.x];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NSH; ++j) s += a[j].x + a[j].y + a[j].z + a[j].w;
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) s += b[j].x + b[j].y + b[j].z + b[j].w;
+    if (s == 12345.678f) out[blockIdx.x] = s;
+}
+// rewrites the shared region (as the producer kernel of a chain would), 32 workgroups
+__global__ __launch_bounds__(256) void rewrite_kernel(float4* __restrict__ shared, int n16, float v) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) shared[i] = make_float4(v, v, v, v);
+}
+
+// I: epilogue-store shapes.  N workgroups x 256 threads; thread (row = tid/4, part = tid%4) writes `reps` scalars.
+//   frag = 1: out[rep][row][blockIdx*4 + part]      (row pitch 2048 floats: 16-byte fragments of lines shared by 8 workgroups)
+//   frag = 0: out[rep][blockIdx][row*4 + part]      (each workgroup writes one contiguous 1 KB block per rep)
+__global__ __launch_bounds__(256) void store_kernel(float* __restrict__ out, int reps, int frag, float v) {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    for (int rep = 0; rep < reps; ++rep) {
+        float* base = out + (long long)rep * 64 * 2048;
+        if (frag) base[(long long)row * 2048 + blockIdx.x * 4 + part] = v + rep;
+        else base[(long long)blockIdx.x * 256 + row * 4 + part] = v + rep;
+    }
+}
+
 // spins for ~ms milliseconds (s_memtime runs at 100 MHz)
 __global__ void blocker_kernel(long long ticks, int* sink) {
     const long long t0 = __builtin_readcyclecounter();
@@ -121,6 +154,36 @@ int main(int argc, char** argv) {
         blocked_chain("E empty 256 WG (device only)", st, N, [&](int) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, st, f, 0); });
         blocked_chain("E body 128 WG 9 slab (device only)", st, N, [&](int i) { hipLaunchKernelGGL(body_kernel, dim3(128), dim3(256), 0, st, (i & 1) ? b : a, (i & 1) ? a : b, f, 9, stride); });
         blocked_chain("E body 128 WG 1 slab (device only)", st, N, [&](int i) { hipLaunchKernelGGL(body_kernel, dim3(128), dim3(256), 0, st, (i & 1) ? b : a, (i & 1) ? a : b, f, 1, stride); });
+    }
+    // H: pull bandwidth of N workgroups (device-only; each timed launch is preceded by a rewrite of the shared region)
+    {
+        hipStream_t st = s_nb;
+        float4 *sh, *pr; float* o;
+        CK(hipMalloc(&sh, 512 << 10)); CK(hipMalloc(&pr, 256LL * 512 * 1024)); CK(hipMalloc(&o, 4096));
+        CK(hipMemset(sh, 0, 512 << 10)); CK(hipMemset(pr, 0, 256LL * 512 * 1024));
+        const int NR = 300;
+        blocked_chain("H0 rewrite 128 KB only (32 WG)", st, NR, [&](int i) { hipLaunchKernelGGL(rewrite_kernel, dim3(32), dim3(256), 0, st, sh, 8192, (float)i); });
+        const int grids[5] = {16, 32, 64, 128, 256};
+        for (int gi = 0; gi < 5; ++gi) {
+            const int G = grids[gi];
+            char nm[128];
+#define PULL(NSH, NPR) \
+            snprintf(nm, sizeof nm, "H rewrite + pull shared %3d KB priv %3d KB x %3d WG", NSH * 4, NPR * 4, G); \
+            blocked_chain(nm, st, NR, [&](int i) { hipLaunchKernelGGL(rewrite_kernel, dim3(32), dim3(256), 0, st, sh, 8192, (float)i); \
+                                                   hipLaunchKernelGGL((pull_kernel<NSH, NPR>), dim3(G), dim3(256), 0, st, sh, pr, o); });
+            PULL(32, 0) PULL(0, 8) PULL(32, 8) PULL(16, 4) PULL(0, 40)
+#undef PULL
+        }
+    }
+    // I: fragmented vs contiguous epilogue stores, 128 workgroups, 8 output arrays of [64][2048] floats
+    {
+        hipStream_t st = s_nb;
+        float* o;
+        CK(hipMalloc(&o, 8LL * 64 * 2048 * 4)); CK(hipMemset(o, 0, 8LL * 64 * 2048 * 4));
+        blocked_chain("I stores 128 WG x 8 arrays, 16-B fragments", st, 500, [&](int i) { hipLaunchKernelGGL(store_kernel, dim3(128), dim3(256), 0, st, o, 8, 1, (float)i); });
+        blocked_chain("I stores 128 WG x 8 arrays, contiguous 1 KB", st, 500, [&](int i) { hipLaunchKernelGGL(store_kernel, dim3(128), dim3(256), 0, st, o, 8, 0, (float)i); });
+        blocked_chain("I stores 128 WG x 1 array, 16-B fragments", st, 500, [&](int i) { hipLaunchKernelGGL(store_kernel, dim3(128), dim3(256), 0, st, o, 1, 1, (float)i); });
+        blocked_chain("I stores 128 WG x 1 array, contiguous 1 KB", st, 500, [&](int i) { hipLaunchKernelGGL(store_kernel, dim3(128), dim3(256), 0, st, o, 1, 0, (float)i); });
     }
     // F: hipModuleLaunchKernel (no host-pointer -> function lookup) enqueue cost
     {
