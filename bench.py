@@ -5,13 +5,20 @@ decoder forward, loss, BPTT, Adam, weight re-pack [+ gradient all-reduce]) on sy
 (BASELINE.json configs[2]; metric quoted at 1/2/4/8 MI355X, weak scaling).
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+      N > 1 without a torchrun environment: this process re-launches itself as N ranks
+      (python -m torch.distributed.run --nproc-per-node N ..., one rank per GPU, RCCL).
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+      (what the driver does) works as before: RANK / LOCAL_RANK / WORLD_SIZE come from the env.
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints ONE JSON line.  After the timed region rank 0 runs ONE more, instrumented step (HIP events
+around every conv / attention launch inside the step, lxo_timing_*) from which the roofline entries are computed,
+then the secondary measurements (none of them touches `value`).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,14 +30,8 @@ if ROOT not in sys.path:
 
 GF_TRAIN_PER_IMG = 55.925e9      # conv fwd+dgrad+wgrad FLOPs per 128x512 image
 MFMA_BF16_PEAK = 2.5e15          # MI355X_MICROARCH.md: dense bf16 MFMA peak
-
-
-def conv_layers(B, H, W, C=512):
-    """(name, M, N, K) of the implicit GEMMs of conv2..conv6 forward at this input size."""
-    c = lambda n: -(-n // 2)
-    H1, W1 = c(H), c(W); H2, W2 = c(H1), c(W1); H4 = c(H2); W5 = c(W2)
-    return [("conv2", B * H1 * W1, 128, 9 * 64), ("conv3", B * H2 * W2, 256, 9 * 128), ("conv4", B * H2 * W2, 256, 9 * 256),
-            ("conv5", B * H4 * W2, C, 9 * 256), ("conv6", B * (H4 - 2) * (W5 - 2), C, 9 * C)]
+HBM_PEAK = 8.0e12                # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+METRIC = "formula-images/sec training step (batch 64, 128x512)"
 
 
 def cpu_baseline(seconds_budget=15.0):
@@ -70,48 +71,228 @@ def cpu_baseline(seconds_budget=15.0):
                       % (n, B, f.shape[1])}
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 outside torchrun: become the launcher of N ranks of this same script."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------ measurement helpers (rank 0, after the timed region) ----
+def timing_records(lib):
+    import ctypes
+    out = []
+    for i in range(lib.lxo_timing_count()):
+        fam, nm = ctypes.c_char_p(), ctypes.c_char_p()
+        work, ms = ctypes.c_double(), ctypes.c_float()
+        if lib.lxo_timing_get(i, ctypes.byref(fam), ctypes.byref(nm), ctypes.byref(work), ctypes.byref(ms)) == 0:
+            out.append((fam.value.decode(), nm.value.decode(), work.value, ms.value * 1e-3))
+    return out
+
+
+def instrumented_step(eng, img, f_d, l, torch):
+    """One more real training step with per-launch HIP events (lxo_timing_*) and per-call events around the ABI calls."""
+    lib = eng.lib
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    marks = []
+
+    def mark(name):
+        e = ev(); e.record(); marks.append((name, e))
+    lib.lxo_timing_enable(1)
+    torch.cuda.synchronize()
+    mark("start")
+    eng.forward(img, f_d, phase_hook=mark)
+    mark("decoder_fwd")
+    eng.loss(l, 1.0 / float(np.asarray(l).sum()))
+    mark("loss")
+    eng.backward(phase_hook=mark)
+    mark("encoder_bwd")
+    eng.optimizer_step(1e-3)
+    mark("optimizer+pack")
+    torch.cuda.synchronize()
+    lib.lxo_timing_enable(0)
+    phases = {}
+    for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+        phases[n1] = phases.get(n1, 0.0) + e0.elapsed_time(e1)
+    return timing_records(lib), {k: round(v, 3) for k, v in phases.items()}
+
+
+def roofline_from_records(recs, family, label, bound, peak, unit):
+    sel = [r for r in recs if r[0] in family]
+    if not sel:
+        return None
+    work = sum(r[2] for r in sel); secs = sum(r[3] for r in sel)
+    scale = 1e12 if unit == "TFLOP/s" else 1e9
+    per = {}
+    for fam, nm, w, s in sel:
+        k = fam + ":" + nm
+        a = per.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += w; a[2] += s
+    return {"kernel": label, "bound": bound, "achieved": round(work / secs / scale, 2), "peak": peak / scale, "unit": unit,
+            "frac": round(work / secs / peak, 4), "traffic": None, "launches": len(sel),
+            "work_per_launch": work / len(sel), "avg_launch_us": round(secs / len(sel) * 1e6, 2),
+            "source": "HIP events around each launch inside one real training step (lxo_timing_*)",
+            "per_launch": {k: {"n": v[0], "us": round(v[2] / v[0] * 1e6, 2), "rate": round(v[1] / v[2] / scale, 1)} for k, v in sorted(per.items())}}
+
+
+def count_set(n, seed, H, W):
+    """Crops whose ink density tells the formula length (tests/test_gpu_benchcfg.py): ~250 Adam steps teach the model a
+    per-class count-down to END, which is what a decode measurement with early exit needs."""
+    classes = [(0.0, 2), (0.08, 4), (0.3, 9), (0.6, 5)]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    imgs, forms = [], []
+    for _ in range(n):
+        ink, L = classes[int(rng.integers(0, len(classes)))]
+        im = np.full((H, W, 1), 255, np.uint8)
+        m = rng.random((H, W, 1)) < ink
+        vals = rng.integers(0, 128, size=(H, W, 1)).astype(np.uint8)
+        im[m] = vals[m]
+        imgs.append(im); forms.append([7] * L)
+    return imgs, forms
+
+
+def secondary(args, eng_train, torch, dev, B, H, W, V):
+    """configs[1] (encoder only, B=32), the worst-case T=151 step, configs[4] decode tokens/s.  Separate engines; never `value`."""
+    from latex_ocr_amd import synthetic
+    from latex_ocr_amd.engine import Engine
+    from latex_ocr_amd.model.utils.image import pad_batch_images
+    from latex_ocr_amd.model.utils.text import pad_batch_formulas
+    out = {}
+
+    def timed(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    # ---- configs[1]: encoder-only conv kernels, batch 32 ----
+    eng = Engine(V, dtype="bf16", device=dev, seed=0)
+    imgs, forms = synthetic.make_set(32, H, W, V, 3, 5, seed=7)
+    img32 = torch.from_numpy(pad_batch_images(imgs)).to(dev)
+    dt = timed(lambda: eng._encode_only(img32, 1), 20)
+    out["config2_encoder_only_b32"] = {"fwd_ms": round(dt * 1e3, 3), "fwd_img_per_s": round(32 / dt, 1),
+                                       "conv_fwd_tflops": round(18.667e9 * (H * W / 65536.0) * 32 / dt / 1e12, 1)}
+    # ---- worst case: every formula at max_length_formula = 150 (T = 151) ----
+    imgs, forms = synthetic.make_set(B, H, W, V, 150, 151, seed=8)
+    imgT = torch.from_numpy(pad_batch_images(imgs)).to(dev)
+    fT, lT = pad_batch_formulas(forms, V - 2, V - 1)
+    fT_d = torch.from_numpy(fT).to(dev)
+    dt = timed(lambda: eng.train_step(imgT, fT_d, lT, 1e-3, sync_loss=False), 10)
+    out["worst_case_T151"] = {"ms_per_step": round(dt * 1e3, 3), "img_per_s": round(B / dt, 1), "T": int(fT.shape[1])}
+    # ---- configs[4]: decode.  (a) at the step bound (random weights never emit END: 152 steps), (b) with weights trained
+    #      to END by the count-down recipe (early exit) ----
+    dec_img = imgT
+    # id_end = -1 can never be emitted: every row runs to the bound (max_iter + 1 = 152 steps), as an untrained model does
+    ns = int(eng.greedy_decode(dec_img, -1, max_iter=151).shape[1])
+    dt = timed(lambda: eng.greedy_decode(dec_img, -1, max_iter=151), 3, warm=1)
+    out["decode_greedy_bound"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": ns, "us_per_step": round(dt * 1e6 / ns, 1),
+                                  "tokens_per_s": round(B * ns / dt, 0), "batch": B}
+    ns = int(eng.beam_decode(dec_img, -1, 5, max_iter=151).shape[1])
+    dt = timed(lambda: eng.beam_decode(dec_img, -1, 5, max_iter=151), 2, warm=1)
+    out["decode_beam5_bound"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": ns, "us_per_step": round(dt * 1e6 / ns, 1),
+                                 "tokens_per_s": round(B * ns / dt, 0), "batch": B, "beam": 5,
+                                 "note": "tokens = emitted positions of the best hypothesis per image (B x steps); the encoder is inside the timing"}
+    engc = Engine(V, dtype="bf16", device=dev, seed=0)
+    for step in range(260):
+        ci, cf = count_set(16, 100 + step, H, W)
+        f, l = pad_batch_formulas(cf, V - 2, V - 1)
+        engc.train_step(pad_batch_images(ci), f, l, 1e-3, sync_loss=False)
+    ci, cf = count_set(B, 5, H, W)
+    cimg = torch.from_numpy(pad_batch_images(ci)).to(dev)
+    ids = engc.greedy_decode(cimg, V - 1, max_iter=151)
+    ntok = int(sum(min(len(x) + 1, ids.shape[1]) for x in cf))
+    dt = timed(lambda: engc.greedy_decode(cimg, V - 1, max_iter=151), 5, warm=1)
+    out["decode_greedy_trained_to_end"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": int(ids.shape[1]), "tokens_per_s": round(ntok / dt, 0),
+                                           "batch": B, "note": "weights: 260 Adam steps on the ink-density count-down set; tokens = formula tokens + END"}
+    bids = engc.beam_decode(cimg, V - 1, 5, max_iter=151)
+    dt = timed(lambda: engc.beam_decode(cimg, V - 1, 5, max_iter=151), 5, warm=1)
+    out["decode_beam5_trained_to_end"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": int(bids.shape[1]), "tokens_per_s": round(ntok / dt, 0),
+                                          "batch": B, "beam": 5}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--vocab", type=int, default=500)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="headline timing only (for profiler runs): no roofline micro-timings, no secondary keys")
+    ap.add_argument("--no-extras", action="store_true", help="headline timing only (profiler runs): no instrumented step, no secondary keys")
+    ap.add_argument("--no-secondary", action="store_true", help="skip configs[1] / T=151 / decode measurements")
+    ap.add_argument("--sim", action="store_true", help="TEST ONLY: CPU tensors, gloo, the hipsim build of the kernels, tiny shapes")
     args = ap.parse_args()
-    if args.dtype != "bf16":
+    if args.dtype != "bf16" and not args.sim:
         ap.error("bench.py measures the bf16 path (the metric's dtype); f32 is the parity mode exercised by tests/")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
-    dist = None
-    if world > 1 or os.environ.get("LXO_FORCE_DIST") == "1":
-        import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-        from latex_ocr_amd.dist import DataParallel
-        dist = DataParallel(device=dev)
-
     from latex_ocr_amd import synthetic
     from latex_ocr_amd.engine import Engine
     from latex_ocr_amd.model.utils.image import pad_batch_images
     from latex_ocr_amd.model.utils.text import pad_batch_formulas
 
-    B, H, W, V = args.batch, args.height, args.width, args.vocab
-    imgs, forms = synthetic.make_set(B, H, W, V, 30, 101, seed=1234 + rank)
+    dist = None
+    if args.sim:
+        # the N > 1 path on a GPU-less box: same driver code, gloo instead of RCCL, kernels interpreted by tests/hipsim
+        import ctypes
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from simlib import SIM_SO, build_sim
+        from latex_ocr_amd import _abi
+        if rank == 0:
+            build_sim()
+        dev = "cpu"
+        sync = lambda: None
+        if world > 1:
+            import torch.distributed as td
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group(backend="gloo", rank=rank, world_size=world)
+            td.barrier()
+            from latex_ocr_amd.dist import DataParallel
+            dist = DataParallel(device="cpu")
+        small = dict(C=128, E=128, U=128, O=128, D=16)
+        B, H, W, V = 2, 32, 48, 11
+        eng = Engine(V, dims=small, dtype="f32", device="cpu", seed=0, lib=_abi.bind(ctypes.CDLL(SIM_SO)))
+        imgs, forms = synthetic.make_set(B, H, W, V, 2, 5, seed=1234 + rank)
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = "cuda:%d" % local_rank
+        sync = torch.cuda.synchronize
+        if world > 1 or os.environ.get("LXO_FORCE_DIST") == "1":
+            import torch.distributed as td
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+            from latex_ocr_amd.dist import DataParallel
+            dist = DataParallel(device=dev)
+        B, H, W, V = args.batch, args.height, args.width, args.vocab
+        eng = Engine(V, dtype=args.dtype, device=dev, seed=0)
+        imgs, forms = synthetic.make_set(B, H, W, V, 30, 101, seed=1234 + rank)
     img = torch.from_numpy(pad_batch_images(imgs)).to(dev)
     f, l = pad_batch_formulas(forms, V - 2, V - 1)
     f_d = torch.from_numpy(f).to(dev)
     T = int(f.shape[1])
-    eng = Engine(V, dtype=args.dtype, device=dev, seed=0)
 
     def step():
         return eng.train_step(img, f_d, l, 1e-3, dist=dist, sync_loss=False)
@@ -120,14 +301,14 @@ def main():
         step()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -136,70 +317,65 @@ def main():
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
 
-    out = None
-    if rank == 0 and args.no_extras:
-        print(json.dumps({"metric": "formula-images/sec training step (batch 64, 128x512)", "value": round(value, 2), "unit": "img/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3)}), flush=True)
-    elif rank == 0:
-        # ---- roofline of the dominant kernel family: the implicit-GEMM conv (MFMA bound) ----
-        flops, secs, per = eng.time_conv_gemms(B, H, W)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "conv_nt_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # dominant kernel: conv_halo2wg_kernel (8x32-pixel halo tiles x 128 / 64 channels, two workgroups per CU; all ten conv launches)
-        dom = [x for x in per if x["kernel"] == "conv_halo2wg_kernel"] or per
-        dflops, dsecs = sum(x["flops"] for x in dom), sum(x["us"] for x in dom) * 1e-6
-        for x in per:
-            x.pop("flops", None)
-        roof = {"kernel": "%s (bf16 implicit-GEMM 3x3 conv, halo tiles): %d of the %d conv forward/dgrad launches of a step"
-                          % (dom[0]["kernel"], len(dom), len(per)),
-                "bound": "mfma", "achieved": round(dflops / dsecs / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(dflops / dsecs / MFMA_BF16_PEAK, 4), "traffic": traffic,
-                "flops_per_launch": dflops / len(dom), "avg_launch_us": round(dsecs / len(dom) * 1e6, 1),
-                "all_conv_launches": {"achieved": round(flops / secs / 1e12, 2), "frac": round(flops / secs / MFMA_BF16_PEAK, 4),
-                                      "launches": per}}
-        c8 = lambda n: -(-(-(-(-(-n // 2)) // 2)) // 2)
-        Rr = (c8(H) - 2) * (c8(W) - 2)
-        nbytes, asec = eng.time_attention(B, Rr)
-        roof_att = {"kernel": "attn_fwd_part_kernel + attn_fwd_combine_kernel (one decoder step, B samples)", "bound": "hbm",
-                    "achieved": round(nbytes / asec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / asec / 8e12, 4),
-                    "traffic": None, "bytes_per_launch": nbytes, "avg_launch_us": round(asec * 1e6, 2)}
+    if rank == 0:
         out = {
-            "metric": "formula-images/sec training step (batch 64, 128x512)", "value": round(value, 2), "unit": "img/s",
+            "metric": METRIC, "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.sim else args.dtype, "data": "synthetic",
             "config": {"workload": "configs[2]: full encoder+attention+decoder training step, batch %d/GPU, %dx%d, vocab %d, "
                                    "T=%d (lengths U{30..100}), Adam" % (B, H, W, V, T),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
-            "conv_roofline_fraction_e2e": round(GF_TRAIN_PER_IMG * (H * W / (128.0 * 512.0)) * value / world / MFMA_BF16_PEAK, 4),
         }
-        out["roofline"] = roof
-        out["roofline_attention"] = roof_att
-        if world == 1:
-            # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still
-            # inside their formula (same loss and gradients; the reference and `value` above run every padded step)
-            eng.skip_padded = True
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dts = (time.perf_counter() - t1) / args.steps
-            eng.skip_padded = False
-            out["extension_skip_padded_steps"] = {"value": round(B / dts, 2), "unit": "img/s", "ms_per_step": round(dts * 1e3, 3),
-                                                  "note": "not the headline metric: padded (sample, step) pairs skipped, batch sorted by length"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if args.sim:
+            out["config"]["workload"] = "TEST ONLY (--sim): hipsim-interpreted kernels on CPU, gloo, tiny shapes"
+        if not args.sim and not args.no_extras:
+            out["conv_roofline_fraction_e2e"] = round(GF_TRAIN_PER_IMG * (H * W / (128.0 * 512.0)) * value / world / MFMA_BF16_PEAK, 4)
+            recs, phases = instrumented_step(eng, img, f_d, l, torch)
+            roof = roofline_from_records(recs, ("conv_fwd", "conv_dgrad"),
+                                         "conv_halo2wg_kernel (bf16 implicit-GEMM 3x3 conv, halo tiles): the 10 conv forward / data-gradient launches of a step",
+                                         "mfma", MFMA_BF16_PEAK, "TFLOP/s")
+            tpath = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")
+            if roof is not None and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = "profiles/r02_conv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_final.sh), FETCH x2 (gfx950)"
+                except Exception:
+                    pass
+            out["roofline"] = roof
+            out["roofline_wgrad"] = roofline_from_records(recs, ("conv_wgrad",), "conv_wgrad_kernel (bf16 3x3 weight gradient, tap reuse): 5 launches of a step",
+                                                          "mfma", MFMA_BF16_PEAK, "TFLOP/s")
+            out["roofline_attention"] = roofline_from_records(recs, ("attn_fwd",), "attn_fwd_part_kernel + attn_fwd_combine_kernel: one decoder step, B samples, att_img + img streamed once",
+                                                              "hbm", HBM_PEAK, "GB/s")
+            out["roofline_attention_bwd"] = roofline_from_records(recs, ("attn_bwd",), "attn_bwd_part_kernel: one BPTT step, the same two streams",
+                                                                  "hbm", HBM_PEAK, "GB/s")
+            out["ms_per_step_by_phase"] = phases
+            if world == 1:
+                # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still
+                # inside their formula (same loss and gradients; the reference and `value` above run every padded step)
+                eng.skip_padded = True
+                for _ in range(2):
+                    step()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(min(args.steps, 10)):
+                    step()
+                sync()
+                dts = (time.perf_counter() - t1) / min(args.steps, 10)
+                eng.skip_padded = False
+                out["extension_skip_padded_steps"] = {"value": round(B / dts, 2), "unit": "img/s", "ms_per_step": round(dts * 1e3, 3),
+                                                      "note": "not the headline metric: padded (sample, step) pairs skipped, batch sorted by length; runs on round 1's split-K step kernels (lxo_*_active), so it no longer beats the fused default"}
+                if not args.no_secondary:
+                    try:
+                        out["secondary"] = secondary(args, eng, torch, dev, B, H, W, V)
+                    except Exception as e:          # never lose the headline line to a secondary measurement
+                        out["secondary"] = {"error": repr(e)}
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         import torch.distributed as td
-        dist.barrier()                   # ranks > 0 wait for rank 0's roofline micro-timings before tearing down
+        dist.barrier()                   # ranks > 0 wait for rank 0's extra measurements before tearing down
         td.destroy_process_group()
 
 

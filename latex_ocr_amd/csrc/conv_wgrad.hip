@@ -45,7 +45,13 @@ namespace {
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co, int tiles_x, int tiles_y, int nblocks, int per_split) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wci = wave >> 2, wco = wave & 3;            // 2 x 4 waves: 32 ci x 32 co each (x 9 taps)
-    const int tile = blockIdx.x, split = blockIdx.y;
+    // XCD-aware order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  The `ntiles` (ci, co) tiles of ONE pixel
+    // range read the same input and d_out blocks, so they are made neighbours on ONE XCD (the n-th workgroup of XCD x is
+    // tile n % ntiles of pixel range (n / ntiles) * 8 + x): every block is then fetched once per XCD and served to the other
+    // tiles from L2, instead of every XCD pulling every block through the fabric (grid (tile, split) put tile t on XCD t % 8).
+    const int ntiles = p.nbatch;                                // launcher passes the tile count here (nbatch is unused for conv)
+    const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
+    const int tile = seq % ntiles, split = (seq / ntiles) * 8 + xcd;
     const int ci0 = (tile / tiles_co) * WCI, co0 = (tile % tiles_co) * WCO;
     const int Cout = p.J;
     const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.A);
@@ -57,8 +63,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     const int sch = tid & 7;                               // patch: 16-byte chunk (8 channels) of the 64-channel row
     const int dch = tid & 15;                              // d_out: 16-byte chunk of the 128-channel row
     auto issue = [&](int pb, int stage) {
-        char* ps = lxo_wgrad_lds + stage * WSTAGE;
-        char* ds = ps + WPATCH;
         const int tx_i = pb % tiles_x, ty_i = (pb / tiles_x) % tiles_y, b = pb / (tiles_x * tiles_y);
         const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
 #pragma unroll
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
             const bool ok = prow < WPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const int gch = (sch ^ ((prow >> 1) & 7)) << 3;
             const void* src = ok ? (const void*)(X + (((long long)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + gch) : (const void*)zline;
-            glds16(src, ps + (wave * 64 + 512 * j) * 16);
+            LXO_GLDS16_HIDDEN(src, lxo_wgrad_lds, stage * WSTAGE + (wave * 64 + 512 * j) * 16);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                      // 4 LDS-DMA: block pixel k = (tid >> 4) + 32 j
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
             const int gch = (dch ^ (k & 15)) << 3;            // the GLOBAL chunk this lane fetches (LDS slot dch holds it)
             const bool ok = oy < p.Ho && ox < p.Wo && (co0 + gch) < Cout;
             const void* src = ok ? (const void*)(DY + (((long long)b * p.Ho + oy) * p.Wo + ox) * Cout + co0 + gch) : (const void*)zline;
-            glds16(src, ds + (wave * 64 + 512 * j) * 16);
+            LXO_GLDS16_HIDDEN(src, lxo_wgrad_lds, stage * WSTAGE + WPATCH + (wave * 64 + 512 * j) * 16);
         }
     };
 
@@ -94,6 +98,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     const int a_chunk = a_ch >> 3, a_sub = (a_ch & 7) * 2;  // 16-byte chunk, byte offset inside it
     const int b_ch = wco * 32 + 16 * g + 4 * qc;           // channel (within the 128)
     const int b_chunk = b_ch >> 3, b_sub = (b_ch & 7) * 2;
+    // Every LDS address of the K loop = (per-lane register) + (compile-time immediate): the loop used to spend ~14 issue
+    // slots per MFMA on swizzle arithmetic (SQ_ACTIVE_INST_ANY 39 %, MFMA pipe 33 % busy).  A patch read touches pixel
+    // row prow = Cc + bl with Cc even and compile-time, bl = 8h + qj per lane, so its swizzle key ((prow >> 1) & 7) is
+    // (Cc/2 + (bl >> 1)) & 7: eight per-lane offsets, indexed by the compile-time (Cc/2) & 7, cover every read.  A d_out
+    // read touches pixel Cd + bl with Cd a multiple of 16, so its key (pixel & 15) depends on the lane only.
+    const int bl = 8 * h + qj;
+    int poff[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) poff[k] = bl * 128 + ((a_chunk ^ ((k + (bl >> 1)) & 7)) << 4) + a_sub;
+    const int doff_a = WPATCH + bl * 256 + ((b_chunk ^ (bl & 15)) << 4) + b_sub;
+    const int doff_b = WPATCH + (bl + 4) * 256 + ((b_chunk ^ ((bl + 4) & 15)) << 4) + b_sub;
 
     issue(pb_beg, 0);
     for (int pb = pb_beg; pb < pb_end; ++pb) {
@@ -101,29 +116,32 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): only this block's loads are outstanding here
         __builtin_amdgcn_s_barrier();
         if (pb + 1 < pb_end) issue(pb + 1, stage ^ 1);
-        const char* ps = lxo_wgrad_lds + stage * WSTAGE;
-        const char* ds = ps + WPATCH;
-#pragma unroll 1
+        const char* sb = lxo_wgrad_lds + stage * WSTAGE;
+        const char* pk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pk[k] = sb + poff[k];
+        const char* da = sb + doff_a;
+        const char* db = sb + doff_b;
+#pragma unroll
         for (int ks = 0; ks < 8; ++ks) {                   // 16 pixels per K-step: row ty = ks>>2, x = (ks&3)*16 + 8h ..
-            const int ty = ks >> 2, xk = (ks & 3) * 16 + 8 * h;
+            constexpr int dummy = 0; (void)dummy;
+            const int ty = ks >> 2, xc = (ks & 3) * 16;     // compile-time after unrolling
             // B operand: d_out pixels k0..k0+7 of this lane's channel
             u32x4 bfr;
             {
-                const int k0 = ty * 64 + xk;
-                const int ka = k0 + qj, kb = k0 + 4 + qj;
-                const u32x2 lo = tr_read(ds + ka * 256 + ((b_chunk ^ (ka & 15)) << 4) + b_sub);
-                const u32x2 hi = tr_read(ds + kb * 256 + ((b_chunk ^ (kb & 15)) << 4) + b_sub);
+                const int cd = (ty * 64 + xc) * 256;
+                const u32x2 lo = tr_read(da + cd);
+                const u32x2 hi = tr_read(db + cd);
                 bfr = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 // patch row ty + kh, pixels xk .. xk+11 -> three reads, six dwords of pixel pairs
-                const int pr0 = (ty + kh) * WPW + xk;
                 unsigned d[6];
 #pragma unroll
                 for (int q3 = 0; q3 < 3; ++q3) {
-                    const int prow = pr0 + 4 * q3 + qj;
-                    const u32x2 v = tr_read(ps + prow * 128 + ((a_chunk ^ ((prow >> 1) & 7)) << 4) + a_sub);
+                    const int cc = (ty + kh) * WPW + xc + 4 * q3;        // even, compile-time
+                    const u32x2 v = tr_read(pk[(cc >> 1) & 7] + cc * 128);
                     d[2 * q3] = v[0]; d[2 * q3 + 1] = v[1];
                 }
                 const u32x4 a0 = {d[0], d[1], d[2], d[3]};
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
                 acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 1], 0, 0, 0);
                 acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 2], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);              // 144 accumulator registers: keep the reads of later K-steps from being hoisted (spills)
         }
     }
     // reduce into dW[(tap*Cin + ci)][co]
@@ -168,6 +187,10 @@ int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     if (nsplit > nblocks) nsplit = nblocks;
     const int per_split = cdiv(nblocks, nsplit);
     nsplit = cdiv(nblocks, per_split);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, nsplit), dim3(WTHREADS), 2 * WSTAGE, s, p, tiles_co, tiles_x, tiles_y, nblocks, per_split);
+    GemmTN q = p;
+    q.nbatch = tiles;
+    // splits are dealt to the 8 XCDs in turn: round the split count up to a multiple of 8 (empty ranges return at once)
+    const int nsplit8 = (nsplit + 7) / 8 * 8;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * nsplit8), dim3(WTHREADS), 2 * WSTAGE, s, q, tiles_co, tiles_x, tiles_y, nblocks, per_split);
     return (int)hipGetLastError();
 }

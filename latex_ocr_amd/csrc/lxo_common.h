@@ -77,6 +77,19 @@ LXO_DEV float wave_max(float v) {
 }
 LXO_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// LDS-DMA that hipcc's s_waitcnt bookkeeping does not see: global -> LDS, 16 bytes per lane, destination = wave-uniform LDS
+// byte address (lds_base + byte_off) + 16 * lane.  With the builtin form hipcc places `s_waitcnt vmcnt(0)` in front of the next
+// ds_read_b64_tr_b16 (it cannot tell the two LDS stages apart), which drains the prefetch of the NEXT pixel block before the
+// current one is computed: the double buffering never overlapped anything.  The caller counts completion itself
+// (s_waitcnt vmcnt(N), then a barrier, then the reads).  M0 is compiler-reserved: saved, set and restored inside the statement
+// (cdna_hip_programming.md section 5.7).  tests/hipsim pre-defines the macro with its interpreter hook.
+#ifndef LXO_GLDS16_HIDDEN
+#define LXO_GLDS16_HIDDEN(gsrc, lds_base, byte_off) do { unsigned keep_m0_; \
+    const unsigned dst_m0_ = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_base) + (unsigned)(byte_off)); \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_m0_) : "v"(gsrc), "s"(dst_m0_) : "memory"); } while (0)
+#endif
+
 // dtype codes of the C ABI (include/lxo.h)
 #ifndef LXO_F32
 #define LXO_F32 0

@@ -165,7 +165,7 @@ class Engine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
     # ---------------------------------------------------------------- steps --
-    def forward(self, img, formula, dropout=None, active_rows=None):
+    def forward(self, img, formula, dropout=None, active_rows=None, phase_hook=None):
         """Encoder + teacher-forced decoder; leaves logits in the workspace.  dropout = (keep_prob, seed)
         applies tf.nn.dropout on h and o (attention_cell.py:72,83) with this step's counter-based masks;
         backward() regenerates the same masks from the bound shape."""
@@ -180,6 +180,8 @@ class Engine(object):
         st = self._stream()
         self._bind_side()
         self._ck(self.lib.lxo_encoder_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), st), "encoder_fwd")
+        if phase_hook:
+            phase_hook("encoder_fwd")
         self._active = None if active_rows is None else np.ascontiguousarray(active_rows, dtype=np.int32)
         if self._active is None:
             self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
@@ -211,9 +213,10 @@ class Engine(object):
                                                   ctypes.c_float(inv_ntok), self._stream()), "ce_loss")
         return self.region("loss")[:2]
 
-    def backward(self, comm=None):
+    def backward(self, comm=None, phase_hook=None):
         """BPTT + encoder backward into self.grads (zeroed first).  `comm(lo, hi)` is called as soon
-        as the gradient range [lo, hi) is final (data-parallel bucket all-reduce hook)."""
+        as the gradient range [lo, hi) is final (data-parallel bucket all-reduce hook); phase_hook(name) after each
+        part (bench.py's per-phase table)."""
         st = self._stream()
         self._bind_side()
         self.grads.zero_()
@@ -232,6 +235,8 @@ class Engine(object):
         else:
             self._ck(self.lib.lxo_decoder_train_bwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
                                                            _p(self.grads), act, st), "decoder_train_bwd_active")
+        if phase_hook:
+            phase_hook("decoder_bwd")
         self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
                                           6, 5, st), "encoder_bwd")
         if comm:

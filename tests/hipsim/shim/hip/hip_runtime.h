@@ -273,6 +273,8 @@ template <class G, class Lp> inline void hipsim_global_load_lds(G g, Lp l, unsig
     memcpy(reinterpret_cast<char*>((uintptr_t)l) + off + hipsim::lane() * size, reinterpret_cast<const void*>((uintptr_t)g), size);
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipsim_global_load_lds(g, l, size, off, aux)
+// csrc/lxo_common.h: the inline-asm LDS-DMA
+#define LXO_GLDS16_HIDDEN(gsrc, lds_base, byte_off) hipsim_global_load_lds((const void*)(gsrc), (char*)(lds_base) + (byte_off), 16, 0, 0)
 
 // ---- host API subset used by the C-ABI layer ----
 inline hipError_t hipGetLastError() { return hipSuccess; }

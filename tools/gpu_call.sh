@@ -15,6 +15,8 @@ case $what in
             cd $R
             DB=$(ls gpurun_out/${TAG}_prof/*/*_results.db 2>/dev/null | head -1)
             if [ -n "$DB" ]; then python tools/prof_summary.py $DB gpurun_out/${TAG}_kernels.csv "$TAG"; head -24 gpurun_out/${TAG}_kernels.csv | cut -c1-160; python tools/prof_by_grid.py $DB > gpurun_out/${TAG}_bygrid.txt 2>&1; rm -rf gpurun_out/${TAG}_prof; fi;;
+  ktests)   timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q -x > gpurun_out/${TAG}_ktests.log 2>&1; echo "ktests rc=$?"; tail -4 gpurun_out/${TAG}_ktests.log;;
+  benchq)   timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"; python tools/bench_brief.py gpurun_out/${TAG}_bench.log;;
   benchold) LXO_STEP_KERNELS=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_benchold.log 2>&1; echo "benchold rc=$?"; tail -1 gpurun_out/${TAG}_benchold.log | cut -c1-300;;
   *) echo "unknown $what";;
 esac
