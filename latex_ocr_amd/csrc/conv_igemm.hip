@@ -789,6 +789,19 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
 
 }  // namespace
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of the loaded code object: set it once per
+// (kernel family, device), not once per process (a second GPU used from the same process would launch with the default limit)
+static bool attr_needed(int family) {
+    static bool done[4][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[family][dev]) return false;
+    done[family][dev] = true;
+    return true;
+}
+
+// Tuning knobs (read once per process, measurement only; the defaults are the shipped configuration):
+// LXO_CONV_HALO=0 / LXO_CONV_2WG=0 / LXO_CONV_256=0 fall back to the older kernel generations kept for A/B runs.
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
     static int use_halo = -1;
@@ -796,12 +809,10 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     static int use_2wg = -1;
     if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }
     if (use_halo && use_2wg && (p.N % 64) == 0) {
-        static bool w_attr = false;
         constexpr int LDS4 = WPATCHB + 2 * 128 * CBK * 2, LDS2 = WPATCHB + 2 * 64 * CBK * 2;     // 77824, 61440
-        if (!w_attr) {
+        if (attr_needed(0)) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
-            w_attr = true;
         }
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
@@ -814,11 +825,9 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
     static int use_256 = -1;
     if (use_256 < 0) { const char* e = getenv("LXO_CONV_256"); use_256 = (e && e[0] == '0') ? 0 : 1; }
     if (use_halo && use_256 && (p.N % QBN) == 0) {
-        static bool q_attr = false;
         constexpr int LDSQ = 2 * QPATCH + 2 * QB_STAGE;
-        if (!q_attr) {
+        if (attr_needed(1)) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSQ));
-            q_attr = true;
         }
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_n = p.N / QBN, tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
@@ -826,12 +835,10 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
         return (int)hipGetLastError();
     }
     if (use_halo) {
-        static bool halo_attr = false;
         constexpr int LDSB = 2 * HPATCH + 3 * HB_STAGE, LDSB64 = 2 * HPATCH + 3 * (HB_STAGE / 2);
-        if (!halo_attr) {
+        if (attr_needed(2)) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<bf16_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<bf16_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB64));
-            halo_attr = true;
         }
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_x = cdiv(p.Wo, HTW), tiles_y = cdiv(p.Ho, HTH);
@@ -844,10 +851,8 @@ int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
         hipLaunchKernelGGL((conv_halo_kernel<bf16_t, 2>), dim3(B * tiles_x * tiles_y * tiles_n), dim3(CTH), LDSB, s, p, tiles_n, tiles_x, tiles_y);
         return (int)hipGetLastError();
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (attr_needed(3)) {
         HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE));
-        attr_set = true;
     }
     const int tiles_n = cdiv(p.N, CBN), tiles_m = cdiv(p.M, CBM);
     hipLaunchKernelGGL((conv_igemm_kernel<bf16_t>), dim3(tiles_m * tiles_n), dim3(CTH), 3 * STAGE, s, p, tiles_n);

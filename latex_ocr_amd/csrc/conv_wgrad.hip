@@ -173,10 +173,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
 // bf16 only; Cin % 64 == 0, Cout % 8 == 0
 int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.J % 8) return -2;
-    static bool attr = false;
-    if (!attr) {
-        HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE));
-        attr = true;
+    {   // per device, not per process (see conv_igemm.hip attr_needed)
+        static bool done[64] = {};
+        int dev = 0;
+        const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        if (!known || !done[dev]) {
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE));
+            if (known) done[dev] = true;
+        }
     }
     const int B = p.M / (p.Ho * p.Wo);
     const int tiles_ci = p.Cin / WCI, tiles_co = cdiv(p.J, WCO);

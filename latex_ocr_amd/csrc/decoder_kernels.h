@@ -10,6 +10,7 @@ struct Drop { unsigned thr; float inv_keep; unsigned seed; int t, row0, rows_tot
 int lxo_k_rowmean(int dt, const void* img, float* mean, int B, int R, int C, hipStream_t st);
 int lxo_k_embed_gather(int dt, const float* table, const float* start, const int* formula, void* out, int B, int T, int D, int Dp, int V, hipStream_t st);
 int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* ids, void* out, int n, int D, int Dp, int V, hipStream_t st);
+int lxo_k_embed_table(int dt, const float* table, const float* start, void* out, int V, int D, int Dp, hipStream_t st);
 int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, float* ht_out, int ldh, Drop dr, int B, int U, hipStream_t st);
 int lxo_k_lstm_bwd(const float* gates, const float* c_prev, const float* c_cur, Slabs s1, Slabs s3, Slabs s4, int off4,
                    float* dcc, float* dz, Drop dr, int carry_rows, int B, int U, hipStream_t st);

@@ -118,6 +118,20 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     }
 }
 
+// decode: every possible next input once -- row v < V = embedding_table[v], row V = start_token (decoder.py:75-95, greedy_decoder_cell.py:40-43,59)
+template <typename CT>
+__global__ __launch_bounds__(256) void embed_table_kernel(const float* __restrict__ table, const float* __restrict__ start, CT* __restrict__ out,
+                                                         int V, int D, int Dp) {
+    const long long total = (long long)(V + 1) * Dp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int d = (int)(i % Dp);
+        const int r = (int)(i / Dp);
+        float v = 0.f;
+        if (d < D) v = r < V ? table[(long long)r * D + d] : start[d];
+        out[i] = from_f32<CT>(v);
+    }
+}
+
 // TF-1.12 LSTMCell, gate order i,j,f,o, forget_bias 1.0 (attention_cell.py:71).  A group of 4 threads owns 4 units of
 // one row: thread q sums gate q's pre-activations for the 4 units (z + the K1 slabs: one round trip of 16-byte loads),
 // activates them and hands them over through LDS; then thread q finishes unit u + q.  B*U threads (128 workgroups at
@@ -988,6 +1002,12 @@ int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* 
     const int g = grid1((long long)n * Dp);
     if (dt == LXO_BF16) LAUNCH((embed_rows_kernel<bf16_t>), g, table, start, ids, (bf16_t*)out, n, D, Dp, V);
     else LAUNCH((embed_rows_kernel<float>), g, table, start, ids, (float*)out, n, D, Dp, V);
+    DONE;
+}
+int lxo_k_embed_table(int dt, const float* table, const float* start, void* out, int V, int D, int Dp, hipStream_t st) {
+    const int g = grid1((long long)(V + 1) * Dp);
+    if (dt == LXO_BF16) LAUNCH((embed_table_kernel<bf16_t>), g, table, start, (bf16_t*)out, V, D, Dp);
+    else LAUNCH((embed_table_kernel<float>), g, table, start, (float*)out, V, D, Dp);
     DONE;
 }
 int lxo_k_lstm_fwd(const float* z, Slabs zs, const float* c_prev, float* gates, float* c_out, float* h_out, float* ht_out, int ldh, Drop dr, int B, int U, hipStream_t st) {

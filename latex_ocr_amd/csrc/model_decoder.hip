@@ -126,19 +126,23 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
 static int cell_step_fused(const Plan& P, const float* prm, const void* wp, void* ws, int nr, int beam,
                            const float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
                            const bf16_t* recb_prev, bf16_t* recb_cur,
-                           float* gates_t, float* atth_t, float* alpha_t, Drop dr, hipStream_t st) {
+                           float* gates_t, float* atth_t, float* alpha_t, Drop dr, hipStream_t st,
+                           const int* zx_idx = nullptr, int zx_row = -1) {
+    // zx_t: training = the step's rows of emb K[0:D] + b; decode = the per-token table (zx_idx picks the row of each decoder row,
+    // zx_row >= 0 = one row for all: the start token)
     const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
     const bool bf = P.bf;
     const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG);
     const char* img = (const char*)P.ws<void>(ws, W_IMG);
     float* part = P.ws<float>(ws, W_APART);
     RStep a; memset(&a, 0, sizeof(a));
-    a.M = nr; a.U = U; a.O = O; a.dr = dr;
+    a.M = nr; a.U = U; a.O = O; a.dr = dr; a.zx_row = -1;
     // z = zx + [o_prev, h_prev] K[D:] -> gates, c, h, h~        (attention_cell.py:70-72)
     RStep k1 = a;
     k1.A = bf ? (const void*)recb_prev : (const void*)rec_prev; k1.lda = bf ? P.RECB : P.REC;
     k1.W = P.pk(wp, K_LSTM_RT); k1.ldw = P.ldRT; k1.N = 4 * U; k1.K = P.XH; k1.epi = RS_LSTM_FWD;
     k1.zx = zx_t; k1.c_prev = cs_prev; k1.gates = gates_t; k1.c_out = cs_cur;
+    k1.zx_idx = zx_idx; k1.zx_vocab = P.s.V; k1.zx_row = zx_row;
     k1.out = rec_cur + O; k1.out2 = rec_cur + P.OFF_HT; k1.ldo = P.REC;
     if (bf) { k1.outb = recb_cur + O; k1.out2b = recb_cur + P.OFF_HT; k1.ldob = P.RECB; }
     RC(lxo_launch_rstep(P.s.dtype, bf, k1, st));
@@ -267,7 +271,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_k_tanh_bwd(dolog + (size_t)(T - 1) * B * O, O, kNoSlabs, rec + (size_t)T * B * P.REC, P.REC,
                           gall + (size_t)(T - 1) * B * O, O, bf ? gb : nullptr, P.GBP, P.drop(T - 1, 0), 0, B, O, st));
         RStep a; memset(&a, 0, sizeof(a));
-        a.M = B; a.U = U; a.O = O;
+        a.M = B; a.U = U; a.O = O; a.zx_row = -1;
         for (int t = T - 1; t >= 0; --t) {
             const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
             float* g_t = gall + (size_t)t * B * O;
@@ -395,28 +399,94 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
 }
 
 // ------------------------------------------------------------------ decode ----
-static int decode_common_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam, int cur, const int* ids_prev, hipStream_t st) {
-    const int U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V, E = P.s.E;
-    float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
-    float* zx = P.ws<float>(ws, W_DEC_ZX);
-    // next input embedding (start token at time 0), its LSTM x-part, then the cell step
-    RC(lxo_k_embed_rows(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], ids_prev, P.ws<void>(ws, W_DEC_EMB), nv, D, P.Dp, V, st));
-    RC(nt(P, false, true, false, P.ws<void>(ws, W_DEC_EMB), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, nv, 4 * U, P.Dp,
+// x-part of the LSTM pre-activation for every possible input token, once per decode call: row v = embedding_table[v] K[0:D] + b,
+// row V = the start token's.  The step kernels then pick rows by the previous ids (no per-step gather + GEMM launches).
+static int decode_token_table(const Plan& P, const float* prm, const void* wp, void* ws, hipStream_t st) {
+    const int U = P.s.U, D = P.s.D, V = P.s.V;
+    RC(lxo_k_embed_table(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], P.ws<void>(ws, W_DEC_TXE), V, D, P.Dp, st));
+    RC(nt(P, false, true, false, P.ws<void>(ws, W_DEC_TXE), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, P.ws<float>(ws, W_DEC_TX), 4 * U, V + 1, 4 * U, P.Dp,
           prm + P.poff[P_LSTM_B], 0, false, st));
+    return 0;
+}
+static int decode_common_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam, int cur, const int* ids_prev, hipStream_t st) {
+    const int U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
+    float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     const int prev = cur ^ 1;
     if (fused_steps(P)) {
         bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
-        RC(cell_step_fused(P, prm, wp, ws, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
+        RC(cell_step_fused(P, prm, wp, ws, nv, beam, P.ws<float>(ws, W_DEC_TX), rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
                            rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U,
                            recb + (size_t)prev * nv * P.RECB, recb + (size_t)cur * nv * P.RECB, nullptr,
-                           P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st));
-    } else
-    RC(cell_step(P, prm, wp, ws, 0, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
-                 rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U, nullptr,
-                 P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st));
+                           P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st,
+                           ids_prev, ids_prev ? -1 : V));
+    } else {
+        // next input embedding (start token at time 0), its LSTM x-part, then the cell step
+        float* zx = P.ws<float>(ws, W_DEC_ZX);
+        RC(lxo_k_embed_rows(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], ids_prev, P.ws<void>(ws, W_DEC_EMB), nv, D, P.Dp, V, st));
+        RC(nt(P, false, true, false, P.ws<void>(ws, W_DEC_EMB), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, nv, 4 * U, P.Dp,
+              prm + P.poff[P_LSTM_B], 0, false, st));
+        RC(cell_step(P, prm, wp, ws, 0, nv, beam, zx, rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
+                     rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U, nullptr,
+                     P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st));
+    }
     RC(nt(P, true, true, nv <= 64, rec + (size_t)cur * nv * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_DEC_LOGITS), P.Vp,
           nv, V, O, nullptr, 0, false, st));
-    (void)E;
+    return 0;
+}
+
+// Host side of dynamic_decode's `while not all(finished)` (dynamic_decode.py:38-61): steps are enqueued in chunks of CHUNK;
+// each chunk ends with an asynchronous copy of its per-step "rows still unfinished" counters into pinned host memory and
+// an event.  The host enqueues chunk c + 1 BEFORE it waits for chunk c's event, so the stream never drains while the
+// host looks at the flags (the round-1 loop synchronised the stream every 8 steps); if chunk c turns out to contain the
+// last step, chunk c + 1 ran speculatively (its ids land beyond `steps` columns, which no caller reads).
+namespace {
+struct DecodePoll { int* host; hipEvent_t ev[2]; bool ok; };
+thread_local DecodePoll g_poll = {nullptr, {nullptr, nullptr}, false};
+int poll_init() {
+    if (g_poll.ok) return 0;
+    HIPRC(hipHostMalloc((void**)&g_poll.host, 2 * 64 * sizeof(int), 0));      // one-time 512-byte pinned buffer per host thread
+    HIPRC(hipEventCreateWithFlags(&g_poll.ev[0], hipEventDisableTiming));
+    HIPRC(hipEventCreateWithFlags(&g_poll.ev[1], hipEventDisableTiming));
+    g_poll.ok = true;
+    return 0;
+}
+}  // namespace
+template <typename StepFn>
+static int decode_loop(int max_iter, int* flags, hipStream_t st, int* steps_out, StepFn step) {
+    RC(poll_init());
+    const int CHUNK = 8;
+    int enq = 0;                 // steps enqueued so far
+    int nchunks = 0;             // chunks enqueued
+    int steps = -1;              // final step count once known
+    auto enqueue_chunk = [&]() -> int {
+        const int slot = nchunks & 1;
+        int* dflags = flags + slot * 32;                      // device counters of this chunk (flags[0..63]: two slots of 32)
+        HIPRC(hipMemsetAsync(dflags, 0, CHUNK * sizeof(int), st));
+        int n = 0;
+        for (; n < CHUNK && enq <= max_iter; ++n, ++enq) RC(step(enq, dflags + n));
+        HIPRC(hipMemcpyAsync(g_poll.host + slot * 64, dflags, CHUNK * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPRC(hipEventRecord(g_poll.ev[slot], st));
+        g_poll.host[slot * 64 + 32] = n;                      // steps in this chunk
+        g_poll.host[slot * 64 + 33] = enq - n;                // first step of this chunk
+        ++nchunks;
+        return 0;
+    };
+    RC(enqueue_chunk());
+    int checked = 0;
+    while (steps < 0) {
+        if (enq <= max_iter) RC(enqueue_chunk());             // speculative: keeps the stream busy while the host polls
+        const int slot = checked & 1;
+        HIPRC(hipEventSynchronize(g_poll.ev[slot]));
+        const int n = g_poll.host[slot * 64 + 32], first = g_poll.host[slot * 64 + 33];
+        for (int c = 0; c < n; ++c) {
+            // dynamic_decode.py:38-51: stop after the first step that leaves nothing unfinished, or after step max_iter
+            if (g_poll.host[slot * 64 + c] == 0 || first + c >= max_iter) { steps = first + c + 1; break; }
+        }
+        ++checked;
+        if (steps < 0 && checked == nchunks && enq > max_iter) steps = enq;      // cannot happen (the last step hits the bound); belt and braces
+    }
+    if (nchunks > checked) HIPRC(hipEventSynchronize(g_poll.ev[(nchunks - 1) & 1]));   // the speculative chunk must not outlive the call's buffers
+    if (steps_out) *steps_out = steps;
     return 0;
 }
 
@@ -431,32 +501,15 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
     int* ids_step = P.ws<int>(ws, W_DEC_IDS);
     HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st));
     // rec/cs slot 0 holds the initial state; slots alternate
-    int steps = 0;
-    const int CHUNK = 8;                               // host checks "all finished" every CHUNK steps
-    int host_cnt[64];
-    bool done = false;
-    while (!done) {
-        HIPRC(hipMemsetAsync(flags, 0, 64 * sizeof(int), st));
-        int issued = 0;
-        for (int c = 0; c < CHUNK && steps + c <= max_iter; ++c) {
-            const int time = steps + c;
-            const int cur = (time + 1) & 1;
-            RC(decode_common_step(P, prm, wp, ws, B, 1, cur, time == 0 ? nullptr : ids_step, st));
-            if (alpha_out)      // attention weights of this step (what attention_mechanism.py:96-105 hands to its py_func hook)
-                HIPRC(hipMemcpyAsync(alpha_out + (size_t)time * B * P.Rp, P.ws<float>(ws, W_ALPHA), (size_t)B * P.Rp * 4, hipMemcpyDeviceToDevice, st));
-            RC(lxo_k_argmax(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, id_end, ids_step, ids_out, ms, time, finished, flags + c, st));
-            ++issued;
-        }
-        HIPRC(hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPRC(hipStreamSynchronize(st));
-        // dynamic_decode.py:38-51: stop after the first step that leaves nothing unfinished, or after step max_iter
-        for (int c = 0; c < issued; ++c) {
-            ++steps;
-            if (host_cnt[c] == 0 || steps - 1 >= max_iter) { done = true; break; }
-        }
-        if (issued == 0) done = true;
-    }
-    if (steps_out) *steps_out = steps;
+    if (fused_steps(P)) RC(decode_token_table(P, prm, wp, ws, st));
+    RC(decode_loop(max_iter, flags, st, steps_out, [&](int time, int* unfinished) -> int {
+        const int cur = (time + 1) & 1;
+        RC(decode_common_step(P, prm, wp, ws, B, 1, cur, time == 0 ? nullptr : ids_step, st));
+        if (alpha_out)      // attention weights of this step (what attention_mechanism.py:96-105 hands to its py_func hook)
+            HIPRC(hipMemcpyAsync(alpha_out + (size_t)time * B * P.Rp, P.ws<float>(ws, W_ALPHA), (size_t)B * P.Rp * 4, hipMemcpyDeviceToDevice, st));
+        RC(lxo_k_argmax(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, id_end, ids_step, ids_out, ms, time, finished, unfinished, st));
+        return 0;
+    }));
     return 0;
 }
 
@@ -475,33 +528,17 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
     HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)nv * 4, st));
     HIPRC(hipMemsetAsync(logp, 0, (size_t)nv * 4, st));
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
-    int steps = 0;
-    const int CHUNK = 8;
-    int host_cnt[64];
-    bool done = false;
-    while (!done) {
-        HIPRC(hipMemsetAsync(flags, 0, 64 * sizeof(int), st));
-        int issued = 0;
-        for (int c = 0; c < CHUNK && steps + c <= max_iter; ++c) {
-            const int time = steps + c;
-            const int cur = (time + 1) & 1;
-            RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st));
-            RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, P.s.div_gamma, P.s.div_prob, P.s.div_seed, tmp,
-                               logp, finished, ids_step, par_step,
-                               ids_out, parents_out, ms, flags + c, st));
-            RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
-                                 tmp, tmp + (size_t)nv * P.XH, nv, st));
-            if (fused_steps(P)) RC(mirror_oh(P, ws, (size_t)cur * nv, nv, st));    // the re-ordered [o | h] rows feed the next LSTM GEMM
-            ++issued;
-        }
-        HIPRC(hipMemcpyAsync(host_cnt, flags, 64 * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPRC(hipStreamSynchronize(st));
-        for (int c = 0; c < issued; ++c) {
-            ++steps;
-            if (host_cnt[c] == 0 || steps - 1 >= max_iter) { done = true; break; }
-        }
-        if (issued == 0) done = true;
-    }
-    if (steps_out) *steps_out = steps;
+    if (fused_steps(P)) RC(decode_token_table(P, prm, wp, ws, st));
+    RC(decode_loop(max_iter, flags, st, steps_out, [&](int time, int* unfinished) -> int {
+        const int cur = (time + 1) & 1;
+        RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st));
+        RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, P.s.div_gamma, P.s.div_prob, P.s.div_seed, tmp,
+                           logp, finished, ids_step, par_step,
+                           ids_out, parents_out, ms, unfinished, st));
+        RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
+                             tmp, tmp + (size_t)nv * P.XH, nv, st));
+        if (fused_steps(P)) RC(mirror_oh(P, ws, (size_t)cur * nv, nv, st));    // the re-ordered [o | h] rows feed the next LSTM GEMM
+        return 0;
+    }));
     return 0;
 }

@@ -43,7 +43,7 @@ enum WsId {
     W_DLOGITS, W_LOSS, W_DOLOG, W_G, W_DHC, W_DE, W_DATTH, W_DZ, W_DXH, W_DCC, W_DIMG, W_DATTIMG,
     W_DEMB, W_DPRE0, W_DMEAN, W_G0, W_G1, W_G2, W_GNORM,
     W_S_K1, W_S_K2, W_S_K4, W_S_B1, W_S_B3, W_S_B4,   // split-K slabs of the recurrent GEMMs (step_kernels == 1 only)
-    W_RECB, W_GB, W_DZB, W_CARRYH,                    // fused step kernels: bf16 mirrors of rec / g_t / d_z_t, carried d_h
+    W_RECB, W_GB, W_DZB, W_CARRYH, W_DEC_TX, W_DEC_TXE,                    // fused step kernels: bf16 mirrors of rec / g_t / d_z_t, carried d_h; decode: x-part of the LSTM pre-activation per token (+ its input rows)
     // decode-only
     W_DEC_IDS, W_DEC_FLAGS, W_DEC_EMB, W_DEC_ZX, W_DEC_LOGITS, W_BEAM_LP, W_BEAM_PAR, W_BEAM_TMP,
     W_COLS,        // cnn encoder only: im2col of the strided conv [B*H6*W5][8C], reused for its column gradient

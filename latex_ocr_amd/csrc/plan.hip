@@ -43,7 +43,7 @@ static const char* kWsNames[W_COUNT] = {
     "dlogits", "loss", "do_log", "g", "dhc", "de", "datth", "dz", "dxh", "dcc", "d_img", "d_att_img",
     "d_emb", "dpre0", "dmean", "g0", "g1", "g2", "gnorm",
     "s_k1", "s_k2", "s_k4", "s_b1", "s_b3", "s_b4",
-    "recb", "gb", "dzb", "carry_h",
+    "recb", "gb", "dzb", "carry_h", "dec_tx", "dec_txe",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
     "cols",
 };
@@ -165,6 +165,8 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
         wb[W_DEC_IDS] = BK_ * ms * 4;
         wb[W_DEC_FLAGS] = 256 + BK_ * 4;
         wb[W_DEC_EMB] = BK_ * Dp * esz;
+        wb[W_DEC_TX] = (size_t)(V + 1) * 4 * U * f4;       // row v = embedding_table[v] K[0:D] + b, row V = start_token K[0:D] + b
+        wb[W_DEC_TXE] = (size_t)(V + 1) * Dp * esz;
         wb[W_DEC_ZX] = BK_ * 4 * U * f4;
         wb[W_DEC_LOGITS] = BK_ * Vp * f4;
         wb[W_BEAM_LP] = BK_ * 2 * f4;

@@ -22,6 +22,8 @@ struct RStep {
     float* out2; bf16_t* out2b;    // LSTM_FWD: h~ (same pitches as out / outb); CARRY: carry_h [M][U]
     // LSTM_FWD
     const float* zx; const float* c_prev; float* gates; float* c_out;
+    const int* zx_idx; int zx_vocab, zx_row;   // decode: row m of the x-part = zx[clamp(zx_idx[m], 0, zx_vocab - 1)] (zx = per-token table), or zx[zx_row] for
+                                               // every m when zx_idx is null and zx_row >= 0 (start token); training: zx_idx null, zx_row < 0 -> zx[m]
     // LSTM_BWD (c_prev shared with LSTM_FWD)
     const float* dhm; int lddhm; const float* carry_h; const float* gates_in; const float* c_cur; float* dcc; int carry_rows;
     // CARRY

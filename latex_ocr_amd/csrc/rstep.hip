@@ -107,8 +107,11 @@ __global__ __launch_bounds__(256) void rstep_kernel(RStep p) {
     float e0[4], e1[4], e2[4], e3[4], e4[4], e5[4], e6[4], e7[4], e8[4];
     if constexpr (EPI == RS_LSTM_FWD) {
         const int U = p.U, u = blockIdx.x * 4 + part;
+        long long zr = mc;                                    // row of the x-part: the step's own row, or the token's row of the decode table
+        if (p.zx_idx) { int id = p.zx_idx[mc]; id = id < 0 ? 0 : (id >= p.zx_vocab ? p.zx_vocab - 1 : id); zr = id; }
+        else if (p.zx_row >= 0) zr = p.zx_row;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pz[q] = p.zx[(long long)mc * 4 * U + q * U + u];
+        for (int q = 0; q < 4; ++q) pz[q] = p.zx[zr * 4 * U + q * U + u];
         pcp = p.c_prev[(long long)mc * U + u];
     } else if constexpr (EPI == RS_LSTM_BWD) {
         const int U = p.U;

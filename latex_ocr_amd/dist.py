@@ -49,6 +49,11 @@ class DataParallel(object):
         td.all_reduce(t, op=td.ReduceOp.SUM)
         return float(t.item())
 
+    def broadcast_scalar(self, x, src=0):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
+        td.broadcast(t, src=src)
+        return float(t.item())
+
     def all_reduce(self, t):
         td.all_reduce(t, op=td.ReduceOp.SUM)
 

@@ -84,7 +84,7 @@ def bleu_score(references, hypotheses, max_n=4):
             h = Counter(tuple(hyp[i:i + n]) for i in range(len(hyp) - n + 1))
             r = Counter(tuple(ref[i:i + n]) for i in range(len(ref) - n + 1))
             num[n - 1] += sum(min(c, r[g]) for g, c in h.items())
-            den[n - 1] += max(1, sum(h.values())) if len(hyp) >= n else 0
+            den[n - 1] += max(1, len(hyp) - n + 1)      # nltk modified_precision: Fraction(num, max(1, sum(counts))) also for hypotheses shorter than n
     if num[0] == 0 or min(num) == 0 or min(den) == 0:
         return 0.0
     logp = sum(math.log(n / d) for n, d in zip(num, den)) / max_n

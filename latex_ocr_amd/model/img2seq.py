@@ -80,12 +80,14 @@ class Img2SeqModel(BaseModel):
         world = self.dist.world if self.dist is not None else 1
         rank = self.dist.rank if self.dist is not None else 0
         nbatches = (len(train_set) + batch_size * world - 1) // (batch_size * world)
-        prog = Progbar(nbatches)
         keep = getattr(config, "dropout", 1)
         if not keep > 0:
             raise ValueError("dropout is a keep probability and must be > 0, got {}".format(keep))
         depth = int(getattr(config, "prefetch_depth", 2))
         batches = ShardedBuckets(train_set, batch_size, world, rank) if world > 1 else None
+        if batches is not None:
+            nbatches = len(batches)        # steps this pass really takes (per shape bucket), what the LR schedule was scaled with
+        prog = Progbar(nbatches)
         if depth > 0:
             feed = Prefetcher(train_set, batch_size, self._vocab.id_pad, self._vocab.id_end, device=self.engine.device,
                               depth=depth, batches=batches)
@@ -106,6 +108,10 @@ class Img2SeqModel(BaseModel):
         config_eval = Config({"dir_answers": self._dir_output + sub, "batch_size": config.batch_size})
         scores = self.evaluate(config_eval, val_set)
         score = scores["perplexity"]
+        if self.dist is not None:
+            # every rank scored its own copy of the validation set with atomically (order-dependently) accumulated statistics:
+            # rank 0's number decides, so that score-driven decay / early stopping cannot diverge between ranks
+            score = self.dist.broadcast_scalar(score)
         lr_schedule.update(score=score)
         return score
 

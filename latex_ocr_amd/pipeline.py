@@ -25,7 +25,13 @@ class Batch(object):
     def wait(self, stream=None):
         """Make `stream` (default: the current stream) wait for this batch's host-to-device copies."""
         if self.ready is not None:
-            (stream or torch.cuda.current_stream(self.img.device)).wait_event(self.ready)
+            st = stream or torch.cuda.current_stream(self.img.device)
+            st.wait_event(self.ready)
+            # the tensors were allocated on the copy stream: tell the caching allocator that `st` uses them too, or the
+            # block could be handed back to the copy stream (and overwritten by a later upload) while kernels of this
+            # step -- conv1's backward re-reads the image -- are still running
+            self.img.record_stream(st)
+            self.formula.record_stream(st)
         return self
 
 
@@ -113,7 +119,7 @@ class ShardedBuckets(object):
         self.dataset, self.batch_size, self.world, self.rank = dataset, int(batch_size), int(world), int(rank)
         self.dropped = 0
 
-    def __iter__(self):
+    def _groups(self):
         groups, order = {}, []
         for img, form in self.dataset:
             key = tuple(np.asarray(img).shape)
@@ -121,6 +127,24 @@ class ShardedBuckets(object):
                 groups[key] = []
                 order.append(key)
             groups[key].append((img, form))
+        return groups, order
+
+    def __len__(self):
+        """Optimisation steps one pass takes: sum over shape buckets of ceil(n_bucket / (batch_size * world)), minus the
+        dropped tails -- NOT ceil(N / (batch_size * world)): the LR schedule and the global batch counter are scaled by
+        this number (train.py, Img2SeqModel._run_train)."""
+        if getattr(self, "_n_steps", None) is None:
+            groups, order = self._groups()
+            gb = self.batch_size * self.world
+            n = 0
+            for key in order:
+                m = len(groups[key])
+                n += m // gb + (1 if (m % gb) >= self.world else 0)
+            self._n_steps = n
+        return self._n_steps
+
+    def __iter__(self):
+        groups, order = self._groups()
         self.dropped = 0
         gb = self.batch_size * self.world
         for key in order:

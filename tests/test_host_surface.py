@@ -81,6 +81,13 @@ def test_eval_text():
     assert E.exact_match_score(refs, hyps) == 0.5
     assert abs(E.edit_distance(refs, hyps) - (1 - 1 / 7.0)) < 1e-12
     assert E.bleu_score([["a", "b", "c", "d", "e"]], [["a", "b", "c", "d", "e"]]) == 1.0
+    # nltk corpus_bleu semantics for hypotheses shorter than n: modified_precision returns Fraction(num, max(1, sum(counts))),
+    # i.e. every short hypothesis still adds 1 to the n-gram denominator.  Hand computation for the two pairs below:
+    #   p1 = (5+2)/(5+2), p2 = (4+1)/(4+1), p3 = 3/(3+1), p4 = 2/(2+1); lengths equal -> BP = 1
+    refs = [["a", "b", "c", "d", "e"], ["x", "y"]]
+    hyps = [["a", "b", "c", "d", "e"], ["x", "y"]]
+    want = (1.0 * 1.0 * (3 / 4.0) * (2 / 3.0)) ** 0.25
+    assert abs(E.bleu_score(refs, hyps) - want) < 1e-12
 
 
 def test_beam_backtrace_follows_parents():

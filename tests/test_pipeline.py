@@ -62,6 +62,8 @@ def test_sharded_buckets_equal_shapes_and_full_coverage():
         seen += len(i0) + len(i1)
     sb = ShardedBuckets(ds, bs, world, 0); list(sb)
     assert seen + sb.dropped == len(ds)
+    # the step count the LR schedule is scaled with = what a pass really yields (two shape buckets: 3 steps for 23 crops + 2 for 17, whose 1-crop tail is dropped)
+    assert len(sb) == len(per_rank[0]) == 5 and len(ShardedBuckets(ds, bs, 1, 0)) == len(list(ShardedBuckets(ds, bs, 1, 0)))
     # world 1 = the reference's bucket grouping, nothing dropped
     one = list(ShardedBuckets(ds, bs, 1, 0))
     assert sum(len(b[0]) for b in one) == len(ds)

@@ -52,7 +52,9 @@ def main(argv=None):
         td.init_process_group(backend="nccl" if use_gpu else "gloo")
         from latex_ocr_amd.dist import DataParallel
         dist = DataParallel(device=config.device if use_gpu else "cpu")
-        n_batches_epoch = (len(train_set) + config.batch_size * world - 1) // (config.batch_size * world)
+        # steps per epoch under data parallelism = what ShardedBuckets will yield (per shape bucket), not ceil(N / (bs * world))
+        from latex_ocr_amd.pipeline import ShardedBuckets
+        n_batches_epoch = len(ShardedBuckets(train_set, config.batch_size, world, int(os.environ.get("RANK", "0"))))
         lr_schedule = LRSchedule(lr_init=config.lr_init, start_decay=config.start_decay * n_batches_epoch,
                                  end_decay=config.end_decay * n_batches_epoch, end_warm=config.end_warm * n_batches_epoch,
                                  lr_warm=config.lr_warm, lr_min=config.lr_min)
