@@ -217,6 +217,11 @@ constexpr int HPSLOTS = 7 * CTH;                                                
 constexpr int HPATCH = HPSLOTS * 16, HB_STAGE = CBN * CBK * 2;                         // 57344, 16384
 
 #define LXO_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also carries a
+// workgroup-scope fence, which on gfx950 is `s_waitcnt vmcnt(0)`: in the epilogue that made every pass wait for the
+// acknowledgement of the previous pass's global STORES (in-kernel stamps: 32 k cycles of epilogue per tile, a quarter of a
+// conv4 tile and more than half of a conv2 tile).  The epilogue's barriers only protect the f32 staging tile in LDS.
+#define LXO_LDS_BARRIER() do { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } while (0)
 
 // NJ = 32-channel blocks per wave: 2 -> 128-channel tiles, 1 -> 64-channel tiles (layers with Cout <= 64: conv2's dgrad)
 template <typename OT, int NJ>
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
     OT* __restrict__ C = reinterpret_cast<OT*>(p.C);
     const bool plain = !p.out_pre && !p.addend && !p.relu_ref && !p.colsum && !p.accumulate && p.ldc == p.N && (p.N & 7) == 0;
     if (plain) {
-        __syncthreads();
+        LXO_LDS_BARRIER();
         bf16_t* ot = reinterpret_cast<bf16_t*>(lxo_conv_lds);
         constexpr int OP = BN + 8;
 #pragma unroll
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmNT p, int tiles_n, i
                     ot[ml * OP + nl] = f2bf(v);
                 }
         }
-        __syncthreads();
+        LXO_LDS_BARRIER();
 #pragma unroll
         for (int it = 0; it < 4 * NJ; ++it) {
             const int idx = tid + 512 * it, row = idx / (BN / 8), c8 = (idx % (BN / 8)) * 8;
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bias8[e] = p.bias ? p.bias[n + e] : 0.f; csum[e] = 0.f; }
     for (int half = 0; half < 2; ++half) {
-        __syncthreads();
+        LXO_LDS_BARRIER();
         if (wm == half) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
                     for (int e = 0; e < 16; ++e)
                         ot[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf) * OP + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][e];
         }
-        __syncthreads();
+        LXO_LDS_BARRIER();
 #pragma unroll 2
         for (int it = 0; it < 8; ++it) {
             const int row = (tid >> 5) + 16 * it;                       // 0..127 within the half
@@ -586,10 +591,10 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
     }
     if (p.colsum) {
         // 16 thread rows hold partial sums of the same 8 channels: reduce through LDS, then ONE coalesced atomic per channel
-        __syncthreads();
+        LXO_LDS_BARRIER();
 #pragma unroll
         for (int e = 0; e < 8; ++e) ot[(tid >> 5) * OP + c8 + e] = csum[e];
-        __syncthreads();
+        LXO_LDS_BARRIER();
         if (tid < QBN) {
             float sres = 0.f;
 #pragma unroll
@@ -611,8 +616,13 @@ constexpr int WTHR = 256, WPSLOTS = 11 * WTHR;                        // 2816 sl
 constexpr int WPATCHB = WPSLOTS * 16;                                  // 45056
 
 // NJ = 32-channel blocks per wave: 4 -> 128-channel tiles, 2 -> 64-channel tiles (Cout = 64: conv2's dgrad)
-template <int NJ>
-__global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
+// EPI = which fused epilogue is compiled in: 0 bias + activation only; 1 + pre-addend copy + f32 addend (conv6 forward: timing
+// signal); 2 + ReLU mask + bias-gradient column sums (conv4 data gradient); 3 everything, decided at run time.  With the
+// optional operands behind run-time branches hipcc put `s_waitcnt vmcnt(0)` into every row iteration (it cannot count loads
+// it may or may not have issued), so each 16-byte store waited for the previous one's acknowledgement: in-kernel stamps
+// showed 6.3 k cycles per 64-row pass, 32 k per tile -- a quarter of a conv4 tile, more than half of a conv2 tile.
+template <int NJ, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
     constexpr int WBN = 32 * NJ, WBSTAGE = WBN * CBK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = gridDim.x, bid = blockIdx.x;
@@ -669,12 +679,15 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
     const int khalf = lane >> 5;
 
     const int nchunk = p.Cin / CBK, nk = nchunk * 9;
+#define CSTAMP(i) do { if (p.dbg && tid == 0 && (i) < 64) p.dbg[(long long)bid * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+    CSTAMP(0);
     issue_patch(0);
     issue_b(0, 0);
     for (int t = 0; t < nk; ++t) {
         const int c = t / 9, tap = t - 9 * c;
         LXO_VMCNT(0);                                              // B(t) (and, at t == 0, the first patch) have landed
         __builtin_amdgcn_s_barrier();
+        CSTAMP(1 + t);
         if (tap == 0 && t > 0) {
             // new 64-channel slice: every wave is past the old patch, so the single buffer can be refilled; the other
             // workgroup of this CU computes while this one waits for it
@@ -713,6 +726,7 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
         }
     }
 
+    CSTAMP(1 + nk);
     // ---- epilogue: one wave's 64 pixels x WBN channels at a time through LDS as f32 [64][WBN + 4] ----
     bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(p.C);
     bf16_t* __restrict__ Cpre = reinterpret_cast<bf16_t*>(p.out_pre);
@@ -721,10 +735,16 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
     constexpr int OP = WBN + 4, CH = 4 * NJ, RPI = 256 / CH;          // 16-byte chunks per row, rows per iteration
     const int c8 = (tid % CH) * 8, n = n0 + c8;
     float bias8[8], csum[8];
+    {
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bias8[e] = p.bias ? p.bias[n + e] : 0.f; csum[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { bias8[e] = e < 4 ? b0[e] : b1[e - 4]; csum[e] = 0.f; }
+    }
+    const float act_floor = p.act == 1 ? 0.f : -3.0e38f;
     for (int pass = 0; pass < 4; ++pass) {
-        __syncthreads();
+        LXO_LDS_BARRIER();
+        CSTAMP(40 + 3 * pass);
         if (wave == pass) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -734,50 +754,78 @@ __global__ __launch_bounds__(256) void conv_halo2wg_kernel(GemmNT p, int tiles_n
                     for (int e = 0; e < 16; ++e)
                         ot[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf) * OP + j * 32 + (lane & 31)] = acc[i][j][e];
         }
-        __syncthreads();
-#pragma unroll 2
-        for (int it = 0; it < 64 / RPI; ++it) {
+        LXO_LDS_BARRIER();
+        CSTAMP(41 + 3 * pass);
+        constexpr int NIT = 64 / RPI;
+        constexpr bool HAS_ADD = EPI == 1 || EPI == 3, HAS_REF = EPI == 2 || EPI == 3;
+        // phase 1: every operand of the pass's rows is requested (LDS tile, addend, ReLU reference, old C) before anything is used
+        f32x4 t0[NIT], t1[NIT], a0[NIT], a1[NIT], c0[NIT], c1[NIT];
+        u32x4 rf[NIT];
+        long long mrow[NIT];
+        bool okr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             const int row = tid / CH + RPI * it;                        // 0..63 within the pass
             const int oy = oy0 + pass * 2 + (row >> 5), ox = ox0 + (row & 31);
-            if (oy >= p.Ho || ox >= p.Wo) continue;
-            const long long m = ((long long)b * p.Ho + oy) * p.Wo + ox;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ot + row * OP + c8), v1 = *reinterpret_cast<const f32x4*>(ot + row * OP + c8 + 4);
+            okr[it] = oy < p.Ho && ox < p.Wo;
+            mrow[it] = okr[it] ? ((long long)b * p.Ho + oy) * p.Wo + ox : 0;
+            t0[it] = *reinterpret_cast<const f32x4*>(ot + row * OP + c8); t1[it] = *reinterpret_cast<const f32x4*>(ot + row * OP + c8 + 4);
+            if constexpr (HAS_ADD) {
+                if (p.addend) {
+                    const float* ad = p.addend + (mrow[it] % p.addend_rows) * p.N + n;
+                    a0[it] = *reinterpret_cast<const f32x4*>(ad); a1[it] = *reinterpret_cast<const f32x4*>(ad + 4);
+                } else { a0[it] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[it] = a0[it]; }
+            }
+            if constexpr (HAS_REF) {
+                if (ref) rf[it] = *reinterpret_cast<const u32x4*>(ref + mrow[it] * p.ldr + n);
+                else rf[it] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0: mask passes everything
+            }
+            if constexpr (EPI == 3) {
+                if (p.accumulate) {
+                    float cv[8];
+                    load8(C + mrow[it] * p.ldc + n, cv);
+                    c0[it] = f32x4{cv[0], cv[1], cv[2], cv[3]}; c1[it] = f32x4{cv[4], cv[5], cv[6], cv[7]};
+                } else { c0[it] = f32x4{0.f, 0.f, 0.f, 0.f}; c1[it] = c0[it]; }
+            }
+        }
+        // phase 2: arithmetic and the stores, back to back
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[e] = p.alpha * (e < 4 ? v0[e] : v1[e - 4]) + bias8[e];
-                if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
-                else if (p.act == 2) v[e] = tanhf(v[e]);
-            }
-            if (Cpre) store8(Cpre + m * p.ldc + n, v);
-            if (p.addend) {
-                const float* ad = p.addend + (m % p.addend_rows) * p.N + n;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ad), a1 = *reinterpret_cast<const f32x4*>(ad + 4);
+            for (int e = 0; e < 8; ++e)      // ReLU as a max against a wave-uniform floor: no per-element branches (act is 0 or 1 here; the launcher routes tanh elsewhere)
+                v[e] = fmaxf(p.alpha * (e < 4 ? t0[it][e] : t1[it][e - 4]) + bias8[e], act_floor);
+            if constexpr (HAS_ADD) {
+                if (Cpre && okr[it]) store8(Cpre + mrow[it] * p.ldc + n, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (e < 4 ? a0[e] : a1[e - 4]);
+                for (int e = 0; e < 8; ++e) v[e] += (e < 4 ? a0[it][e] : a1[it][e - 4]);
             }
-            if (ref) {
-                float rv[8];
-                load8(ref + m * p.ldr + n, rv);
+            if constexpr (HAS_REF) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned w = rf[it][e >> 1];
+                    const float rv = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+                    v[e] = rv > 0.f ? v[e] : 0.f;
+                }
             }
+            if (okr[it]) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += v[e];
-            if (p.accumulate) {
-                float cv[8];
-                load8(C + m * p.ldc + n, cv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += cv[e];
+                for (int e = 0; e < 8; ++e) csum[e] += v[e];
             }
-            store8(C + m * p.ldc + n, v);
+            if constexpr (EPI == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (e < 4 ? c0[it][e] : c1[it][e - 4]);
+            }
+            if (okr[it]) store8(C + mrow[it] * p.ldc + n, v);
         }
+        CSTAMP(42 + 3 * pass);
     }
+    CSTAMP(2 + nk);
     if (p.colsum) {
-        __syncthreads();
+        LXO_LDS_BARRIER();
 #pragma unroll
         for (int e = 0; e < 8; ++e) ot[(tid / CH) * OP + c8 + e] = csum[e];
-        __syncthreads();
+        LXO_LDS_BARRIER();
         if (tid < WBN) {
             float sres = 0.f;
 #pragma unroll
@@ -802,24 +850,40 @@ static bool attr_needed(int family) {
 
 // Tuning knobs (read once per process, measurement only; the defaults are the shipped configuration):
 // LXO_CONV_HALO=0 / LXO_CONV_2WG=0 / LXO_CONV_256=0 fall back to the older kernel generations kept for A/B runs.
-int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s) {
+static thread_local unsigned long long* g_conv_dbg = nullptr;
+extern "C" int lxo_conv_debug(unsigned long long* buf) { g_conv_dbg = buf; return 0; }
+int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
+    GemmNT p = p0;
+    p.dbg = g_conv_dbg;
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
     static int use_halo = -1;
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
     static int use_2wg = -1;
     if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }
-    if (use_halo && use_2wg && (p.N % 64) == 0) {
+    if (use_halo && use_2wg && (p.N % 64) == 0 && p.act != 2) {
         constexpr int LDS4 = WPATCHB + 2 * 128 * CBK * 2, LDS2 = WPATCHB + 2 * 64 * CBK * 2;     // 77824, 61440
         if (attr_needed(0)) {
-            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
         }
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
-        if (p.N % 128 == 0)
-            hipLaunchKernelGGL(conv_halo2wg_kernel<4>, dim3(B * tiles_x * tiles_y * (p.N / 128)), dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
-        else
-            hipLaunchKernelGGL(conv_halo2wg_kernel<2>, dim3(B * tiles_x * tiles_y * (p.N / 64)), dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+        const bool has_add = p.addend || p.out_pre, has_ref = p.relu_ref || p.colsum;
+        const int epi = p.accumulate || (has_add && has_ref) ? 3 : (has_add ? 1 : (has_ref ? 2 : 0));
+        const dim3 g4(B * tiles_x * tiles_y * (p.N / 128)), g2(B * tiles_x * tiles_y * (p.N / 64));
+        if (p.N % 128 == 0) {
+            if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 0>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 1) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else hipLaunchKernelGGL((conv_halo2wg_kernel<4, 3>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+        } else {
+            if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 0>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+            else hipLaunchKernelGGL((conv_halo2wg_kernel<2, 3>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+        }
         return (int)hipGetLastError();
     }
     static int use_256 = -1;

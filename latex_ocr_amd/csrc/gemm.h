@@ -21,6 +21,7 @@ struct GemmNT {
     int accumulate;
     float* colsum;
     float alpha;
+    unsigned long long* dbg;   // measurement aid (null = off): conv_halo2wg_kernel stamps its phases here, [workgroup][64] (tools/conv_stamps.py)
 };
 
 // C[I,J] (+)= sum_m A[m,I] * B[m,J]      ("TN": reduction over rows)

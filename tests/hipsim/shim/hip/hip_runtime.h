@@ -268,6 +268,19 @@ template <class Lp> inline hipsim_v4s hipsim_ds_read_tr16_b64(Lp p) {
 inline unsigned hipsim_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
 #define __builtin_amdgcn_alignbit(hi, lo, sh) hipsim_alignbit(hi, lo, sh)
 
+// v_permlane32_swap_b32 vdst, src: lanes 32-63 of vdst swap with lanes 0-31 of src; returns {new vdst, new src}
+typedef __attribute__((ext_vector_type(2))) unsigned hipsim_v2u;
+inline hipsim_v2u hipsim_permlane32_swap(unsigned vdst, unsigned src) {
+    const unsigned l = hipsim::lane();
+    const unsigned other_src = hipsim::exchange(src, l ^ 32u);      // what the partner lane holds in src
+    const unsigned other_dst = hipsim::exchange(vdst, l ^ 32u);     // what the partner lane holds in vdst
+    hipsim_v2u r;
+    if (l < 32) { r[0] = vdst; r[1] = other_dst; }
+    else { r[0] = other_src; r[1] = src; }
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipsim_permlane32_swap(a, b)
+
 // LDS-DMA: every lane copies `size` bytes from its own global pointer to (wave-uniform LDS base + lane*size)
 template <class G, class Lp> inline void hipsim_global_load_lds(G g, Lp l, unsigned size, int off, unsigned) {
     memcpy(reinterpret_cast<char*>((uintptr_t)l) + off + hipsim::lane() * size, reinterpret_cast<const void*>((uintptr_t)g), size);
