@@ -666,13 +666,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         for (int j = 0; j < NJ; ++j) glds16(src + j * b_step, dst + 4096 * j);
     };
 
+    // The accumulators START as the bias (alpha == 1 for every convolution): its loads overlap the first patch / weight
+    // DMA, and no epilogue has to fetch 64 per-lane bias values with the MFMA results waiting (5.6 k cycles in the stamps).
+    // Layout (MFMA operands swapped, see the K loop): acc[i][j][e] -> channel j*32 + 8*(e>>2) + 4*(lane>>5) + (e&3).
     f32x16 acc[2][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int k = 0; k < 4; ++k) {
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 32 + 8 * k + 4 * (lane >> 5));
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) { acc[0][j][4 * k + e] = bq[e]; acc[1][j][4 * k + e] = bq[e]; }
+        }
+    }
 
     const int a_prow0 = (wave * 2) * QPW + (lane & 31);             // this wave's two tile rows
     const int b_row0 = lane & 31;
@@ -721,12 +728,56 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ks & 1][i]),
-                                                                        __builtin_bit_cast(bf16x8_t, bfr[ks & 1][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks & 1][j]),
+                                                                        __builtin_bit_cast(bf16x8_t, af[ks & 1][i]), acc[i][j], 0, 0, 0);
         }
     }
+    // The MFMA runs with the operand roles swapped (D = W X^T: rows = channels, columns = pixels), so
+    // acc[i][j][e] = pixel (tile row 2*wave + i, column lane & 31), channel j*32 + 8*(e>>2) + 4*khalf + (e&3):
+    // a lane holds 4 CONSECUTIVE channels of one pixel per register quad, which is what both epilogues want.
 
     CSTAMP(1 + nk);
+    if constexpr (EPI == 0) {
+        // ---- plain epilogue (bias, ReLU, bf16): every wave packs its own 64 pixels x WBN channels into a bf16 tile in LDS
+        // (8-byte writes of 4 channels), ONE barrier, then the workgroup streams the 256 pixel rows out in 16-byte pieces,
+        // rows contiguous across lanes.  One pass instead of four f32 passes through a single 64-row staging tile.
+        bf16_t* __restrict__ Cq = reinterpret_cast<bf16_t*>(p.C);
+        constexpr int BP = WBN * 2 + 16;                                // row pitch in bytes: 16-byte aligned, an odd number of 16-byte groups
+        char* bt = lxo_conv_lds;
+        const float floor_q = p.act == 1 ? 0.f : -3.0e38f;
+        LXO_LDS_BARRIER();                                              // every wave is past the patch and the weight stages
+        CSTAMP(40);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * k + e], floor_q);
+                    const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(bt + (wave * 64 + i * 32 + (lane & 31)) * BP + (j * 32 + 8 * k + 4 * khalf) * 2) = pk;
+                }
+        }
+        CSTAMP(41);
+        LXO_LDS_BARRIER();
+        CSTAMP(42);
+        constexpr int CHQ = WBN / 8, RPQ = 256 / CHQ;                   // 16-byte pieces per pixel row, rows per sweep
+        const int cq = tid % CHQ;
+        bf16_t* const tile0 = Cq + (((long long)b * p.Ho + oy0) * p.Wo + ox0) * p.ldc + n0 + cq * 8;      // 64-bit once; 32-bit offsets per row
+        u32x4 q4[256 / RPQ];
+#pragma unroll
+        for (int it = 0; it < 256 / RPQ; ++it) q4[it] = *reinterpret_cast<const u32x4*>(bt + (tid / CHQ + RPQ * it) * BP + cq * 16);
+#pragma unroll
+        for (int it = 0; it < 256 / RPQ; ++it) {
+            const int row = tid / CHQ + RPQ * it;                       // 0..255: tile row row >> 5, column row & 31
+            const int ty = row >> 5, tx = row & 31;
+            if (oy0 + ty < p.Ho && ox0 + tx < p.Wo) *reinterpret_cast<u32x4*>(tile0 + (ty * p.Wo + tx) * p.ldc) = q4[it];
+        }
+        CSTAMP(2 + nk);
+        return;
+    }
     // ---- epilogue: one wave's 64 pixels x WBN channels at a time through LDS as f32 [64][WBN + 4] ----
     bf16_t* __restrict__ C = reinterpret_cast<bf16_t*>(p.C);
     bf16_t* __restrict__ Cpre = reinterpret_cast<bf16_t*>(p.out_pre);
@@ -734,13 +785,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     float* ot = reinterpret_cast<float*>(lxo_conv_lds);
     constexpr int OP = WBN + 4, CH = 4 * NJ, RPI = 256 / CH;          // 16-byte chunks per row, rows per iteration
     const int c8 = (tid % CH) * 8, n = n0 + c8;
-    float bias8[8], csum[8];
-    {
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+    float csum[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bias8[e] = e < 4 ? b0[e] : b1[e - 4]; csum[e] = 0.f; }
-    }
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
     const float act_floor = p.act == 1 ? 0.f : -3.0e38f;
     for (int pass = 0; pass < 4; ++pass) {
         LXO_LDS_BARRIER();
@@ -751,8 +798,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        ot[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf) * OP + j * 32 + (lane & 31)] = acc[i][j][e];
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 q4 = {acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]};
+                        *reinterpret_cast<f32x4*>(&ot[(i * 32 + (lane & 31)) * OP + j * 32 + 8 * k + 4 * khalf]) = q4;
+                    }
         }
         LXO_LDS_BARRIER();
         CSTAMP(41 + 3 * pass);
@@ -793,8 +842,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         for (int it = 0; it < NIT; ++it) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)      // ReLU as a max against a wave-uniform floor: no per-element branches (act is 0 or 1 here; the launcher routes tanh elsewhere)
-                v[e] = fmaxf(p.alpha * (e < 4 ? t0[it][e] : t1[it][e - 4]) + bias8[e], act_floor);
+            for (int e = 0; e < 8; ++e)      // ReLU as a max against a wave-uniform floor: no per-element branches (act is 0 or 1 here; the launcher routes tanh elsewhere); the bias is already inside the accumulators
+                v[e] = fmaxf(e < 4 ? t0[it][e] : t1[it][e - 4], act_floor);
             if constexpr (HAS_ADD) {
                 if (Cpre && okr[it]) store8(Cpre + mrow[it] * p.ldc + n, v);
 #pragma unroll
@@ -860,7 +909,7 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
     static int use_2wg = -1;
     if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }
-    if (use_halo && use_2wg && (p.N % 64) == 0 && p.act != 2) {
+    if (use_halo && use_2wg && (p.N % 64) == 0 && p.act != 2 && p.alpha == 1.f) {
         constexpr int LDS4 = WPATCHB + 2 * 128 * CBK * 2, LDS2 = WPATCHB + 2 * 64 * CBK * 2;     // 77824, 61440
         if (attr_needed(0)) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));

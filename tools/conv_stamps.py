@@ -41,10 +41,7 @@ for name, h, w, ci, co in (("conv4 fwd", 32, 128, 256, 256), ("conv2 fwd", 64, 2
         g = gaps[:, pos::9].ravel()
         print("   K-step at tap %d                  median %7d  p10 %7d  p90 %7d" % (pos, np.median(g), np.percentile(g, 10), np.percentile(g, 90)))
     print("   epilogue                          median %7d  p10 %7d  p90 %7d" % (np.median(epi), np.percentile(epi, 10), np.percentile(epi, 90)))
-    names = ["barrier in", "tile in LDS", "rows stored"]
-    for ps in range(4):
-        for k in range(3):
-            col = 40 + 3 * ps + k
-            v = d[:, col] - d[:, nk + 1]
-            print("   epilogue pass %d %-12s  median %7d  (since K loop end)" % (ps, names[k], np.median(v)))
+    for col, nm in ((40, "all waves out of the K loop"), (41, "own bf16 tile written"), (42, "all tiles in LDS"), (nk + 2, "rows stored")):
+        v = d[:, col] - d[:, nk + 1]
+        print("   epilogue: %-28s median %7d  (since this wave left the K loop)" % (nm, np.median(v)))
     print("   whole tile                        median %7d   (32 MFMA x 32 cycles x %d K-steps = %d cycles of MFMA issue per wave)" % (np.median(tot), nk, 1024 * nk))
