@@ -319,30 +319,32 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
     float m = -3.0e38f, l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // Every load of the loop is UNCONDITIONAL (row and channel indices clamped into the chunk, the contribution of a clamped
+    // row or lane masked afterwards): with `if (r < n) load` hipcc branched around each load and put `s_waitcnt vmcnt(0)` behind
+    // it, so the 8 row loads of an iteration were 8 serial memory round trips instead of 8 requests in flight.
+    const int c0l = cok ? c0 : 0;                            // lanes beyond C re-read channel 0 (their accumulators are never stored)
     for (int base = wave; base < n; base += ATT_W * ATT_U) {
         float xi[ATT_U][8], pt[ATT_U];
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {                 // issue the img rows first: they are consumed last
-            const int r = base + ATT_W * u;
-            if (cok && r < n) load8(im + (long long)r * C + c0, xi[u]);
-            else { for (int e = 0; e < 8; ++e) xi[u][e] = 0.f; }
+            const int r = min(base + ATT_W * u, n - 1);
+            load8(im + (long long)r * C + c0l, xi[u]);
             pt[u] = 0.f;
         }
 #pragma unroll
         for (int kc = 0; kc < KCT; ++kc) {
             const int k0 = kc * 256 + lane * 4;
-            if (kc < KC && k0 < E) {
-                float x[ATT_U][4];
+            const bool kok = kc < KC && k0 < E;
+            const int k0l = kok ? k0 : 0;
+            float x[ATT_U][4];
 #pragma unroll
-                for (int u = 0; u < ATT_U; ++u) {
-                    const int r = base + ATT_W * u;
-                    if (r < n) load4(ai + (long long)r * E + k0, x[u]);
-                    else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f; }
-                }
+            for (int u = 0; u < ATT_U; ++u) load4(ai + (long long)min(base + ATT_W * u, n - 1) * E + k0l, x[u]);
 #pragma unroll
-                for (int u = 0; u < ATT_U; ++u)
+            for (int u = 0; u < ATT_U; ++u) {
+                float a = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pt[u] = fmaf(tanh_ct<CT>(x[u][j] + ah[kc][j]), bt[kc][j], pt[u]);
+                for (int j = 0; j < 4; ++j) a = fmaf(tanh_ct<CT>(x[u][j] + ah[kc][j]), bt[kc][j], a);
+                pt[u] += kok ? a : 0.f;                     // bt is zero for masked lanes anyway; keep NaN-free
             }
         }
 #pragma unroll
@@ -504,25 +506,23 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
             for (int j = 0; j < 4; ++j) ah[kc][j] = a4[j];
         }
     }
+    const int c0l = cok ? c0 : 0;                            // unconditional loads, as in the forward kernel
     for (int base = wave; base < n; base += ATT_W * ATT_U) {
         float xi[ATT_U][8], pt[ATT_U], al[ATT_U];
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
-            const int r = base + ATT_W * u;
-            if (cok && r < n) load8(im + (long long)r * C + c0, xi[u]);
-            else { for (int e = 0; e < 8; ++e) xi[u][e] = 0.f; }
-            al[u] = r < n ? alpha[(long long)v * Rp + r0 + r] : 0.f;
+            const int r = base + ATT_W * u, rc = min(r, n - 1);
+            load8(im + (long long)rc * C + c0l, xi[u]);
+            const float a = alpha[(long long)v * Rp + r0 + rc];
+            al[u] = r < n ? a : 0.f;                        // a clamped row contributes nothing: d = al * (...) = 0
         }
         float x[KCT][ATT_U][4];
 #pragma unroll
         for (int kc = 0; kc < KCT; ++kc) {
             const int k0 = kc * 256 + lane * 4;
+            const int k0l = (kc < KC && k0 < E) ? k0 : 0;
 #pragma unroll
-            for (int u = 0; u < ATT_U; ++u) {
-                const int r = base + ATT_W * u;
-                if (kc < KC && k0 < E && r < n) load4(ai + (long long)r * E + k0, x[kc][u]);
-                else { x[kc][u][0] = x[kc][u][1] = x[kc][u][2] = x[kc][u][3] = 0.f; }
-            }
+            for (int u = 0; u < ATT_U; ++u) load4(ai + (long long)min(base + ATT_W * u, n - 1) * E + k0l, x[kc][u]);
         }
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
