@@ -610,16 +610,12 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
             if (kc < KC && k0 < E) {
                 float a[4][4], d[4][4];
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {          // 4 time steps of loads in flight
-                    const int t = t0 + tt;
-                    if (t < T) {
-                        load4(att_h + ((long long)t * B + b) * E + k0, a[tt]);
+                for (int tt = 0; tt < 4; ++tt) {          // 4 time steps of loads in flight: unconditional (step clamped, d zeroed), or hipcc waits behind each
+                    const int t = t0 + tt, tc = min(t, T - 1);
+                    load4(att_h + ((long long)tc * B + b) * E + k0, a[tt]);
+                    f32x4 dq = *reinterpret_cast<const f32x4*>(de + ((long long)tc * B + b) * Rp + rbase);      // rbase % 4 == 0, Rp % 8 == 0: in bounds
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) d[tt][rr] = (rbase + rr < R) ? de[((long long)t * B + b) * Rp + rbase + rr] : 0.f;
-                    } else {
-                        a[tt][0] = a[tt][1] = a[tt][2] = a[tt][3] = 0.f;
-                        d[tt][0] = d[tt][1] = d[tt][2] = d[tt][3] = 0.f;
-                    }
+                    for (int rr = 0; rr < 4; ++rr) d[tt][rr] = (t < T && rbase + rr < R) ? dq[rr] : 0.f;
                 }
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {

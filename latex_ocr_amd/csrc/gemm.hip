@@ -22,24 +22,29 @@ template <typename CT> struct StageReg;
 template <> struct StageReg<bf16_t> { u32x4 v; };
 template <> struct StageReg<float> { f32x4 lo, hi; };
 
+// The load itself is UNCONDITIONAL (callers pass a valid address -- offset 0 of the operand -- for rows outside the
+// matrix) and the value is zeroed afterwards: `ok ? load : 0` made hipcc branch around every load and wait vmcnt(0) behind
+// it (260 such waits in one gemm_nt instantiation), which serialised the staging loads of a K-step.
 template <typename CT, typename TA>
 LXO_DEV StageReg<CT> stage_load(const TA* p, bool ok) {
     StageReg<CT> r;
     if constexpr (is_bf16<CT>::value) {
         if constexpr (is_bf16<TA>::value) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            r.v = ok ? *reinterpret_cast<const u32x4*>(p) : z;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+            r.v = ok ? v : z;
         } else {
             float v[8];
-            if (ok) load8(p, v);
-            else { for (int i = 0; i < 8; ++i) v[i] = 0.f; }
+            load8(p, v);
             u32x4 t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-            r.v = t;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            r.v = ok ? t : z;
         }
     } else {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        r.lo = ok ? *reinterpret_cast<const f32x4*>(p) : z;
-        r.hi = ok ? *reinterpret_cast<const f32x4*>(p + 4) : z;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+        r.lo = ok ? lo : z;
+        r.hi = ok ? hi : z;
     }
     return r;
 }
@@ -185,6 +190,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p) {
     OT* __restrict__ C = reinterpret_cast<OT*>(p.C);
     OT* __restrict__ Cpre = reinterpret_cast<OT*>(p.out_pre);
     const CT* __restrict__ ref = reinterpret_cast<const CT*>(p.relu_ref);
+    if (!Cpre && !p.addend && !ref && !p.accumulate && !p.colsum && p.act != 2) {
+        // plain product (+ bias, + ReLU): nothing is loaded inside the element loop, so the stores issue back to back
+        const float floor_v = p.act == 1 ? 0.f : -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            const bool n_ok = n < p.N;
+            const float bias = p.bias ? p.bias[n_ok ? n : 0] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (n_ok && m < p.M) C[(long long)m * p.ldc + n] = from_f32<OT>(fmaxf(p.alpha * acc[i][j][r] + bias, floor_v));
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
