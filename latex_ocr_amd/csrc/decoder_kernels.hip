@@ -413,12 +413,31 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
     const int cq = (C + 3) / 4, rq = (R + 3) / 4;
     const int c = qd * cq + tid, r = qd * rq + tid;           // cq, rq <= 256 for C <= 1024, R <= 1024 (else the loops below)
     const bool c_ok = tid < cq && c < C, r_ok = tid < rq && r < R;
-    float pcx[8], sraw = 0.f;
     const bool fast = nch <= 8 && cq <= 256 && rq <= 256;
     if (fast) {
+        // every operand is requested up front by UNCONDITIONAL loads (chunk index clamped, the clamped copies masked by a
+        // zero sum): conditional loads made hipcc wait behind each of them, one memory round trip per chunk statistic
+        const int cl = c_ok ? c : 0, rl = r_ok ? r : 0;
+        float pc8[8], m8[8], l8[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pcx[k] = (k < nch && c_ok) ? pv[(long long)k * (C + 2) + 2 + c] : 0.f;
-        if (r_ok) sraw = alpha[(long long)v * Rp + r];
+        for (int k = 0; k < 8; ++k) {
+            const long long o = (long long)min(k, nch - 1) * (C + 2);
+            m8[k] = pv[o]; l8[k] = pv[o + 1]; pc8[k] = pv[o + 2 + cl];
+        }
+        const float sraw = alpha[(long long)v * Rp + rl];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (k >= nch) l8[k] = 0.f; if (l8[k] > 0.f) m = fmaxf(m, m8[k]); }
+        float l = 0.f, t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float w = l8[k] > 0.f ? expf(m8[k] - m) : 0.f; l += l8[k] * w; t = fmaf(pc8[k], w, t); }
+        const float inv = 1.0f / l;
+        if (c_ok) {
+            ctx[(long long)v * ldctx + c] = t * inv;
+            if (ctxb) ctxb[(long long)v * ldcb + c] = f2bf(t * inv);      // bf16 mirror: A operand of the fused o projection
+        }
+        if (r_ok) alpha[(long long)v * Rp + r] = expf(sraw - m) * inv;
+        return;
     }
     float mc[32], lc[32];
     float m = -3.0e38f;
@@ -432,17 +451,6 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < 32; ++k) { mc[k] = lc[k] > 0.f ? expf(mc[k] - m) : 0.f; l += lc[k] * mc[k]; }
     const float inv = 1.0f / l;
-    if (fast) {
-        if (c_ok) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t = fmaf(pcx[k], mc[k], t);
-            ctx[(long long)v * ldctx + c] = t * inv;
-            if (ctxb) ctxb[(long long)v * ldcb + c] = f2bf(t * inv);      // bf16 mirror: A operand of the fused o projection
-        }
-        if (r_ok) alpha[(long long)v * Rp + r] = expf(sraw - m) * inv;
-        return;
-    }
     for (int cc = qd * cq + tid; cc < min(C, (qd + 1) * cq); cc += 256) {
         float t = 0.f;
         for (int k = 0; k < nch; ++k) t = fmaf(pv[(long long)k * (C + 2) + 2 + cc], mc[k], t);

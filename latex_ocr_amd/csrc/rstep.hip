@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void rstep_kernel(RStep p) {
         const int U = p.U;
         const float* gr = p.gates_in + (long long)mc * 4 * U + n;
         ld4(p.dhm + (long long)mc * p.lddhm + n, e0);
-        if (mc < p.carry_rows) ld4(p.carry_h + (long long)mc * U + n, e1); else { e1[0] = e1[1] = e1[2] = e1[3] = 0.f; }
+        ld4(p.carry_h + (long long)mc * U + n, e1);           // unconditional (the buffer always exists); rows without a carry are zeroed below
+        if (mc >= p.carry_rows) { e1[0] = e1[1] = e1[2] = e1[3] = 0.f; }
         ld4(gr, e2); ld4(gr + U, e3); ld4(gr + 2 * U, e4); ld4(gr + 3 * U, e5);
         ld4(p.c_cur + (long long)mc * U + n, e6); ld4(p.c_prev + (long long)mc * U + n, e7); ld4(p.dcc + (long long)mc * U + n, e8);
     } else if constexpr (EPI == RS_CARRY) {
