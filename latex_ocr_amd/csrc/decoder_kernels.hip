@@ -479,8 +479,43 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
     const CT* ai = att_img + ((long long)v * R + r0) * E;
     const CT* im = img + ((long long)v * R + r0) * C;
     constexpr int KC = KCT;
+    const int c0 = lane * 8;
+    const bool cok = c0 < C;
+    const int c0l = cok ? c0 : 0;                            // unconditional loads, as in the forward kernel
+    float s = 0.f, dc[8];
+    float ah[KCT][4], acc[KCT][4];
+    if (dcs.n == 1 && C <= 512) {
+        // d_ctx arrives as final values (fused step kernels): ONE round of loads -- this lane's 8 channels of d_ctx and ctx,
+        // its slice of att_h -- and every wave forms s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r by itself (its 64 lanes cover all
+        // C channels): no slab loop, no LDS reduction, no barrier, instead of four dependent memory round trips
+        const float* dp = dcs.p + (long long)v * dcs.ld + dcoff + c0l;
+        const float* cp = ctx + (long long)v * ldctx + c0l;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(cp), x1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        f32x4 a4[KCT];
+#pragma unroll
+        for (int kc = 0; kc < KCT; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            a4[kc] = *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + ((kc < KC && k0 < E) ? k0 : 0));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dc[e] = cok ? d0[e] : 0.f; dc[4 + e] = cok ? d1[e] : 0.f; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = fmaf(x0[e], dc[e], fmaf(x1[e], dc[4 + e], s));
+        s = wave_sum(s);
+#pragma unroll
+        for (int kc = 0; kc < KCT; ++kc) {
+            const int k0 = kc * 256 + lane * 4;
+            const bool kok = kc < KC && k0 < E;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ah[kc][j] = kok ? a4[kc][j] : 0.f; acc[kc][j] = 0.f; }
+        }
+        if (ch == 0 && dctx_out) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (cok) dctx_out[(long long)v * lddc + c0 + e] = dc[e];
+        }
+    } else {
     // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r
-    float s = 0.f;
     for (int c = tid; c < C; c += 512) {
         const float d = slab_sum(dcs, v, dcoff + c);
         if (ch == 0 && dctx_out) dctx_out[(long long)v * lddc + c] = d;          // summed d_ctx, kept for the deferred d_img GEMM
@@ -492,9 +527,6 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
     s = 0.f;
 #pragma unroll
     for (int w = 0; w < ATT_W; ++w) s += red[w];
-    const int c0 = lane * 8;
-    const bool cok = c0 < C;
-    float dc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) dc[e] = 0.f;
     if (cok) {
@@ -502,7 +534,6 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) { dc[e] = d0[e]; dc[4 + e] = d1[e]; }
     }
-    float ah[KCT][4], acc[KCT][4];
 #pragma unroll
     for (int kc = 0; kc < KCT; ++kc) {
         const int k0 = kc * 256 + lane * 4;
@@ -514,7 +545,7 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
             for (int j = 0; j < 4; ++j) ah[kc][j] = a4[j];
         }
     }
-    const int c0l = cok ? c0 : 0;                            // unconditional loads, as in the forward kernel
+    }
     for (int base = wave; base < n; base += ATT_W * ATT_U) {
         float xi[ATT_U][8], pt[ATT_U], al[ATT_U];
 #pragma unroll
@@ -1044,7 +1075,9 @@ int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, Drop dr, int rows, int cols
 }
 static int att_u() {
     static int u = -1;
-    if (u < 0) { const char* e = getenv("LXO_ATT_U"); u = (e && atoi(e) == 8) ? 8 : 4; }
+    // rows of both streams a wave keeps in flight per iteration.  8 since the row loads are unconditional (one request burst per
+    // iteration); 4 was faster only while hipcc serialised the conditional loads.  LXO_ATT_U=4 selects the old instantiation.
+    if (u < 0) { const char* e = getenv("LXO_ATT_U"); u = (e && atoi(e) == 4) ? 4 : 8; }
     return u;
 }
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
