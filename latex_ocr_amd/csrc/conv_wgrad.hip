@@ -110,11 +110,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     const int doff_a = WPATCH + bl * 256 + ((b_chunk ^ (bl & 15)) << 4) + b_sub;
     const int doff_b = WPATCH + (bl + 4) * 256 + ((b_chunk ^ ((bl + 4) & 15)) << 4) + b_sub;
 
+#define WSTAMP(i) do { if (p.dbg && tid == 0 && (i) < 64) p.dbg[(long long)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+    WSTAMP(0);
     issue(pb_beg, 0);
     for (int pb = pb_beg; pb < pb_end; ++pb) {
         const int stage = (pb - pb_beg) & 1;
+        WSTAMP(1 + 3 * (pb - pb_beg));
         __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): only this block's loads are outstanding here
+        WSTAMP(2 + 3 * (pb - pb_beg));
         __builtin_amdgcn_s_barrier();
+        WSTAMP(3 + 3 * (pb - pb_beg));
         if (pb + 1 < pb_end) issue(pb + 1, stage ^ 1);
         const char* sb = lxo_wgrad_lds + stage * WSTAGE;
         const char* pk[8];
@@ -122,28 +127,35 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
         for (int k = 0; k < 8; ++k) pk[k] = sb + poff[k];
         const char* da = sb + doff_a;
         const char* db = sb + doff_b;
+        // One K-step of raw operands (2 d_out reads + 9 patch reads = 22 dwords) is read AHEAD: the reads of K-step ks + 1 are
+        // issued before the MFMAs of K-step ks, so the LDS latency hides under 288 cycles of matrix work instead of stalling
+        // every K-step (SQ_WAIT_ANY was 31 % with the reads and the MFMAs of a K-step back to back).
+        u32x2 rb[2][2], rd[2][9];
+        auto read_ks = [&](int ks, u32x2 (&b2)[2], u32x2 (&d9)[9]) {
+            const int ty = ks >> 2, xc = (ks & 3) * 16;
+            const int cd = (ty * 64 + xc) * 256;
+            b2[0] = tr_read(da + cd);
+            b2[1] = tr_read(db + cd);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {                   // 16 pixels per K-step: row ty = ks>>2, x = (ks&3)*16 + 8h ..
-            constexpr int dummy = 0; (void)dummy;
-            const int ty = ks >> 2, xc = (ks & 3) * 16;     // compile-time after unrolling
-            // B operand: d_out pixels k0..k0+7 of this lane's channel
-            u32x4 bfr;
-            {
-                const int cd = (ty * 64 + xc) * 256;
-                const u32x2 lo = tr_read(da + cd);
-                const u32x2 hi = tr_read(db + cd);
-                bfr = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                // patch row ty + kh, pixels xk .. xk+11 -> three reads, six dwords of pixel pairs
-                unsigned d[6];
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int q3 = 0; q3 < 3; ++q3) {
                     const int cc = (ty + kh) * WPW + xc + 4 * q3;        // even, compile-time
-                    const u32x2 v = tr_read(pk[(cc >> 1) & 7] + cc * 128);
-                    d[2 * q3] = v[0]; d[2 * q3 + 1] = v[1];
+                    d9[kh * 3 + q3] = tr_read(pk[(cc >> 1) & 7] + cc * 128);
                 }
+        };
+        read_ks(0, rb[0], rd[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {                   // 16 pixels per K-step: row ty = ks>>2, x = (ks&3)*16 + 8h ..
+            const int cur = ks & 1;                          // compile-time after unrolling
+            if (ks + 1 < 8) read_ks(ks + 1, rb[cur ^ 1], rd[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);              // reads of ks + 1 stay ahead of the MFMAs of ks; nothing is hoisted further (144 accumulator registers)
+            const u32x4 bfr = {rb[cur][0][0], rb[cur][0][1], rb[cur][1][0], rb[cur][1][1]};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                // patch row ty + kh, pixels xk .. xk+11: six dwords of pixel pairs
+                const unsigned d[6] = {rd[cur][kh * 3][0], rd[cur][kh * 3][1], rd[cur][kh * 3 + 1][0], rd[cur][kh * 3 + 1][1],
+                                       rd[cur][kh * 3 + 2][0], rd[cur][kh * 3 + 2][1]};
                 const u32x4 a0 = {d[0], d[1], d[2], d[3]};
                 const u32x4 a1 = {__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
                                   __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16)};
@@ -152,9 +164,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
                 acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 1], 0, 0, 0);
                 acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 2], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);              // 144 accumulator registers: keep the reads of later K-steps from being hoisted (spills)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    WSTAMP(61);
     // reduce into dW[(tap*Cin + ci)][co]
     const int co = co0 + wco * 32 + (lane & 31);
     if (co < Cout) {
@@ -166,11 +179,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
                 if (ci < p.Cin) atomicAdd(&p.C[((long long)t * p.Cin + ci) * p.ldc + co], acc[t][e]);
             }
     }
+    WSTAMP(62);
 }
 
 }  // namespace
 
 // bf16 only; Cin % 64 == 0, Cout % 8 == 0
+static thread_local unsigned long long* g_wgrad_dbg = nullptr;
+extern "C" int lxo_wgrad_debug(unsigned long long* buf) { g_wgrad_dbg = buf; return 0; }
 int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.J % 8) return -2;
     {   // per device, not per process (see conv_igemm.hip attr_needed)
@@ -193,6 +209,7 @@ int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     nsplit = cdiv(nblocks, per_split);
     GemmTN q = p;
     q.nbatch = tiles;
+    q.dbg = g_wgrad_dbg;
     // splits are dealt to the 8 XCDs in turn: round the split count up to a multiple of 8 (empty ranges return at once)
     const int nsplit8 = (nsplit + 7) / 8 * 8;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * nsplit8), dim3(WTHREADS), 2 * WSTAGE, s, q, tiles_co, tiles_x, tiles_y, nblocks, per_split);

@@ -35,6 +35,7 @@ struct GemmTN {
     int nsplit, nbatch;
     long long strideA, strideB, strideC;
     int atomic;                // 1: atomicAdd into C (C pre-initialised); 0: plain store (nsplit must be 1)
+    unsigned long long* dbg;   // measurement aid (null = off): conv_wgrad_kernel stamps its pixel blocks here, [workgroup][64] (tools/conv_stamps.py)
 };
 
 // dt: LXO_F32 / LXO_BF16 = compute type (type of Bp / conv tensors);
