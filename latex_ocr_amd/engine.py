@@ -70,8 +70,10 @@ class Engine(object):
         ywo = self._offsets["Decoder/AttentionCell/rnn/y_W_o"][0]        # the last variable: final before the recurrence runs
         self.buckets = [(ywo, self.n_params), (first_dec, ywo), (c5, first_dec), (0, c5)]
         # optional second stream for the half-batch interleave of the recurrent loop (LXO_DUAL_STREAM=1).
-        # Measured slower than one stream in round 1 (18.8 vs 17.3 ms/step: twice the launches make the
-        # eager host loop the bottleneck), so it is off by default until the loop is graph-captured.
+        # Measured slower than one stream in round 1 (18.8 vs 17.3 ms/step).  Round 2 measured why (tools/loop_probe.py,
+        # DESIGN.md "launch cost"): the loop is bound by the device-side dependent-launch boundary, not by the host, and
+        # two half-batch chains double the boundaries while each launch keeps its fixed cost; the interleave also forces
+        # the round-1 split-K step kernels.  Off by default, kept as an A/B switch.
         self.side_stream = None
         if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "0") == "1":
             self.side_stream = torch.cuda.Stream(self.device)

@@ -18,6 +18,15 @@ case $what in
   ktests)   timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q -x > gpurun_out/${TAG}_ktests.log 2>&1; echo "ktests rc=$?"; tail -4 gpurun_out/${TAG}_ktests.log;;
   benchq)   timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"; python tools/bench_brief.py gpurun_out/${TAG}_bench.log;;
   benchold) LXO_STEP_KERNELS=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_benchold.log 2>&1; echo "benchold rc=$?"; tail -1 gpurun_out/${TAG}_benchold.log | cut -c1-300;;
+  wstamps)  timeout 300 python tools/wgrad_stamps.py > gpurun_out/${TAG}_wgrad_stamps.log 2>&1; echo "wstamps rc=$?"; tail -12 gpurun_out/${TAG}_wgrad_stamps.log;;
+  traffic)  cd /tmp && export TMPDIR=/tmp
+            for CNT in FETCH_SIZE WRITE_SIZE; do
+              (timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $R/gpurun_out/${TAG}_pmc_$CNT -- python $R/tools/pmc_conv.py > $R/gpurun_out/${TAG}_pmc_$CNT.log 2>&1; echo "pmc $CNT rc=$?")
+            done
+            cd $R
+            F=$(ls gpurun_out/${TAG}_pmc_FETCH_SIZE/*/*_results.db | head -1); Wd=$(ls gpurun_out/${TAG}_pmc_WRITE_SIZE/*/*_results.db | head -1)
+            python tools/pmc_traffic.py $F $Wd gpurun_out/${TAG}_conv_traffic.json conv_halo2wg_kernel; cat gpurun_out/${TAG}_conv_traffic.json | cut -c1-600
+            rm -rf gpurun_out/${TAG}_pmc_FETCH_SIZE gpurun_out/${TAG}_pmc_WRITE_SIZE;;
   *) echo "unknown $what";;
 esac
 done
