@@ -139,7 +139,9 @@ int lxo_pack_weights(const lxo_shape* s, const float* params, void* wpack, void*
 int lxo_encoder_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                     const uint8_t* img, void* stream);
 /* backward of conv layers last_layer..first_layer (6..1), accumulating into grads;
- * layer 6 consumes ws region "d_img".  Split so a data-parallel caller can
+ * layer 6 consumes ws region "d_img" (f32 mode: the f32 gradient w.r.t. the encoder output; bf16 mode: d_y6, i.e. that
+ * gradient with conv6's ReLU mask applied, in bf16 -- the decoder's last GEMM applies the mask and sums conv6's bias
+ * gradient in its epilogue, see lxo_decoder_train_bwd).  Split so a data-parallel caller can
  * all-reduce finished buckets while earlier layers still run. */
 int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                     const uint8_t* img, float* grads, int last_layer, int first_layer, void* stream);
@@ -178,7 +180,8 @@ int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula,
 int lxo_ce_loss_fwd_bwd_dev(const lxo_shape* s, void* ws, const int32_t* formula,
                             const int32_t* lengths, const float* ntok_dev, void* stream);
 /* BPTT through the decoder (what TF autodiff does for img2seq.py:119-123);
- * accumulates decoder gradients into grads and leaves d(enc) in ws region "d_img". */
+ * accumulates decoder gradients into grads and leaves d(enc) in ws region "d_img" (bf16 mode: already masked by conv6's
+ * ReLU and converted, with conv6's bias gradient added to grads; f32 mode: the plain f32 gradient). */
 int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                           const int32_t* formula, float* grads, void* stream);
 /* The same in two parts so that a data-parallel caller can start reducing gradients before the recurrence has run:

@@ -351,29 +351,33 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
             if constexpr (BF) {
                 if constexpr (is_bf16<TA>::value) {
                     const u32x4 z = {0u, 0u, 0u, 0u};
-                    const u32x4 r0 = aok[0] ? *reinterpret_cast<const u32x4*>(ap[0]) : z;
-                    const u32x4 r1 = aok[1] ? *reinterpret_cast<const u32x4*>(ap[1]) : z;
+                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(ap[0]), l1 = *reinterpret_cast<const u32x4*>(ap[1]);   // unconditional: see stage_load
+                    const u32x4 r0 = aok[0] ? l0 : z, r1 = aok[1] ? l1 : z;
                     pack_rows(r0, r1, pa[q]);
                 } else {
                     float r0[8], r1[8];
-                    if (aok[0]) load8(ap[0], r0); else { for (int e = 0; e < 8; ++e) r0[e] = 0.f; }
-                    if (aok[1]) load8(ap[1], r1); else { for (int e = 0; e < 8; ++e) r1[e] = 0.f; }
+                    load8(ap[0], r0); load8(ap[1], r1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { r0[e] = aok[0] ? r0[e] : 0.f; r1[e] = aok[1] ? r1[e] : 0.f; }
                     pack_rows(r0, r1, pa[q]);
                 }
                 if constexpr (is_bf16<TB>::value) {
                     const u32x4 z = {0u, 0u, 0u, 0u};
-                    const u32x4 r0 = bok[0] ? *reinterpret_cast<const u32x4*>(bq[0]) : z;
-                    const u32x4 r1 = bok[1] ? *reinterpret_cast<const u32x4*>(bq[1]) : z;
+                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(bq[0]), l1 = *reinterpret_cast<const u32x4*>(bq[1]);
+                    const u32x4 r0 = bok[0] ? l0 : z, r1 = bok[1] ? l1 : z;
                     pack_rows(r0, r1, pb[q]);
                 } else {
                     float r0[8], r1[8];
-                    if (bok[0]) load8(bq[0], r0); else { for (int e = 0; e < 8; ++e) r0[e] = 0.f; }
-                    if (bok[1]) load8(bq[1], r1); else { for (int e = 0; e < 8; ++e) r1[e] = 0.f; }
+                    load8(bq[0], r0); load8(bq[1], r1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { r0[e] = bok[0] ? r0[e] : 0.f; r1[e] = bok[1] ? r1[e] : 0.f; }
                     pack_rows(r0, r1, pb[q]);
                 }
             } else {
-                if (aok[0]) load8(reinterpret_cast<const float*>(ap[0]), fa[q]); else { for (int e = 0; e < 8; ++e) fa[q][e] = 0.f; }
-                if (bok[0]) load8(reinterpret_cast<const float*>(bq[0]), fb[q]); else { for (int e = 0; e < 8; ++e) fb[q][e] = 0.f; }
+                load8(reinterpret_cast<const float*>(ap[0]), fa[q]);
+                load8(reinterpret_cast<const float*>(bq[0]), fb[q]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { fa[q][e] = aok[0] ? fa[q][e] : 0.f; fb[q][e] = bok[0] ? fb[q][e] : 0.f; }
             }
         }
     };

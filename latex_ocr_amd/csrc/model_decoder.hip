@@ -6,6 +6,7 @@
 #include "gemm.h"
 #include "decoder_kernels.h"
 #include "rstep.h"
+#include "dimg.h"
 #include "api_util.h"
 #include "timing.h"
 
@@ -383,17 +384,31 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(nt(P, true, true, true, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, 0, true, st));
     // ---- d_img = sum_t alpha_t (x) d_ctx_t  (batched over samples)  + d_mean / R + d_att_img W_att_img^T ----
     float* dimg = P.ws<float>(ws, W_DIMG);
-    {
-        GemmTN g; memset(&g, 0, sizeof(g));
-        g.A = alpha; g.B = dhc + U; g.C = dimg; g.M = T; g.I = P.R; g.J = C;
-        g.lda = B * P.Rp; g.ldb = B * P.HC; g.ldc = C;
-        g.nsplit = 1; g.nbatch = B; g.strideA = P.Rp; g.strideB = P.HC; g.strideC = (long long)P.R * C; g.atomic = 0;
-        RC(lxo_launch_gemm_tn(P.s.dtype, 1, 1, g, st));
+    if (P.dimg_masked()) {
+        // one batched GEMM contracts both products, adds the mean gradient and applies conv6's ReLU mask + bias-gradient sum
+        // in its epilogue (dimg.hip): region "d_img" receives d_y6 in the compute dtype, lxo_encoder_bwd skips its mask pass
+        RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
+                          T, B, P.R, P.Rp, E, st));
+        DimgArgs a; memset(&a, 0, sizeof(a));
+        a.alpha = alpha; a.ld_alpha = (long long)B * P.Rp; a.Rp = P.Rp;
+        a.dctx = dhc + U; a.ld_dctx = (long long)B * P.HC; a.HC = P.HC;
+        a.datt = P.ws<bf16_t>(ws, W_DATTIMG); a.W = (const bf16_t*)P.pk(wp, K_ATT_IMG); a.ldw = E;
+        a.dmean = dmean; a.T = T; a.B = B; a.R = P.R; a.C = C; a.E = E;
+        a.y6 = P.ws<bf16_t>(ws, W_Y6); a.dy6 = P.ws<bf16_t>(ws, W_DIMG); a.db = gw(P_CONV6_B);
+        RC(lxo_launch_dimg_fused(a, st));
+    } else {
+        {
+            GemmTN g; memset(&g, 0, sizeof(g));
+            g.A = alpha; g.B = dhc + U; g.C = dimg; g.M = T; g.I = P.R; g.J = C;
+            g.lda = B * P.Rp; g.ldb = B * P.HC; g.ldc = C;
+            g.nsplit = 1; g.nbatch = B; g.strideA = P.Rp; g.strideB = P.HC; g.strideC = (long long)P.R * C; g.atomic = 0;
+            RC(lxo_launch_gemm_tn(P.s.dtype, 1, 1, g, st));
+        }
+        RC(lxo_k_add_mean_grad(dimg, dmean, B, P.R, C, st));
+        RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
+                          T, B, P.R, P.Rp, E, st));
+        RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     }
-    RC(lxo_k_add_mean_grad(dimg, dmean, B, P.R, C, st));
-    RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
-                      T, B, P.R, P.Rp, E, st));
-    RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, st));
     return 0;
 }

@@ -181,11 +181,12 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         return 0;
     };
     // weight gradient of a layer whose d_y sits in buffer xi (just produced on the main stream)
-    auto wgrad = [&](const void* in, int xi, float* dw, int H, int W, int Cin, int Cout, bool valid) -> int {
-        if (!side) return conv_wgrad(P, in, G[xi], dw, H, W, Cin, Cout, valid, st);
+    auto wgrad = [&](const void* in, int xi, float* dw, int H, int W, int Cin, int Cout, bool valid, const void* dy_at = nullptr) -> int {
+        const void* dy = dy_at ? dy_at : G[xi];
+        if (!side) return conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, st);
         HIPRC(hipEventRecord(g_ev_x, st));
         HIPRC(hipStreamWaitEvent(side, g_ev_x, 0));
-        RC(conv_wgrad(P, in, G[xi], dw, H, W, Cin, Cout, valid, side));
+        RC(conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, side));
         HIPRC(hipEventRecord(g_ev_free[xi], side));
         pending[xi] = true;
         return 0;
@@ -196,6 +197,13 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         void* const Yup = l <= 5 ? G[YB[l + 1]] : nullptr;      // gradient handed down by the layer above
         switch (l) {
         case 6:   // d_y6 = d_img * (y6>0) -> X ; wgrad6 ; d_p5 = dgrad6 -> Y
+            if (P.dimg_masked()) {        // the decoder left d_y6 (masked, compute dtype) in "d_img" and summed the bias gradient
+                const void* dy6 = P.ws<void>(ws, W_DIMG);
+                RC(wgrad(P.ws<void>(ws, W_P5), XB[6], gw(P_CONV6_W), P.H6, P.W5, C, C, true, dy6));
+                RC(acquire(YB[6]));
+                RC(conv_dgrad(P, dy6, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, st));
+                break;
+            }
             RC(acquire(XB[6]));
             RC(lxo_k_mask_convert(dt, P.ws<float>(ws, W_DIMG), P.ws<void>(ws, W_Y6), X, gw(P_CONV6_B), (long long)B * P.R, C, st));
             RC(wgrad(P.ws<void>(ws, W_P5), XB[6], gw(P_CONV6_W), P.H6, P.W5, C, C, true));

@@ -78,6 +78,9 @@ struct Plan {
     // chunks the R regions are split into for the attention stream, for nv decoder rows
     int attn_chunks(int nv) const;
 
+    // bf16 mode: the decoder's d_img GEMM (dimg.hip) applies conv6's ReLU mask and bias-gradient sum in its epilogue and
+    // leaves d_y6 (compute dtype) in ws region "d_img"; otherwise the region holds the f32 gradient w.r.t. the encoder output
+    bool dimg_masked() const { return bf && s.E % 32 == 0; }
     template <class T> T* ws(void* base, WsId id) const { return reinterpret_cast<T*>(static_cast<char*>(base) + woff[id]); }
     const void* pk(const void* base, PackId id) const { return static_cast<const char*>(base) + koff[id]; }
     void* pk(void* base, PackId id) const { return static_cast<char*>(base) + koff[id]; }
