@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void dimg_fused_kernel(DimgArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     tw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TP + j * 32 + (lane & 31)] = acc[i][j][r] + dm[j];
+            __builtin_amdgcn_wave_barrier();                         // the wave's 64 lanes exchange through tw (in-order LDS: no s_barrier)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = rbase + tr + 8 * k;
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void dimg_fused_kernel(DimgArgs p) {
                 for (int e = 0; e < 8; ++e) cs[e] += v[e];
                 if (ok) store8(p.dy6 + ((long long)b * p.R + row) * p.C + cbase, v);
             }
+            __builtin_amdgcn_wave_barrier();
         }
         // bias gradient: the 8 lanes of equal (lane & 7) hold the same 8 columns
 #pragma unroll
