@@ -195,7 +195,7 @@ extern "C" int lxo_attention_fwd(int dt, const void* att_img, const void* img, c
     const int need = (R + 1023) / 1024; if (nch < need) nch = need;
     Slabs none = {nullptr, 0, 0, 0};
     CHECK_LAUNCH(lxo_k_attn_fwd(dt, att_img, img, att_h, none, nullptr, beta, alpha, part, ctx, ldctx, nullptr, 0, nv, R, (R + 7) / 8 * 8, E, C, beam < 1 ? 1 : beam,
-                                nch, (hipStream_t)stream), "lxo_attention_fwd");
+                                nch, 0, (hipStream_t)stream), "lxo_attention_fwd");
     return 0;
 }
 

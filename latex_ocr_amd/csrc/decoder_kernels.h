@@ -19,10 +19,10 @@ int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo
 int lxo_k_slab_reduce(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st);
 int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, Drop dr, int rows, int cols, hipStream_t st);
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
-                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st);   // ctxb (nullable): bf16 copy of ctx, pitch ldcb
+                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, int rev, hipStream_t st);   // ctxb (nullable): bf16 copy of ctx, pitch ldcb
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
                    Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
-                   int nv, int R, int Rp, int E, int C, int nch, hipStream_t st);
+                   int nv, int R, int Rp, int E, int C, int nch, int rev, hipStream_t st);
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
                    int T, int B, int R, int Rp, int E, hipStream_t st);
 int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st);

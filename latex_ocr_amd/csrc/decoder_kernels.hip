@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
                                                            const float* __restrict__ att_h, Slabs ahs, float* __restrict__ att_h_out,
                                                            const float* __restrict__ beta,
                                                            float* __restrict__ alpha, float* __restrict__ part,
-                                                           int R, int Rp, int E, int C, int beam, int nch, int rows_per) {
+                                                           int R, int Rp, int E, int C, int beam, int nch, int rows_per, int rev) {
     __shared__ float redc[ATT_W][512];
     __shared__ float red[2 * ATT_W];
     const int ch = blockIdx.x, v = blockIdx.y, bi = v / beam;
@@ -323,7 +323,12 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
     // row or lane masked afterwards): with `if (r < n) load` hipcc branched around each load and put `s_waitcnt vmcnt(0)` behind
     // it, so the 8 row loads of an iteration were 8 serial memory round trips instead of 8 requests in flight.
     const int c0l = cok ? c0 : 0;                            // lanes beyond C re-read channel 0 (their accumulators are never stored)
-    for (int base = wave; base < n; base += ATT_W * ATT_U) {
+    // rev: walk the chunk's row blocks last to first.  The streams are re-read by every step of the recurrence with the same
+    // workgroup -> XCD mapping, 10.6 MB per XCD through a 4 MB L2: read in the same order every time, LRU keeps nothing; with
+    // the direction alternating from step to step, the blocks a launch read last are the ones the next launch reads first.
+    const int nit = n > wave ? (n - wave + ATT_W * ATT_U - 1) / (ATT_W * ATT_U) : 0;
+    for (int it = 0; it < nit; ++it) {
+        const int base = wave + ATT_W * ATT_U * (rev ? nit - 1 - it : it);
         float xi[ATT_U][8], pt[ATT_U];
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {                 // issue the img rows first: they are consumed last
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
                                                            const float* __restrict__ alpha, Slabs dcs, int dcoff, float* __restrict__ dctx_out, int lddc,
                                                            const float* __restrict__ ctx, int ldctx,
                                                            float* __restrict__ de, float* __restrict__ datth,
-                                                           int R, int Rp, int E, int C, int rows_per) {
+                                                           int R, int Rp, int E, int C, int rows_per, int rev) {
     __shared__ float rede[ATT_W][1024];
     __shared__ float red[ATT_W];
     const int ch = blockIdx.x, v = blockIdx.y;
@@ -546,7 +551,9 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
         }
     }
     }
-    for (int base = wave; base < n; base += ATT_W * ATT_U) {
+    const int nit = n > wave ? (n - wave + ATT_W * ATT_U - 1) / (ATT_W * ATT_U) : 0;
+    for (int it = 0; it < nit; ++it) {
+        const int base = wave + ATT_W * ATT_U * (rev ? nit - 1 - it : it);       // see attn_fwd_part_kernel
         float xi[ATT_U][8], pt[ATT_U], al[ATT_U];
 #pragma unroll
         for (int u = 0; u < ATT_U; ++u) {
@@ -640,7 +647,12 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
 #pragma unroll
             for (int j = 0; j < 4; ++j) { x[rr][kc][j] = 0.f; acc[rr][kc][j] = 0.f; }
             if (rbase + rr < R && kc < KC && k0 < E) load4(att_img + ((long long)b * R + rbase + rr) * E + k0, x[rr][kc]);
+            if constexpr (is_bf16<CT>::value) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[rr][kc][j] *= 2.8853900817779268f;
+            }
         }
+    float sumd = 0.f;                                     // bf16 path: sum of d over the steps and the wave's regions
     if (rbase < R)
     for (int t0 = 0; t0 < T; t0 += 4) {
 #pragma unroll
@@ -655,6 +667,10 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
                     f32x4 dq = *reinterpret_cast<const f32x4*>(de + ((long long)tc * B + b) * Rp + rbase);      // rbase % 4 == 0, Rp % 8 == 0: in bounds
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) d[tt][rr] = (t < T && rbase + rr < R) ? dq[rr] : 0.f;
+                    if constexpr (is_bf16<CT>::value) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[tt][j] *= 2.8853900817779268f;
+                    }
                 }
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
@@ -665,13 +681,26 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
                     for (int rr = 0; rr < 4; ++rr) {
                         const float dd = d[tt][rr];
                         if constexpr (is_bf16<CT>::value) {
-                            // with r = 1 / (1 + e^{2s}):  tau = 1 - 2r,  1 - tau^2 = 4 r (1 - r)
-                            const float d4 = 4.f * dd;
+                            // with r = 1 / (1 + e^{2s}):  tau = 1 - 2r,  1 - tau^2 = 4 r (1 - r).  The kernel is VALU-bound
+                            // (1.4 G tanh per launch), so everything around the two transcendentals is pared down: x and
+                            // att_h arrive pre-scaled by 2 log2 e (x once, att_h once per step for all four regions), the
+                            // element pairs run on the packed-f32 ALU (v_pk_add / v_pk_fma), and
+                            // d_beta = sum d - 2 sum d r keeps only the r-part per element
+                            const f32x2 d4 = {4.f * dd, 4.f * dd}, d2 = {dd, dd}, one = {1.f, 1.f};
+                            sumd += dd;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f((x[rr][kc][j] + a[tt][j]) * 2.8853900817779268f) + 1.f);
-                                acc[rr][kc][j] = fmaf(d4, fmaf(-r, r, r), acc[rr][kc][j]);
-                                db[kc][j] = fmaf(dd, fmaf(-2.f, r, 1.f), db[kc][j]);
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x2 xs = {x[rr][kc][2 * h], x[rr][kc][2 * h + 1]}, as = {a[tt][2 * h], a[tt][2 * h + 1]};
+                                const f32x2 y = xs + as;
+                                const f32x2 u = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+                                const f32x2 w = u + one;
+                                const f32x2 r = {__builtin_amdgcn_rcpf(w[0]), __builtin_amdgcn_rcpf(w[1])};
+                                const f32x2 q = __builtin_elementwise_fma(-r, r, r);
+                                f32x2 ac = {acc[rr][kc][2 * h], acc[rr][kc][2 * h + 1]}, dv = {db[kc][2 * h], db[kc][2 * h + 1]};
+                                ac = __builtin_elementwise_fma(d4, q, ac);
+                                dv = __builtin_elementwise_fma(d2, r, dv);
+                                acc[rr][kc][2 * h] = ac[0]; acc[rr][kc][2 * h + 1] = ac[1];
+                                db[kc][2 * h] = dv[0]; db[kc][2 * h + 1] = dv[1];
                             }
                         } else {
 #pragma unroll
@@ -703,7 +732,7 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
         const int k0 = kc * 256 + lane * 4;
         if (kc < KC && k0 < E) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) redb[wave][k0 + j] = db[kc][j];
+            for (int j = 0; j < 4; ++j) redb[wave][k0 + j] = is_bf16<CT>::value ? sumd - 2.f * db[kc][j] : db[kc][j];
         }
     }
     __syncthreads();
@@ -1081,11 +1110,11 @@ static int att_u() {
     return u;
 }
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
-                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, hipStream_t st) {
+                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, int rev, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     dim3 grid(nch, nv);
-#define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per
+#define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per, rev
     if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
         else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
@@ -1100,11 +1129,11 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
 // datth must be zero on entry (chunks accumulate with atomics)
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
                    Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
-                   int nv, int R, int Rp, int E, int C, int nch, hipStream_t st) {
+                   int nv, int R, int Rp, int E, int C, int nch, int rev, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     dim3 grid(nch, nv);
-#define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per
+#define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per, rev
     if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
         else { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }

@@ -43,6 +43,12 @@ Slabs view(const float* p, int K, int M, int N) { Slabs s = {p, K / 128, (long l
 const Slabs kNoSlabs = {nullptr, 0, 0, 0};
 }  // namespace
 
+// the attention kernels walk their row blocks in alternating directions from step to step (L2 reuse; LXO_ATT_ALT=0: always forward)
+static bool att_alternate() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LXO_ATT_ALT"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v == 1;
+}
 // att_img projection + initial states (attention_mechanism.py:19-43, 124-153; attention_cell.py:51-56)
 // nv = number of decoder rows (B for training/greedy, B*beam for beam search; rows v use image v / beam).
 static int attention_prepare(const Plan& P, const float* prm, const void* wp, void* ws, int beam, hipStream_t st) {
@@ -114,7 +120,7 @@ static int cell_step(const Plan& P, const float* prm, const void* wp, void* ws, 
     RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_ATT_H_T), P.ldAHT, s2, nr, E, U, st));
     RC(lxo_k_attn_fwd(P.s.dtype, att_img, img, nullptr, view(s2, U, nr, E), atth_t,
                       prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.OFF_CTX, P.REC, nullptr, 0, nr, P.R, P.Rp, E, C, beam,
-                      P.attn_chunks(nr), st));
+                      P.attn_chunks(nr), 0, st));
     // o = tanh([h, ctx] [o_W_h; o_W_c])           (attention_cell.py:82)
     RC(slab(P, rec_cur + P.OFF_HT, P.REC, P.pk(wp, K_OW_T), P.ldOWT, s4, nr, O, P.HC, st));
     RC(lxo_k_tanh_finalize(view(s4, P.HC, nr, O), rec_cur, P.REC, dr, nr, O, st));
@@ -157,7 +163,7 @@ static int cell_step_fused(const Plan& P, const float* prm, const void* wp, void
     LxoTimed tm("attn_fwd", "part+combine", (double)nr * P.R * (E + C) * P.esz, st);
     RC(lxo_k_attn_fwd(P.s.dtype, att_img, img, atth_t, kNoSlabs, nullptr,
                       prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.OFF_CTX, P.REC, bf ? recb_cur + P.OFF_CTX : nullptr, P.RECB, nr, P.R, P.Rp, E, C, beam,
-                      P.attn_chunks(nr), st));
+                      P.attn_chunks(nr), att_alternate() ? (dr.t & 1) : 0, st));
     }
     // o = dropout(tanh([h~, ctx] [o_W_h; o_W_c]))                  (attention_cell.py:82-83)
     RStep k4 = a;
@@ -290,7 +296,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             LxoTimed tm("attn_bwd", "part", (double)B * P.R * (E + C) * P.esz, st);
             RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + (size_t)t * B * E, prm + P.poff[P_BETA],
                               alpha + (size_t)t * B * P.Rp, dc1, U, nullptr, P.HC, rec_cur + P.OFF_CTX, P.REC,
-                              de + (size_t)t * B * P.Rp, datth_t, B, P.R, P.Rp, E, C, nchb, st));
+                              de + (size_t)t * B * P.Rp, datth_t, B, P.R, P.Rp, E, C, nchb, att_alternate() ? (t & 1) : 0, st));
             }
             // d_h = (d_h~(o projection) + d_att_h W_att_h^T) * mask + carry -> d_z, d_c
             RStep b3 = a;
@@ -340,7 +346,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             RC(slab(P, g_t, O, P.pk(wp, K_OW), P.ldOW, sb1, hb, P.HC, O, sh));
             RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + ((size_t)t * B + r0) * E, prm + P.poff[P_BETA],
                               alpha + ((size_t)t * B + r0) * P.Rp, view(sb1, O, hb, P.HC), U, dhc_t + U, P.HC, rec_cur + P.OFF_CTX, P.REC,
-                              de + ((size_t)t * B + r0) * P.Rp, datth + ((size_t)t * B + r0) * E, hb, P.R, P.Rp, E, C, nchb, sh));
+                              de + ((size_t)t * B + r0) * P.Rp, datth + ((size_t)t * B + r0) * E, hb, P.R, P.Rp, E, C, nchb, 0, sh));
             // d_h += d_att_h W_att_h^T
             RC(slab(P, datth + ((size_t)t * B + r0) * E, E, P.pk(wp, K_ATT_H), P.ldAH, sb3, hb, U, E, sh));
             RC(lxo_k_lstm_bwd(gates + ((size_t)t * B + r0) * 4 * U, cs + ((size_t)t * B + r0) * U, cs + ((size_t)(t + 1) * B + r0) * U,
@@ -432,7 +438,7 @@ static int decode_common_step(const Plan& P, const float* prm, const void* wp, v
         RC(cell_step_fused(P, prm, wp, ws, nv, beam, P.ws<float>(ws, W_DEC_TX), rec + (size_t)prev * nv * P.REC, cs + (size_t)prev * nv * U,
                            rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U,
                            recb + (size_t)prev * nv * P.RECB, recb + (size_t)cur * nv * P.RECB, nullptr,
-                           P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st,
+                           P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, cur, 0, 0}, st,      // t = the record slot: only its parity is used (attention direction)
                            ids_prev, ids_prev ? -1 : V));
     } else {
         // next input embedding (start token at time 0), its LSTM x-part, then the cell step
