@@ -271,8 +271,8 @@ LXO_DEV void pack_rows(const float (&r0)[8], const float (&r1)[8], unsigned (&ou
 template <typename CT, bool CONV, typename TA, typename TB>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     constexpr bool BF = is_bf16<CT>::value;
-    constexpr int BI = 128, BJ = 128, BR = 32;
-    constexpr int PITCH = BF ? 36 : 33;
+    constexpr int BI = 128, BJ = 128, BR = BF ? 64 : 32;      // reduction rows per LDS tile (bf16: 64 -- half the barriers per row)
+    constexpr int PITCH = BF ? BR + 4 : 33;
     __shared__ __attribute__((aligned(16))) CT As[BI * PITCH];
     __shared__ __attribute__((aligned(16))) CT Bs[BJ * PITCH];
 
@@ -296,14 +296,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // staging geometry
-    //  bf16: one (row pair, 8-column chunk) of A and of B per thread, written as packed bf16x2 dwords
+    //  bf16: two (row pair, 8-column chunk) pieces of A and of B per thread, written as packed bf16x2 dwords
     //  f32 : two (row, 8-column chunk) of A and of B per thread
-    constexpr int NQ = BF ? 1 : 2;
+    constexpr int NQ = 2;
     constexpr int NR = BF ? 2 : 1;
     int s_r[NQ], s_c[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        if constexpr (BF) { s_r[q] = 2 * (lane & 15); s_c[q] = (lane >> 4) + 4 * wave; }
+        if constexpr (BF) { s_r[q] = 2 * (lane & 15) + 32 * q; s_c[q] = (lane >> 4) + 4 * wave; }
         else { const int c = tid + 256 * q; s_r[q] = c & 31; s_c[q] = c >> 5; }
     }
     int c_kh[NQ], c_kw[NQ], c_ci[NQ];
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
         if (mb + BR < mend) gload(mb + BR);
         if constexpr (BF) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BR / 16; ++ks) {
                 u32x4 af[2], bfr[2];
                 const int kof = ks * 16 + (lane >> 5) * 8;
 #pragma unroll

@@ -222,8 +222,12 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
         }
     if (dual) RC(join_side(st));
     // logits_t = o_t y_W_o for every step at once  (attention_cell.py:84)
-    RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
-          T * B, V, O, nullptr, 0, false, st));
+    if (P.bf && fused)      // A = the bf16 mirror of o_t the step kernels wrote next to the f32 record
+        RC(nt(P, false, true, false, P.ws<bf16_t>(ws, W_RECB) + (size_t)B * P.RECB, P.RECB, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
+              T * B, V, O, nullptr, 0, false, st));
+    else
+        RC(nt(P, true, true, false, rec + (size_t)B * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_LOGITS), P.Vp,
+              T * B, V, O, nullptr, 0, false, st));
     return 0;
 }
 
@@ -246,10 +250,14 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     float* gates = P.ws<float>(ws, W_GATES); float* atth = P.ws<float>(ws, W_ATTH); float* alpha = P.ws<float>(ws, W_ALPHA);
     const void* dlog = P.ws<void>(ws, W_DLOGITS);
 
+    // the same conditions as in lxo_impl_decoder_train_fwd: the fused step kernels ran (and left the bf16 mirrors of the record)
+    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
+    const bool fused = fused_steps(P) && !dual && !active;
     // d_o (from logits) for every step, and dy_W_o
     if (parts & 1) {
         RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
-        RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
+        if (P.bf && fused) RC(tn(P, false, false, P.ws<bf16_t>(ws, W_RECB) + (size_t)B * P.RECB, P.RECB, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
+        else RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
     }
     if (!(parts & 2)) return 0;
 
@@ -261,9 +269,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         HIPRC(hipMemsetAsync(de, 0, (size_t)TB * P.Rp * 4, st));
         HIPRC(hipMemsetAsync(dz, 0, (size_t)TB * 4 * U * 4, st));
     }
-    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
     const int nh = dual ? 2 : 1;
-    const bool fused = fused_steps(P) && !dual && !active;
     float* dxh = P.ws<float>(ws, W_DXH);
     if (fused) {
         // 4 dependent launches per step: [d_h~|d_ctx] GEMM, attention backward, d_att_h GEMM + LSTM backward,
@@ -276,7 +282,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         const int nchb = P.attn_chunks(B);
         // g_{T-1} = d_o(logits) * tanh'   (no carry yet)
         RC(lxo_k_tanh_bwd(dolog + (size_t)(T - 1) * B * O, O, kNoSlabs, rec + (size_t)T * B * P.REC, P.REC,
-                          gall + (size_t)(T - 1) * B * O, O, bf ? gb : nullptr, P.GBP, P.drop(T - 1, 0), 0, B, O, st));
+                          gall + (size_t)(T - 1) * B * O, O, bf ? gb + (size_t)(T - 1) * B * P.GBP : nullptr, P.GBP, P.drop(T - 1, 0), 0, B, O, st));
         RStep a; memset(&a, 0, sizeof(a));
         a.M = B; a.U = U; a.O = O; a.zx_row = -1;
         for (int t = T - 1; t >= 0; --t) {
@@ -287,7 +293,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             float* dz_t = dz + (size_t)t * B * 4 * U;
             // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
             RStep b1 = a;
-            b1.A = bf ? (const void*)gb : (const void*)g_t; b1.lda = bf ? P.GBP : O;
+            b1.A = bf ? (const void*)(gb + (size_t)t * B * P.GBP) : (const void*)g_t; b1.lda = bf ? P.GBP : O;
             b1.W = P.pk(wp, K_OW); b1.ldw = P.ldOW; b1.N = P.HC; b1.K = O; b1.epi = RS_PLAIN;
             b1.out = dhc_t; b1.ldo = P.HC;
             RC(lxo_launch_rstep(P.s.dtype, bf, b1, st));
@@ -304,15 +310,15 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             b3.W = P.pk(wp, K_ATT_H); b3.ldw = P.ldAH; b3.N = U; b3.K = E; b3.epi = RS_LSTM_BWD;
             b3.dhm = dhc_t; b3.lddhm = P.HC; b3.carry_h = carry_h; b3.carry_rows = (t == T - 1) ? 0 : B;
             b3.gates_in = gates + (size_t)t * B * 4 * U; b3.c_prev = cs + (size_t)t * B * U; b3.c_cur = cs + (size_t)(t + 1) * B * U;
-            b3.dcc = dcc; b3.out = dz_t; b3.outb = bf ? dzb : nullptr; b3.ldob = P.DZBP; b3.dr = P.drop(t, 0);
+            b3.dcc = dcc; b3.out = dz_t; b3.outb = bf ? dzb + (size_t)t * B * P.DZBP : nullptr; b3.ldob = P.DZBP; b3.dr = P.drop(t, 0);
             RC(lxo_launch_rstep(P.s.dtype, 0, b3, st));
             // [d_o carry | d_h carry] = d_z K[D:]^T ; g_{t-1} = (d_o(logits) + d_o carry) * tanh'
             RStep b4 = a;
-            b4.A = bf ? (const void*)dzb : (const void*)dz_t; b4.lda = bf ? P.DZBP : 4 * U;
+            b4.A = bf ? (const void*)(dzb + (size_t)t * B * P.DZBP) : (const void*)dz_t; b4.lda = bf ? P.DZBP : 4 * U;
             b4.W = (const char*)P.pk(wp, K_LSTM) + (size_t)D * P.ldK * P.esz; b4.ldw = P.ldK; b4.N = P.XH; b4.K = 4 * U; b4.epi = RS_CARRY;
             if (t == 0) { b4.first = 1; b4.out = dxh; b4.ldo = P.XH; }
             else {
-                b4.out = gall + (size_t)(t - 1) * B * O; b4.outb = bf ? gb : nullptr; b4.ldob = P.GBP; b4.out2 = carry_h;
+                b4.out = gall + (size_t)(t - 1) * B * O; b4.outb = bf ? gb + (size_t)(t - 1) * B * P.GBP : nullptr; b4.ldob = P.GBP; b4.out2 = carry_h;
                 b4.dolog = dolog + (size_t)(t - 1) * B * O; b4.o_prev = rec + (size_t)t * B * P.REC; b4.ldoprev = P.REC;
                 b4.dr = P.drop(t - 1, 0);
             }
@@ -365,10 +371,21 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_k_slab_reduce(view(sb4, 4 * U, hb, P.XH), dxh + r0 * P.XH, P.XH, hb, P.XH, st));
     }
     // ---- deferred weight gradients over all steps ----
+    if (P.bf && fused) {
+        // the bf16 mirrors the step kernels left (record, g_t, d_z_t) are the operands: half the bytes of the f32 originals, and
+        // these reductions over T*B rows are bound by operand re-reads (every 128 x 128 tile walks all rows of both operands)
+        const bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
+        const bf16_t* gb = P.ws<bf16_t>(ws, W_GB); const bf16_t* dzb = P.ws<bf16_t>(ws, W_DZB);
+        RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
+        RC(tn(P, false, true, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, datth, E, gw(P_ATT_H), E, TB, U, E, st));         // dW_att_h
+        RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st));           // dK rows 0..D
+        RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st));     // dK rows D..
+    } else {
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, datth, E, gw(P_ATT_H), E, TB, U, E, st));      // dW_att_h
     RC(tn(P, false, true, P.ws<void>(ws, W_EMB_IN), P.Dp, dz, 4 * U, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st)); // dK rows 0..D
     RC(tn(P, true, true, rec, P.REC, dz, 4 * U, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st)); // dK rows D..
+    }
     RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, st));
     // embeddings
     float* demb = P.ws<float>(ws, W_DEMB);

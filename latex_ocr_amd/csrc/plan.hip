@@ -157,8 +157,8 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_S_B3] = (size_t)(E / 128) * BL * U * f4;
     wb[W_S_B4] = (size_t)(4 * U / 128) * BL * XH * f4;
     wb[W_RECB] = bf ? (size_t)(T + 1) * B * RECB * 2 : 0;
-    wb[W_GB] = bf ? BL * GBP * 2 : 0;
-    wb[W_DZB] = bf ? BL * DZBP * 2 : 0;
+    wb[W_GB] = bf ? TB * GBP * 2 : 0;                // every step's g_t / d_z_t: the deferred weight-gradient GEMMs read the mirrors
+    wb[W_DZB] = bf ? TB * DZBP * 2 : 0;
     wb[W_CARRYH] = BL * U * f4;
     const int ms = s.max_steps > 0 ? s.max_steps : 0;
     if (ms > 0) {
