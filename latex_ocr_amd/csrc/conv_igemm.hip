@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     // a lane holds 4 CONSECUTIVE channels of one pixel per register quad, which is what both epilogues want.
 
     CSTAMP(1 + nk);
-    if constexpr (EPI == 0) {
+    if constexpr (EPI == 0 || EPI == 2) {
         // ---- plain epilogue (bias, ReLU, bf16): every wave packs its own 64 pixels x WBN channels into a bf16 tile in LDS
         // (8-byte writes of 4 channels), ONE barrier, then the workgroup streams the 256 pixel rows out in 16-byte pieces,
         // rows contiguous across lanes.  One pass instead of four f32 passes through a single 64-row staging tile.
@@ -769,6 +769,55 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         u32x4 q4[256 / RPQ];
 #pragma unroll
         for (int it = 0; it < 256 / RPQ; ++it) q4[it] = *reinterpret_cast<const u32x4*>(bt + (tid / CHQ + RPQ * it) * BP + cq * 16);
+        if constexpr (EPI == 2) {
+            // data gradient of a layer whose input was a ReLU output: d *= (reference activation > 0), bias-gradient column sums of
+            // the masked tile.  The mask operand of every row is requested up front (unconditional, clamped), in the same 16-byte
+            // row pieces as the stores; masking the already rounded bf16 values equals rounding the masked f32 values, and the
+            // column sums are taken over what is stored.
+            const bf16_t* const ref0 = reinterpret_cast<const bf16_t*>(p.relu_ref) + (((long long)b * p.Ho + oy0) * p.Wo + ox0) * p.ldr + n0 + cq * 8;
+            u32x4 rf[256 / RPQ];
+#pragma unroll
+            for (int it = 0; it < 256 / RPQ; ++it) {
+                const int row = tid / CHQ + RPQ * it, ty = row >> 5, tx = row & 31;
+                const bool ok = oy0 + ty < p.Ho && ox0 + tx < p.Wo;
+                rf[it] = *reinterpret_cast<const u32x4*>(ref0 + (ok ? (ty * p.Wo + tx) * p.ldr : 0));
+            }
+            float csum[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+#pragma unroll
+            for (int it = 0; it < 256 / RPQ; ++it) {
+                const int row = tid / CHQ + RPQ * it, ty = row >> 5, tx = row & 31;
+                const bool ok = oy0 + ty < p.Ho && ox0 + tx < p.Wo;
+                u32x4 o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned r = rf[it][d], v = q4[it][d];
+                    // a bf16 activation is positive iff its sign bit is clear and it is not zero
+                    const unsigned lo = (ok && (short)(r & 0xffffu) > 0) ? (v & 0xffffu) : 0u;
+                    const unsigned hi = (ok && (int)r > 0 && (r >> 16) != 0u) ? (v & 0xffff0000u) : 0u;
+                    o[d] = lo | hi;
+                    csum[2 * d] += __uint_as_float(lo << 16);
+                    csum[2 * d + 1] += __uint_as_float(hi);
+                }
+                if (ok) *reinterpret_cast<u32x4*>(tile0 + (ty * p.Wo + tx) * p.ldc) = o;
+            }
+            if (p.colsum) {
+                float* cs = reinterpret_cast<float*>(lxo_conv_lds);      // [RPQ][WBN] partial sums; the bf16 tile has been read
+                LXO_LDS_BARRIER();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[(tid / CHQ) * WBN + cq * 8 + e] = csum[e];
+                LXO_LDS_BARRIER();
+                if (tid < WBN) {
+                    float sres = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RPQ; ++r) sres += cs[r * WBN + tid];
+                    atomicAdd(&p.colsum[n0 + tid], sres);
+                }
+            }
+            CSTAMP(2 + nk);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 256 / RPQ; ++it) {
             const int row = tid / CHQ + RPQ * it;                       // 0..255: tile row row >> 5, column row & 31
@@ -922,7 +971,7 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
         const bool has_add = p.addend || p.out_pre, has_ref = p.relu_ref || p.colsum;
-        const int epi = p.accumulate || (has_add && has_ref) ? 3 : (has_add ? 1 : (has_ref ? 2 : 0));
+        const int epi = p.accumulate || (has_add && has_ref) ? 3 : (has_add ? 1 : (has_ref ? (p.relu_ref ? 2 : 3) : 0));      // 2 = the one-pass masked epilogue: needs the reference
         const dim3 g4(B * tiles_x * tiles_y * (p.N / 128)), g2(B * tiles_x * tiles_y * (p.N / 64));
         if (p.N % 128 == 0) {
             if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 0>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);

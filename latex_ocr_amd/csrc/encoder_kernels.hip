@@ -12,6 +12,7 @@
 //   mask_convert     : d_y6 = d_img(f32) * (y6 > 0) -> compute dtype, + bias gradient
 //   timing_signal    : positional.py:42-64 table [Hp*Wp][C] f32
 #include "encoder_kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -188,6 +189,181 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __re
         const float v = red[0][g8][k] + red[1][g8][k] + red[2][g8][k] + red[3][g8][k];
         if (k < 72) atomicAdd(&dw[(k >> 3) * 64 + g8 * 8 + (k & 7)], v);
         else atomicAdd(&db[g8 * 8 + (k - 72)], v);
+    }
+}
+
+
+// ---- bf16 mode: conv1 + ReLU + 2x2 pool on the matrix cores ----
+// The VALU kernels above spend 2.4 G FMAs per pass over the batch (80 us forward, 216 us backward at B = 64, 128 x 512) for a
+// layer whose memory traffic is 134 MB.  Here a wave treats 8 pooled pixels = 32 full-resolution pixels as one 32 x 16 x 32
+// MFMA tile:  pre[pixel][channel] = sum_tap x[pixel + tap] w[tap][channel]  with K = 9 taps padded to 16.
+//   * tile row m = 4 * window + q (q = position inside the 2 x 2 pool window), so a lane's accumulator registers r, r+1, r+2,
+//     r+3 ARE the four pool positions of one window: pooling is three v_max per (window, channel), no cross-lane traffic;
+//   * the two MFMAs of a tile take the EVEN and the ODD channels (the column order of the weight operand is free), so lane n
+//     ends up with channels 2n and 2n+1 of the same pixels: one packed 4-byte store per window, 128 contiguous bytes per wave;
+//   * the image values (v - 128) / 128 are exact in bf16; the weights are rounded to bf16 like every other layer's.
+// Backward recomputes the tile the same way (so the argmax is the forward's), routes d through first-max + ReLU in registers,
+// and contracts  dW[tap][channel] = sum_pixel x[pixel + tap] d[pixel][channel]  with the d tile taken straight from those
+// registers as the MFMA B operand (k = pixel), the shifted image rows gathered from the LDS patch as the A operand (m = tap).
+typedef __attribute__((ext_vector_type(16))) float c1_v16f;
+LXO_DEV c1_v16f c1_mfma(u32x4 a, u32x4 b, c1_v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+constexpr int C1_SEG = 128;                       // pooled pixels per workgroup pass (4 waves x 4 tiles x 8)
+constexpr int C1_PW = 2 * C1_SEG + 8;             // patch row pitch (2 * 128 + 2 halo columns used)
+
+// patch rows 2py-1 .. 2py+2, columns 256*xc-1 .. 256*xc+256 of image b as bf16 (v - 128) / 128, zero outside the image
+LXO_DEV void c1_stage(bf16_t (*sp)[C1_PW], const uint8_t* im, int H, int W, int py, int xc) {
+    for (int i = threadIdx.x; i < 4 * (2 * C1_SEG + 2); i += 256) {
+        const int dy = i / (2 * C1_SEG + 2), dx = i - dy * (2 * C1_SEG + 2);
+        const int y = 2 * py - 1 + dy, x = 2 * C1_SEG * xc - 1 + dx;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        const float v = fmaf((float)im[in ? y * W + x : 0], 0.0078125f, -1.0f);
+        sp[dy][dx] = in ? f2bf(v) : (bf16_t)0;
+    }
+}
+// weight operand of the even (e = 0) / odd (e = 1) channels: lane n -> channel 2n + e, k = tap
+LXO_DEV u32x4 c1_wop(const float* w, int lane, int e) {
+    const int ch = 2 * (lane & 31) + e, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int t = 8 * h + i; v[i] = t < 9 ? w[t * 64 + ch] : 0.f; }
+    return u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+// image operand of the forward product: lane m = pixel 4 * window + q of the tile, k = tap
+LXO_DEV u32x4 c1_xop(const bf16_t (*sp)[C1_PW], int lane, int pw0) {
+    const int m = lane & 31, h = lane >> 5, q = m & 3, qy = q >> 1, qx = q & 1;
+    const int c = 2 * (pw0 + (m >> 2)) + qx;                    // patch column of tap (., 0)
+    const unsigned r0a = sp[qy][c], r0b = sp[qy][c + 1], r0c = sp[qy][c + 2];
+    const unsigned r1a = sp[qy + 1][c], r1b = sp[qy + 1][c + 1], r1c = sp[qy + 1][c + 2];
+    const unsigned r2a = sp[qy + 2][c], r2b = sp[qy + 2][c + 1], r2c = sp[qy + 2][c + 2];
+    const u32x4 lo = {r0a | (r0b << 16), r0c | (r1a << 16), r1b | (r1c << 16), r2a | (r2b << 16)};     // taps 0..7
+    const u32x4 hi = {r2c, 0u, 0u, 0u};                                                                  // tap 8
+    return h ? hi : lo;
+}
+
+__global__ __launch_bounds__(256) void conv1_pool_fwd_mfma_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                                 int B, int H, int W, int Hp, int Wp) {
+    __shared__ bf16_t sp[4][C1_PW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    const u32x4 w0 = c1_wop(w, lane, 0), w1 = c1_wop(w, lane, 1);
+    const float b0 = bias[2 * n], b1 = bias[2 * n + 1];
+    const int segs_x = (Wp + C1_SEG - 1) / C1_SEG, nseg = B * Hp * segs_x;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int row = seg / segs_x, xc = seg - row * segs_x;
+        const int b = row / Hp, py = row - b * Hp;
+        __syncthreads();                                           // previous pass's readers are done
+        c1_stage(sp, img + (long long)b * H * W, H, W, py, xc);
+        __syncthreads();
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const int pw0 = wave * 32 + tile * 8;
+            const u32x4 xa = c1_xop(sp, lane, pw0);
+            c1_v16f z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            const c1_v16f a0 = c1_mfma(xa, w0, z), a1 = c1_mfma(xa, w1, z);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int px = xc * C1_SEG + pw0 + 2 * g4 + h;     // this lane's window
+                float m0 = -3.0e38f, m1 = -3.0e38f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = 2 * py + (q >> 1) < H && 2 * px + (q & 1) < W;      // SAME pool ignores padding
+                    m0 = fmaxf(m0, ok ? a0[4 * g4 + q] : -3.0e38f);
+                    m1 = fmaxf(m1, ok ? a1[4 * g4 + q] : -3.0e38f);
+                }
+                const unsigned o = pack_bf2(fmaxf(m0 + b0, 0.f), fmaxf(m1 + b1, 0.f));
+                if (px < Wp) *reinterpret_cast<unsigned*>(out + ((long long)row * Wp + px) * 64 + 2 * n) = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_pool_bwd_mfma_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, const bf16_t* __restrict__ dout,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 int B, int H, int W, int Hp, int Wp) {
+    __shared__ bf16_t sp[4][C1_PW];
+    __shared__ float red[4][10][64];                               // per wave: 9 taps + bias, 64 channels
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    const u32x4 w0 = c1_wop(w, lane, 0), w1 = c1_wop(w, lane, 1);
+    const float b0 = bias[2 * n], b1 = bias[2 * n + 1];
+    c1_v16f gw0, gw1;                                              // dW tile [tap][channel]: even / odd channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gw0[r] = 0.f; gw1[r] = 0.f; }
+    float gb0 = 0.f, gb1 = 0.f;
+    const int tp = n < 9 ? n : 0, tkh = tp / 3, tkw = tp - 3 * tkh;   // dW product: lane m = tap (rows >= 9 are never read back)
+    const int segs_x = (Wp + C1_SEG - 1) / C1_SEG, nseg = B * Hp * segs_x;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int row = seg / segs_x, xc = seg - row * segs_x;
+        const int b = row / Hp, py = row - b * Hp;
+        __syncthreads();
+        c1_stage(sp, img + (long long)b * H * W, H, W, py, xc);
+        __syncthreads();
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const int pw0 = wave * 32 + tile * 8;
+            unsigned gq[4];                                        // d_out of this lane's four windows: channels 2n, 2n+1 (unconditional)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int px = xc * C1_SEG + pw0 + 2 * g4 + h;
+                const unsigned v = *reinterpret_cast<const unsigned*>(dout + ((long long)row * Wp + (px < Wp ? px : 0)) * 64 + 2 * n);
+                gq[g4] = px < Wp ? v : 0u;
+            }
+            const u32x4 xa = c1_xop(sp, lane, pw0);
+            c1_v16f z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            const c1_v16f a0 = c1_mfma(xa, w0, z), a1 = c1_mfma(xa, w1, z);
+            float d0[16], d1[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int px = xc * C1_SEG + pw0 + 2 * g4 + h;
+                float best0 = -3.0e38f, best1 = -3.0e38f; int bq0 = 0, bq1 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                      // first max in scan order, as the forward's fmaxf chain
+                    const bool ok = 2 * py + (q >> 1) < H && 2 * px + (q & 1) < W;
+                    const float v0 = fmaxf(a0[4 * g4 + q] + b0, 0.f), v1 = fmaxf(a1[4 * g4 + q] + b1, 0.f);
+                    if (ok && v0 > best0) { best0 = v0; bq0 = q; }
+                    if (ok && v1 > best1) { best1 = v1; bq1 = q; }
+                }
+                const float g0 = best0 > 0.f ? __uint_as_float(gq[g4] << 16) : 0.f;
+                const float g1 = best1 > 0.f ? __uint_as_float(gq[g4] & 0xffff0000u) : 0.f;
+                gb0 += g0; gb1 += g1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { d0[4 * g4 + q] = bq0 == q ? g0 : 0.f; d1[4 * g4 + q] = bq1 == q ? g1 : 0.f; }
+            }
+            // dW += X^T D: k-step s covers the pixels of accumulator registers 8s .. 8s+7 (rows (i&3) + 8(i>>2) + 4h + 16s)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 db0 = {pack_bf2(d0[8 * s2], d0[8 * s2 + 1]), pack_bf2(d0[8 * s2 + 2], d0[8 * s2 + 3]),
+                                   pack_bf2(d0[8 * s2 + 4], d0[8 * s2 + 5]), pack_bf2(d0[8 * s2 + 6], d0[8 * s2 + 7])};
+                const u32x4 db1 = {pack_bf2(d1[8 * s2], d1[8 * s2 + 1]), pack_bf2(d1[8 * s2 + 2], d1[8 * s2 + 3]),
+                                   pack_bf2(d1[8 * s2 + 4], d1[8 * s2 + 5]), pack_bf2(d1[8 * s2 + 6], d1[8 * s2 + 7])};
+                unsigned xv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rr = (i & 3) + 8 * (i >> 2) + 4 * h + 16 * s2, q = rr & 3;     // tile row = pixel 4 * window + q
+                    xv[i] = sp[(q >> 1) + tkh][2 * (pw0 + (rr >> 2)) + (q & 1) + tkw];
+                }
+                const u32x4 xt = {xv[0] | (xv[1] << 16), xv[2] | (xv[3] << 16), xv[4] | (xv[5] << 16), xv[6] | (xv[7] << 16)};
+                gw0 = c1_mfma(xt, db0, gw0);
+                gw1 = c1_mfma(xt, db1, gw1);
+            }
+        }
+    }
+    // taps live in rows (r & 3) + 8 (r >> 2) + 4 h: r = 0..3 -> taps 0..3 (h = 0) / 4..7 (h = 1), r = 4, h = 0 -> tap 8
+    gb0 += __shfl_xor(gb0, 32); gb1 += __shfl_xor(gb1, 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[wave][4 * h + r][2 * n] = gw0[r]; red[wave][4 * h + r][2 * n + 1] = gw1[r]; }
+    if (h == 0) { red[wave][8][2 * n] = gw0[4]; red[wave][8][2 * n + 1] = gw1[4]; red[wave][9][2 * n] = gb0; red[wave][9][2 * n + 1] = gb1; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 640; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        const float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
+        if (t < 9) atomicAdd(&dw[t * 64 + c], v); else atomicAdd(&db[c], v);
     }
 }
 
@@ -485,7 +661,18 @@ template <typename CT> static void conv1_fwd_t(const uint8_t* img, const float* 
     hipLaunchKernelGGL((conv1_pool_fwd_kernel<CT>), dim3(grid_for((long long)B * Hp * ((Wp + 31) / 32), 1, 4096)), dim3(256), 0, s,
                        img, w, b, (CT*)out, B, H, W, Hp, Wp);
 }
+static int conv1_mfma() {       // LXO_CONV1_MFMA=0: the VALU kernels in bf16 mode too (A/B)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LXO_CONV1_MFMA"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v;
+}
 int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s) {
+    if (dt == LXO_BF16 && conv1_mfma()) {
+        const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
+        hipLaunchKernelGGL(conv1_pool_fwd_mfma_kernel, dim3(grid_for((long long)B * Hp * ((Wp + C1_SEG - 1) / C1_SEG), 1, 4096)), dim3(256), 0, s,
+                           img, w, b, (bf16_t*)out, B, H, W, Hp, Wp);
+        return (int)hipGetLastError();
+    }
     DISPATCH_CT(dt, conv1_fwd_t, img, w, b, out, B, H, W, s);
     return (int)hipGetLastError();
 }
@@ -495,6 +682,13 @@ template <typename CT> static void conv1_bwd_t(const uint8_t* img, const float* 
                        img, w, b, (const CT*)dout, dw, db, B, H, W, Hp, Wp);
 }
 int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s) {
+    if (dt == LXO_BF16 && conv1_mfma()) {
+        const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
+        static int cap = -1; if (cap < 0) { const char* e = getenv("LXO_C1_CAP"); cap = e ? atoi(e) : 512; }
+        hipLaunchKernelGGL(conv1_pool_bwd_mfma_kernel, dim3(grid_for((long long)B * Hp * ((Wp + C1_SEG - 1) / C1_SEG), 4, cap)), dim3(256), 0, s,
+                           img, w, b, (const bf16_t*)dout, dw, db, B, H, W, Hp, Wp);
+        return (int)hipGetLastError();
+    }
     DISPATCH_CT(dt, conv1_bwd_t, img, w, b, dout, dw, db, B, H, W, s);
     return (int)hipGetLastError();
 }

@@ -389,7 +389,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, st));
     // embeddings
     float* demb = P.ws<float>(ws, W_DEMB);
-    RC(nt(P, true, true, false, dz, 4 * U, P.pk(wp, K_LSTM), P.ldK, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
+    RC(nt(P, true, true, true, dz, 4 * U, P.pk(wp, K_LSTM), P.ldK, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
     RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, st));
     // ---- initial states ----
     float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
