@@ -210,18 +210,40 @@ LXO_DEV c1_v16f c1_mfma(u32x4 a, u32x4 b, c1_v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 constexpr int C1_SEG = 128;                       // pooled pixels per workgroup pass (4 waves x 4 tiles x 8)
-constexpr int C1_PW = 2 * C1_SEG + 8;             // patch row pitch (2 * 128 + 2 halo columns used)
+constexpr int C1_PW = 2 * C1_SEG + 8;             // patch row pitch in elements (2 * 128 + 2 halo columns used)
 
-// patch rows 2py-1 .. 2py+2, columns 256*xc-1 .. 256*xc+256 of image b as bf16 (v - 128) / 128, zero outside the image
-LXO_DEV void c1_stage(bf16_t (*sp)[C1_PW], const uint8_t* im, int H, int W, int py, int xc) {
-    for (int i = threadIdx.x; i < 4 * (2 * C1_SEG + 2); i += 256) {
+// The patch (image rows 2py-1 .. 2py+2, columns 256*xc-1 .. 256*xc+256 as bf16 (v - 128) / 128, zero outside the image) is
+// kept TWICE, the second copy shifted by one element: every (column, column + 1) pair the MFMA operands need is then one
+// ALIGNED 4-byte LDS read from the copy of matching parity, already in operand order -- no 2-byte reads, no packing.
+struct C1Patch { bf16_t e[4][C1_PW]; bf16_t o[4][C1_PW]; };      // o[r][j] = e[r][j + 1]
+constexpr int C1_NF = (4 * (2 * C1_SEG + 2) + 255) / 256;        // patch bytes per thread
+// The patch of pass i+1 is requested (into registers) before pass i computes and written to the other LDS buffer after it:
+// the image round trip hides behind the MFMA work, one barrier per pass.  Loads are unconditional (clamped address).
+struct C1Fetch { unsigned char v[C1_NF]; };
+LXO_DEV void c1_fetch(C1Fetch& f, const uint8_t* im, int H, int W, int py, int xc) {
+#pragma unroll
+    for (int k = 0; k < C1_NF; ++k) {
+        const int i = min((int)threadIdx.x + 256 * k, 4 * (2 * C1_SEG + 2) - 1);
         const int dy = i / (2 * C1_SEG + 2), dx = i - dy * (2 * C1_SEG + 2);
         const int y = 2 * py - 1 + dy, x = 2 * C1_SEG * xc - 1 + dx;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const float v = fmaf((float)im[in ? y * W + x : 0], 0.0078125f, -1.0f);
-        sp[dy][dx] = in ? f2bf(v) : (bf16_t)0;
+        const unsigned char b = im[in ? y * W + x : 0];
+        f.v[k] = in ? b : (unsigned char)128;                     // 128 -> (128 - 128) / 128 = 0: the zero padding
     }
 }
+LXO_DEV void c1_commit(C1Patch& sp, const C1Fetch& f) {
+#pragma unroll
+    for (int k = 0; k < C1_NF; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        if (i < 4 * (2 * C1_SEG + 2)) {
+            const int dy = i / (2 * C1_SEG + 2), dx = i - dy * (2 * C1_SEG + 2);
+            const bf16_t q = f2bf(fmaf((float)f.v[k], 0.0078125f, -1.0f));      // (v - 128) / 128, exact in bf16
+            sp.e[dy][dx] = q;
+            if (dx > 0) sp.o[dy][dx - 1] = q;
+        }
+    }
+}
+LXO_DEV unsigned c1_pair(const bf16_t* row, int col) { return *reinterpret_cast<const unsigned*>(row + col); }   // col even
 // weight operand of the even (e = 0) / odd (e = 1) channels: lane n -> channel 2n + e, k = tap
 LXO_DEV u32x4 c1_wop(const float* w, int lane, int e) {
     const int ch = 2 * (lane & 31) + e, h = lane >> 5;
@@ -230,129 +252,178 @@ LXO_DEV u32x4 c1_wop(const float* w, int lane, int e) {
     for (int i = 0; i < 8; ++i) { const int t = 8 * h + i; v[i] = t < 9 ? w[t * 64 + ch] : 0.f; }
     return u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
 }
-// image operand of the forward product: lane m = pixel 4 * window + q of the tile, k = tap
-LXO_DEV u32x4 c1_xop(const bf16_t (*sp)[C1_PW], int lane, int pw0) {
+// image operand of the forward product: lane m = pixel 4 * window + q of the tile, k = tap (kh * 3 + kw).
+// With c = 2 * (pw0 + window) + qx the taps of row r sit at columns c, c+1, c+2 of patch row qy + r.
+LXO_DEV u32x4 c1_xop(const C1Patch& sp, int lane, int pw0) {
     const int m = lane & 31, h = lane >> 5, q = m & 3, qy = q >> 1, qx = q & 1;
-    const int c = 2 * (pw0 + (m >> 2)) + qx;                    // patch column of tap (., 0)
-    const unsigned r0a = sp[qy][c], r0b = sp[qy][c + 1], r0c = sp[qy][c + 2];
-    const unsigned r1a = sp[qy + 1][c], r1b = sp[qy + 1][c + 1], r1c = sp[qy + 1][c + 2];
-    const unsigned r2a = sp[qy + 2][c], r2b = sp[qy + 2][c + 1], r2c = sp[qy + 2][c + 2];
-    const u32x4 lo = {r0a | (r0b << 16), r0c | (r1a << 16), r1b | (r1c << 16), r2a | (r2b << 16)};     // taps 0..7
-    const u32x4 hi = {r2c, 0u, 0u, 0u};                                                                  // tap 8
+    const bf16_t (*cp)[C1_PW] = qx ? sp.o : sp.e;                 // copy whose even columns are c, c + 2
+    const int cb = 2 * (pw0 + (m >> 2));
+    const unsigned p00 = c1_pair(cp[qy], cb), p02 = c1_pair(cp[qy], cb + 2);
+    const unsigned p10 = c1_pair(cp[qy + 1], cb), p12 = c1_pair(cp[qy + 1], cb + 2);
+    const unsigned p20 = c1_pair(cp[qy + 2], cb), p22 = c1_pair(cp[qy + 2], cb + 2);
+    const u32x4 lo = {p00, (p02 & 0xffffu) | (p10 << 16), __builtin_amdgcn_alignbit(p12, p10, 16), p20};     // taps 0..7
+    const u32x4 hi = {p22 & 0xffffu, 0u, 0u, 0u};                                                             // tap 8
     return h ? hi : lo;
 }
 
 __global__ __launch_bounds__(256) void conv1_pool_fwd_mfma_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                                  int B, int H, int W, int Hp, int Wp) {
-    __shared__ bf16_t sp[4][C1_PW];
+    __shared__ __attribute__((aligned(16))) C1Patch spb[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
     const u32x4 w0 = c1_wop(w, lane, 0), w1 = c1_wop(w, lane, 1);
-    const float b0 = bias[2 * n], b1 = bias[2 * n + 1];
+    const float b0 = bias[2 * n], b1 = bias[2 * n + 1];           // added after the pool: max(v + b) = max(v) + b
+    c1_v16f z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
     const int segs_x = (Wp + C1_SEG - 1) / C1_SEG, nseg = B * Hp * segs_x;
-    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    if ((int)blockIdx.x >= nseg) return;
+    C1Fetch nf;
+    {
+        const int row = blockIdx.x / segs_x, xc = blockIdx.x - row * segs_x, b = row / Hp, py = row - b * Hp;
+        c1_fetch(nf, img + (long long)b * H * W, H, W, py, xc);
+        c1_commit(spb[0], nf);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x, cur ^= 1) {
         const int row = seg / segs_x, xc = seg - row * segs_x;
         const int b = row / Hp, py = row - b * Hp;
-        __syncthreads();                                           // previous pass's readers are done
-        c1_stage(sp, img + (long long)b * H * W, H, W, py, xc);
-        __syncthreads();
+        {
+            const int ns = min(seg + (int)gridDim.x, nseg - 1);    // next pass (clamped: the last pass re-fetches its own patch)
+            const int nrow = ns / segs_x, nxc = ns - nrow * segs_x, nb = nrow / Hp;
+            c1_fetch(nf, img + (long long)nb * H * W, H, W, nrow - nb * Hp, nxc);
+        }
+        const C1Patch& sp = spb[cur];
+        const bool edge = 2 * py + 1 >= H || (W & 1);              // block-uniform: some pool windows reach past the image
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const int pw0 = wave * 32 + tile * 8;
             const u32x4 xa = c1_xop(sp, lane, pw0);
-            c1_v16f z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            const c1_v16f a0 = c1_mfma(xa, w0, z), a1 = c1_mfma(xa, w1, z);
+            c1_v16f a0 = c1_mfma(xa, w0, z), a1 = c1_mfma(xa, w1, z);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int px = xc * C1_SEG + pw0 + 2 * g4 + h;     // this lane's window
-                float m0 = -3.0e38f, m1 = -3.0e38f;
+                if (edge) {                                        // SAME pool ignores padding
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool ok = 2 * py + (q >> 1) < H && 2 * px + (q & 1) < W;      // SAME pool ignores padding
-                    m0 = fmaxf(m0, ok ? a0[4 * g4 + q] : -3.0e38f);
-                    m1 = fmaxf(m1, ok ? a1[4 * g4 + q] : -3.0e38f);
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = 2 * py + (q >> 1) < H && 2 * px + (q & 1) < W;
+                        a0[4 * g4 + q] = ok ? a0[4 * g4 + q] : -3.0e38f; a1[4 * g4 + q] = ok ? a1[4 * g4 + q] : -3.0e38f;
+                    }
                 }
+                const float m0 = fmaxf(fmaxf(a0[4 * g4], a0[4 * g4 + 1]), fmaxf(a0[4 * g4 + 2], a0[4 * g4 + 3]));
+                const float m1 = fmaxf(fmaxf(a1[4 * g4], a1[4 * g4 + 1]), fmaxf(a1[4 * g4 + 2], a1[4 * g4 + 3]));
                 const unsigned o = pack_bf2(fmaxf(m0 + b0, 0.f), fmaxf(m1 + b1, 0.f));
                 if (px < Wp) *reinterpret_cast<unsigned*>(out + ((long long)row * Wp + px) * 64 + 2 * n) = o;
             }
         }
+        c1_commit(spb[cur ^ 1], nf);                               // nobody reads that buffer during this pass
+        __syncthreads();
     }
+}
+
+// first maximum of the four pool positions (scan order, as the forward's fmaxf chain keeps it), ReLU, and the routed gradient
+LXO_DEV void c1_route(const c1_v16f& a, int g4, float bias, float g, float (&d)[16], float& gsum) {
+    const float v0 = a[4 * g4], v1 = a[4 * g4 + 1], v2 = a[4 * g4 + 2], v3 = a[4 * g4 + 3];      // without the bias: it does not move the argmax
+    const float best = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    const float gg = best + bias > 0.f ? g : 0.f;                  // ReLU: a window whose maximum is not positive passes nothing
+    const bool s0 = v0 == best, s1 = !s0 && v1 == best, s2 = !s0 && !s1 && v2 == best, s3 = !s0 && !s1 && !s2;
+    d[4 * g4] = s0 ? gg : 0.f; d[4 * g4 + 1] = s1 ? gg : 0.f; d[4 * g4 + 2] = s2 ? gg : 0.f; d[4 * g4 + 3] = s3 ? gg : 0.f;
+    gsum += gg;
 }
 
 __global__ __launch_bounds__(256) void conv1_pool_bwd_mfma_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, const bf16_t* __restrict__ dout,
                                                                  float* __restrict__ dw, float* __restrict__ db,
                                                                  int B, int H, int W, int Hp, int Wp) {
-    __shared__ bf16_t sp[4][C1_PW];
+    __shared__ __attribute__((aligned(16))) C1Patch spb[2];
     __shared__ float red[4][10][64];                               // per wave: 9 taps + bias, 64 channels
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
     const u32x4 w0 = c1_wop(w, lane, 0), w1 = c1_wop(w, lane, 1);
     const float b0 = bias[2 * n], b1 = bias[2 * n + 1];
-    c1_v16f gw0, gw1;                                              // dW tile [tap][channel]: even / odd channels
+    c1_v16f z, gw0, gw1;                                           // gw: dW tile [tap][channel], even / odd channels
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { gw0[r] = 0.f; gw1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { z[r] = 0.f; gw0[r] = 0.f; gw1[r] = 0.f; }
     float gb0 = 0.f, gb1 = 0.f;
-    const int tp = n < 9 ? n : 0, tkh = tp / 3, tkw = tp - 3 * tkh;   // dW product: lane m = tap (rows >= 9 are never read back)
+    // dW product: lane m = tap (rows >= 9 are never read back), k = pixel.  Tap (kh, kw) of pixel (window, qy, qx) reads patch
+    // row qy + kh, column 2 * window + qx + kw: the (qx = 0, qx = 1) pair is one aligned dword of the copy of kw's parity.
+    const int tp = n < 9 ? n : 0, tkh = tp / 3, tkw = tp - 3 * tkh;
+    const int tcb = 2 * (tkw >> 1);
     const int segs_x = (Wp + C1_SEG - 1) / C1_SEG, nseg = B * Hp * segs_x;
-    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    // d_out of a pass: this lane's four windows of each of the wave's four tiles, channels 2n, 2n+1 (unconditional, clamped)
+    auto fetch_g = [&](unsigned (&g)[16], int row, int xc) {
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int px = xc * C1_SEG + wave * 32 + tile * 8 + 2 * g4 + h;
+                const unsigned v = *reinterpret_cast<const unsigned*>(dout + ((long long)row * Wp + (px < Wp ? px : 0)) * 64 + 2 * n);
+                g[4 * tile + g4] = px < Wp ? v : 0u;
+            }
+    };
+    C1Fetch nf;
+    unsigned gq[16], gn[16];
+    if ((int)blockIdx.x < nseg) {
+        const int row = blockIdx.x / segs_x, xc = blockIdx.x - row * segs_x, b = row / Hp, py = row - b * Hp;
+        c1_fetch(nf, img + (long long)b * H * W, H, W, py, xc);
+        fetch_g(gn, row, xc);
+        c1_commit(spb[0], nf);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x, cur ^= 1) {
         const int row = seg / segs_x, xc = seg - row * segs_x;
         const int b = row / Hp, py = row - b * Hp;
-        __syncthreads();
-        c1_stage(sp, img + (long long)b * H * W, H, W, py, xc);
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gq[i] = gn[i];
+        {
+            const int ns = min(seg + (int)gridDim.x, nseg - 1);    // next pass (clamped), requested before this pass computes
+            const int nrow = ns / segs_x, nxc = ns - nrow * segs_x, nb = nrow / Hp;
+            c1_fetch(nf, img + (long long)nb * H * W, H, W, nrow - nb * Hp, nxc);
+            fetch_g(gn, nrow, nxc);
+        }
+        const C1Patch& sp = spb[cur];
+        const bf16_t (*tcp)[C1_PW] = (tkw & 1) ? sp.o : sp.e;
+        const bool edge = 2 * py + 1 >= H || (W & 1);
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const int pw0 = wave * 32 + tile * 8;
-            unsigned gq[4];                                        // d_out of this lane's four windows: channels 2n, 2n+1 (unconditional)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int px = xc * C1_SEG + pw0 + 2 * g4 + h;
-                const unsigned v = *reinterpret_cast<const unsigned*>(dout + ((long long)row * Wp + (px < Wp ? px : 0)) * 64 + 2 * n);
-                gq[g4] = px < Wp ? v : 0u;
-            }
             const u32x4 xa = c1_xop(sp, lane, pw0);
-            c1_v16f z;
+            c1_v16f a0 = c1_mfma(xa, w0, z), a1 = c1_mfma(xa, w1, z);
+            if (edge) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            const c1_v16f a0 = c1_mfma(xa, w0, z), a1 = c1_mfma(xa, w1, z);
-            float d0[16], d1[16];
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int px = xc * C1_SEG + pw0 + 2 * g4 + h;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int px = xc * C1_SEG + pw0 + 2 * g4 + h;
-                float best0 = -3.0e38f, best1 = -3.0e38f; int bq0 = 0, bq1 = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {                      // first max in scan order, as the forward's fmaxf chain
-                    const bool ok = 2 * py + (q >> 1) < H && 2 * px + (q & 1) < W;
-                    const float v0 = fmaxf(a0[4 * g4 + q] + b0, 0.f), v1 = fmaxf(a1[4 * g4 + q] + b1, 0.f);
-                    if (ok && v0 > best0) { best0 = v0; bq0 = q; }
-                    if (ok && v1 > best1) { best1 = v1; bq1 = q; }
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = 2 * py + (q >> 1) < H && 2 * px + (q & 1) < W;
+                        a0[4 * g4 + q] = ok ? a0[4 * g4 + q] : -3.0e38f; a1[4 * g4 + q] = ok ? a1[4 * g4 + q] : -3.0e38f;
+                    }
                 }
-                const float g0 = best0 > 0.f ? __uint_as_float(gq[g4] << 16) : 0.f;
-                const float g1 = best1 > 0.f ? __uint_as_float(gq[g4] & 0xffff0000u) : 0.f;
-                gb0 += g0; gb1 += g1;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { d0[4 * g4 + q] = bq0 == q ? g0 : 0.f; d1[4 * g4 + q] = bq1 == q ? g1 : 0.f; }
             }
-            // dW += X^T D: k-step s covers the pixels of accumulator registers 8s .. 8s+7 (rows (i&3) + 8(i>>2) + 4h + 16s)
+            // dW += X^T D: k-step s covers the pixels of accumulator registers 8s .. 8s+7, i.e. tile rows
+            // (i & 3) + 8 (i >> 2) + 4 h + 16 s  =  windows h + 4s (i < 4) and h + 4s + 2 (i >= 4), positions q = i & 3;
+            // the two windows of a k-step are routed and contracted before the next two are touched (registers)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                float d0[16], d1[16];
+#pragma unroll
+                for (int g4 = 2 * s2; g4 < 2 * s2 + 2; ++g4) {
+                    c1_route(a0, g4, b0, __uint_as_float(gq[4 * tile + g4] << 16), d0, gb0);
+                    c1_route(a1, g4, b1, __uint_as_float(gq[4 * tile + g4] & 0xffff0000u), d1, gb1);
+                }
                 const u32x4 db0 = {pack_bf2(d0[8 * s2], d0[8 * s2 + 1]), pack_bf2(d0[8 * s2 + 2], d0[8 * s2 + 3]),
                                    pack_bf2(d0[8 * s2 + 4], d0[8 * s2 + 5]), pack_bf2(d0[8 * s2 + 6], d0[8 * s2 + 7])};
                 const u32x4 db1 = {pack_bf2(d1[8 * s2], d1[8 * s2 + 1]), pack_bf2(d1[8 * s2 + 2], d1[8 * s2 + 3]),
                                    pack_bf2(d1[8 * s2 + 4], d1[8 * s2 + 5]), pack_bf2(d1[8 * s2 + 6], d1[8 * s2 + 7])};
-                unsigned xv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int rr = (i & 3) + 8 * (i >> 2) + 4 * h + 16 * s2, q = rr & 3;     // tile row = pixel 4 * window + q
-                    xv[i] = sp[(q >> 1) + tkh][2 * (pw0 + (rr >> 2)) + (q & 1) + tkw];
-                }
-                const u32x4 xt = {xv[0] | (xv[1] << 16), xv[2] | (xv[3] << 16), xv[4] | (xv[5] << 16), xv[6] | (xv[7] << 16)};
+                const int cb = 2 * (pw0 + h + 4 * s2) + tcb;
+                const u32x4 xt = {c1_pair(tcp[tkh], cb), c1_pair(tcp[tkh + 1], cb), c1_pair(tcp[tkh], cb + 4), c1_pair(tcp[tkh + 1], cb + 4)};
                 gw0 = c1_mfma(xt, db0, gw0);
                 gw1 = c1_mfma(xt, db1, gw1);
             }
         }
+        c1_commit(spb[cur ^ 1], nf);
+        __syncthreads();
     }
     // taps live in rows (r & 3) + 8 (r >> 2) + 4 h: r = 0..3 -> taps 0..3 (h = 0) / 4..7 (h = 1), r = 4, h = 0 -> tap 8
     gb0 += __shfl_xor(gb0, 32); gb1 += __shfl_xor(gb1, 32);
@@ -669,7 +740,8 @@ static int conv1_mfma() {       // LXO_CONV1_MFMA=0: the VALU kernels in bf16 mo
 int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s) {
     if (dt == LXO_BF16 && conv1_mfma()) {
         const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
-        hipLaunchKernelGGL(conv1_pool_fwd_mfma_kernel, dim3(grid_for((long long)B * Hp * ((Wp + C1_SEG - 1) / C1_SEG), 1, 4096)), dim3(256), 0, s,
+        static int capf = -1; if (capf < 0) { const char* e = getenv("LXO_C1_CAPF"); capf = e ? atoi(e) : 4096; }
+        hipLaunchKernelGGL(conv1_pool_fwd_mfma_kernel, dim3(grid_for((long long)B * Hp * ((Wp + C1_SEG - 1) / C1_SEG), 1, capf)), dim3(256), 0, s,
                            img, w, b, (bf16_t*)out, B, H, W, Hp, Wp);
         return (int)hipGetLastError();
     }
