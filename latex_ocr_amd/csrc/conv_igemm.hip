@@ -621,7 +621,7 @@ constexpr int WPATCHB = WPSLOTS * 16;                                  // 45056
 // optional operands behind run-time branches hipcc put `s_waitcnt vmcnt(0)` into every row iteration (it cannot count loads
 // it may or may not have issued), so each 16-byte store waited for the previous one's acknowledgement: in-kernel stamps
 // showed 6.3 k cycles per 64-row pass, 32 k per tile -- a quarter of a conv4 tile, more than half of a conv2 tile.
-template <int NJ, int EPI>
+template <int NJ, int EPI, int PH = 1, int PW = 1>
 __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
     constexpr int WBN = 32 * NJ, WBSTAGE = WBN * CBK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     // a lane holds 4 CONSECUTIVE channels of one pixel per register quad, which is what both epilogues want.
 
     CSTAMP(1 + nk);
-    if constexpr (EPI == 0 || EPI == 2) {
+    if constexpr (EPI == 0 || EPI == 2 || EPI == 4) {
         // ---- plain epilogue (bias, ReLU, bf16): every wave packs its own 64 pixels x WBN channels into a bf16 tile in LDS
         // (8-byte writes of 4 channels), ONE barrier, then the workgroup streams the 256 pixel rows out in 16-byte pieces,
         // rows contiguous across lanes.  One pass instead of four f32 passes through a single 64-row staging tile.
@@ -766,6 +766,55 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         constexpr int CHQ = WBN / 8, RPQ = 256 / CHQ;                   // 16-byte pieces per pixel row, rows per sweep
         const int cq = tid % CHQ;
         bf16_t* const tile0 = Cq + (((long long)b * p.Ho + oy0) * p.Wo + ox0) * p.ldc + n0 + cq * 8;      // 64-bit once; 32-bit offsets per row
+        if constexpr (EPI == 4) {
+            // ---- fused max pool (encoder.py:39,47,52): the activated bf16 tile is complete in LDS; a thread takes 16-byte pieces of
+            // POOLED pixels, reads the ph x pw pieces of the window, keeps the first maximum in scan order (what the separate pool
+            // kernels do) and writes the pooled piece plus one mask byte per element (position | 4 if the maximum is positive).
+            // The backward pass routes by the mask, so the full-resolution activation is written only if somebody asked for it.
+            constexpr int ph = PH, pw = PW;                                  // compile-time window: the loops below unroll, no per-element branches
+            const int Hq = (p.Ho + ph - 1) / ph, Wq = (p.Wo + pw - 1) / pw;
+            constexpr int tqw = QTW / pw, npool = (QTH / ph) * tqw;          // pooled pixels of the tile: QTH % ph == QTW % pw == 0
+            constexpr int NPP = npool * CHQ / 256;                           // pooled 16-byte pieces per thread
+            bf16_t* __restrict__ Pq = reinterpret_cast<bf16_t*>(p.pool_out);
+            unsigned char* __restrict__ Mq = p.pool_mask;
+#pragma unroll
+            for (int it = 0; it < NPP; ++it) {
+                const int pp = tid + 256 * it;
+                const int pq = pp / CHQ, cqq = pp - pq * CHQ;
+                const int pty = pq / tqw, ptx = pq - pty * tqw;
+                const int oyq = oy0 / ph + pty, oxq = ox0 / pw + ptx;
+                u32x4 w4[ph * pw];
+#pragma unroll
+                for (int q = 0; q < ph * pw; ++q)
+                    w4[q] = *reinterpret_cast<const u32x4*>(bt + ((pty * ph + q / pw) * QTW + ptx * pw + q % pw) * BP + cqq * 16);
+                float best[8]; int bq[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { best[e] = -3.0e38f; bq[e] = 0; }
+#pragma unroll
+                for (int q = 0; q < ph * pw; ++q) {
+                    const bool ok = oy0 + pty * ph + q / pw < p.Ho && ox0 + ptx * pw + q % pw < p.Wo;      // SAME pool ignores the padding
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned w = w4[q][e >> 1];
+                        const float v = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+                        const bool up = ok && v > best[e];                   // strict: the first maximum in scan order stays
+                        best[e] = up ? v : best[e]; bq[e] = up ? q : bq[e];
+                    }
+                }
+                if (oyq < Hq && oxq < Wq) {
+                    const long long o = (((long long)b * Hq + oyq) * Wq + oxq) * p.ldc + n0 + cqq * 8;
+                    store8(Pq + o, best);
+                    unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m0 |= (unsigned)(bq[e] | (best[e] > 0.f ? 4 : 0)) << (8 * e);
+                        m1 |= (unsigned)(bq[4 + e] | (best[4 + e] > 0.f ? 4 : 0)) << (8 * e);
+                    }
+                    *reinterpret_cast<u32x2*>(Mq + o) = u32x2{m0, m1};
+                }
+            }
+            if (!p.C) { CSTAMP(2 + nk); return; }
+        }
         u32x4 q4[256 / RPQ];
 #pragma unroll
         for (int it = 0; it < 256 / RPQ; ++it) q4[it] = *reinterpret_cast<const u32x4*>(bt + (tid / CHQ + RPQ * it) * BP + cq * 16);
@@ -965,18 +1014,28 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 4, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
         }
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
         const bool has_add = p.addend || p.out_pre, has_ref = p.relu_ref || p.colsum;
-        const int epi = p.accumulate || (has_add && has_ref) ? 3 : (has_add ? 1 : (has_ref ? (p.relu_ref ? 2 : 3) : 0));      // 2 = the one-pass masked epilogue: needs the reference
+        int epi = p.accumulate || (has_add && has_ref) ? 3 : (has_add ? 1 : (has_ref ? (p.relu_ref ? 2 : 3) : 0));      // 2 = the one-pass masked epilogue: needs the reference
+        if (p.pool_out) {
+            if (epi != 0 || p.N % 128 || !p.pool_mask || p.pool_h < 1 || p.pool_h > 2 || p.pool_w < 1 || p.pool_w > 2 || p.pool_h * p.pool_w == 1) return -2;
+            epi = 4;
+        } else if (!p.C) return -2;
         const dim3 g4(B * tiles_x * tiles_y * (p.N / 128)), g2(B * tiles_x * tiles_y * (p.N / 64));
         if (p.N % 128 == 0) {
             if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 0>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
             else if (epi == 1) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
             else if (epi == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 4 && p.pool_h == 2 && p.pool_w == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 2, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 4 && p.pool_h == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 2, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 4) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 1, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
             else hipLaunchKernelGGL((conv_halo2wg_kernel<4, 3>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
         } else {
             if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 0>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
@@ -984,6 +1043,7 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
         }
         return (int)hipGetLastError();
     }
+    if (p.pool_out || !p.C) return -2;                    // the fused pool lives in conv_halo2wg_kernel only
     static int use_256 = -1;
     if (use_256 < 0) { const char* e = getenv("LXO_CONV_256"); use_256 = (e && e[0] == '0') ? 0 : 1; }
     if (use_halo && use_256 && (p.N % QBN) == 0) {

@@ -22,6 +22,10 @@ struct GemmNT {
     float* colsum;
     float alpha;
     unsigned long long* dbg;   // measurement aid (null = off): conv_halo2wg_kernel stamps its phases here, [workgroup][64] (tools/conv_stamps.py)
+    // fused max pool (conv_halo2wg_kernel, plain epilogue only): pool_out[b][ceil(Ho/ph)][ceil(Wo/pw)][N] = max over the ph x pw window of
+    // the activated tile, pool_mask (one byte per pooled element) = first-max position (qy * pw + qx) | 4 if the maximum is > 0;
+    // C may be null (the full-resolution activation is then never written: nothing else reads it)
+    void* pool_out; unsigned char* pool_mask; int pool_h, pool_w;
 };
 
 // C[I,J] (+)= sum_m A[m,I] * B[m,J]      ("TN": reduction over rows)

@@ -80,6 +80,19 @@ static int conv_fwd(const Plan& P, const void* in, const void* wpk, const float*
     LxoTimed tm("conv_fwd", conv_name(Cin, Cout, valid), 2.0 * g.M * g.N * g.K, st);
     return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
 }
+// fwd + max pool in the conv's epilogue (bf16 mode): writes the pooled activation and the routing mask, not the full-resolution one
+static int conv_fwd_pool(const Plan& P, const void* in, const void* wpk, const float* bias, int H, int W, int Cin, int Cout,
+                         void* pooled, void* mask, int ph, int pw, hipStream_t st) {
+    GemmNT g; memset(&g, 0, sizeof(g));
+    g.A = in; g.Bp = wpk; g.C = nullptr;
+    g.conv = 1; g.H = H; g.W = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.pad = 1;
+    g.M = P.s.B * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
+    g.bias = bias; g.act = 1; g.alpha = 1.f; g.addend_rows = 1;
+    g.pool_out = pooled; g.pool_mask = (unsigned char*)mask; g.pool_h = ph; g.pool_w = pw;
+    LxoTimed tm("conv_fwd", conv_name(Cin, Cout, false), 2.0 * g.M * g.N * g.K, st);
+    return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
+}
 // dgrad: d_in[b,y,x,ci] = sum d_out[b,y+a-padd,x+b-padd,co] * Wd[ci][(a,b,co)], optional ReLU mask of the
 // producing layer's activation (relu_ref, same shape as d_in) and its bias gradient (colsum)
 static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din, int Hout, int Wout, int Cout,
@@ -118,15 +131,23 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
     const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
     void* p1 = P.ws<void>(ws, W_P1);
     RC(lxo_k_conv1_pool_fwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], p1, B, P.s.H, P.s.W, st));
+    const bool pf = P.pool_fused();
+    if (pf) RC(conv_fwd_pool(P, p1, P.pk(wp, K_CONV2_F), prm + P.poff[P_CONV2_B], P.H1, P.W1, 64, 128, P.ws<void>(ws, W_P2), P.ws<void>(ws, W_M2), 2, 2, st));
+    else {
     RC(conv_fwd(P, p1, P.pk(wp, K_CONV2_F), prm + P.poff[P_CONV2_B], P.ws<void>(ws, W_Y2), P.H1, P.W1, 64, 128, false, nullptr, 0, nullptr, st));
     RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y2), P.ws<void>(ws, W_P2), B, P.H1, P.W1, 128, 2, 2, st));
+    }
     RC(conv_fwd(P, P.ws<void>(ws, W_P2), P.pk(wp, K_CONV3_F), prm + P.poff[P_CONV3_B], P.ws<void>(ws, W_Y3), P.H2, P.W2, 128, 256, false, nullptr, 0, nullptr, st));
-    RC(conv_fwd(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.ws<void>(ws, W_Y4), P.H2, P.W2, 256, 256, false, nullptr, 0, nullptr, st));
-    if (!P.cnn) {
+    if (!P.cnn && pf) {
+        RC(conv_fwd_pool(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.H2, P.W2, 256, 256, P.ws<void>(ws, W_P4), P.ws<void>(ws, W_M4), 2, 1, st));
+        RC(conv_fwd_pool(P, P.ws<void>(ws, W_P4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.H4, P.W2, 256, C, P.ws<void>(ws, W_P5), P.ws<void>(ws, W_M5), 1, 2, st));
+    } else if (!P.cnn) {
+        RC(conv_fwd(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.ws<void>(ws, W_Y4), P.H2, P.W2, 256, 256, false, nullptr, 0, nullptr, st));
         RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y4), P.ws<void>(ws, W_P4), B, P.H2, P.W2, 256, 2, 1, st));
         RC(conv_fwd(P, P.ws<void>(ws, W_P4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
         RC(lxo_k_maxpool_fwd(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_P5), B, P.H4, P.W2, C, 1, 2, st));
     } else {
+        RC(conv_fwd(P, P.ws<void>(ws, W_Y3), P.pk(wp, K_CONV4_F), prm + P.poff[P_CONV4_B], P.ws<void>(ws, W_Y4), P.H2, P.W2, 256, 256, false, nullptr, 0, nullptr, st));
         // encoder.py:54-56: conv5 on the un-pooled conv4 output, then the (2,4) stride-2 SAME conv (no activation)
         RC(conv_fwd(P, P.ws<void>(ws, W_Y4), P.pk(wp, K_CONV5_F), prm + P.poff[P_CONV5_B], P.ws<void>(ws, W_Y5), P.H4, P.W2, 256, C, false, nullptr, 0, nullptr, st));
         RC(lxo_k_im2col_s2(dt, P.ws<void>(ws, W_Y5), P.ws<void>(ws, W_COLS), B, P.H4, P.W2, P.H6, P.W5, C, st));
@@ -233,7 +254,8 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
                 RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), st));
                 break;
             }
-            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
             RC(wgrad(P.ws<void>(ws, W_P4), XB[5], gw(P_CONV5_W), P.H4, P.W2, 256, C, false));
             RC(acquire(YB[5]));
             RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, st));
@@ -241,7 +263,8 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         case 4:   // d_y4 = route(d_p4) -> X (cnn: already there, masked) ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> Y (+ db3)
             if (!P.cnn) {
                 RC(acquire(XB[4]));
-                RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
+                if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
+                else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
             }
             RC(wgrad(P.ws<void>(ws, W_Y3), XB[4], gw(P_CONV4_W), P.H2, P.W2, 256, 256, false));
             RC(acquire(YB[4]));
@@ -254,7 +277,8 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
             break;
         case 2:   // d_y2 = route(d_p2) -> X ; wgrad2 ; d_p1 = dgrad2 -> Y
             RC(acquire(XB[2]));
-            RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
             RC(wgrad(P.ws<void>(ws, W_P1), XB[2], gw(P_CONV2_W), P.H1, P.W1, 64, 128, false));
             RC(acquire(YB[2]));
             RC(conv_dgrad(P, X, P.pk(wp, K_CONV2_D), Y, P.H1, P.W1, 128, P.H1, P.W1, 64, false, nullptr, nullptr, st));

@@ -47,6 +47,7 @@ enum WsId {
     // decode-only
     W_DEC_IDS, W_DEC_FLAGS, W_DEC_EMB, W_DEC_ZX, W_DEC_LOGITS, W_BEAM_LP, W_BEAM_PAR, W_BEAM_TMP,
     W_COLS,        // cnn encoder only: im2col of the strided conv [B*H6*W5][8C], reused for its column gradient
+    W_M2, W_M4, W_M5,   // bf16 mode: pool masks of conv2 / conv4 / conv5 (one byte per pooled element; fused conv + pool epilogue)
     W_COUNT
 };
 
@@ -80,6 +81,9 @@ struct Plan {
 
     // bf16 mode: the decoder's d_img GEMM (dimg.hip) applies conv6's ReLU mask and bias-gradient sum in its epilogue and
     // leaves d_y6 (compute dtype) in ws region "d_img"; otherwise the region holds the f32 gradient w.r.t. the encoder output
+    // bf16 mode: conv2 / conv4 / conv5 pool in their own epilogue and leave a routing mask; the full-resolution activations
+    // y2 / y4 / y5 are then never written (LXO_POOL_FUSED=0 restores the separate pool kernels for A/B runs)
+    bool pool_fused() const;
     bool dimg_masked() const { return bf && s.E % 32 == 0; }
     template <class T> T* ws(void* base, WsId id) const { return reinterpret_cast<T*>(static_cast<char*>(base) + woff[id]); }
     const void* pk(const void* base, PackId id) const { return static_cast<const char*>(base) + koff[id]; }

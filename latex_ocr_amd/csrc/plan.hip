@@ -46,6 +46,7 @@ static const char* kWsNames[W_COUNT] = {
     "recb", "gb", "dzb", "carry_h", "dec_tx", "dec_txe",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
     "cols",
+    "m2", "m4", "m5",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
 
@@ -115,6 +116,9 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_COLS] = cnn ? BL * H6 * W5 * 8 * C * esz : 0;
     wb[W_Y6] = BL * R * C * esz;          wb[W_IMG] = BL * R * C * esz;
     wb[W_POS] = (size_t)R * C * f4;
+    wb[W_M2] = bf ? BL * H2 * W2 * 128 : 0;
+    wb[W_M4] = (bf && !cnn) ? BL * H4 * W2 * 256 : 0;
+    wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
     const int nb = s.beam > 1 ? s.beam : 1;
     const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)
     const size_t TB = (size_t)T * B;
@@ -215,6 +219,13 @@ int Plan::validate(char* msg, size_t n) const {
 }
 
 // tf.nn.dropout(., config.dropout) masks of one decoder step (attention_cell.py:72,83)
+bool Plan::pool_fused() const {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LXO_POOL_FUSED"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    static int halo = -1;                                 // the A/B switches that select the older conv kernels (no fused pool there)
+    if (halo < 0) { const char* a = getenv("LXO_CONV_HALO"); const char* b2 = getenv("LXO_CONV_2WG"); halo = ((a && a[0] == '0') || (b2 && b2[0] == '0')) ? 0 : 1; }
+    return bf && v == 1 && halo == 1 && s.C % 128 == 0;
+}
 Drop Plan::drop(int t, int row0) const {
     Drop d = {0u, 1.f, (unsigned)s.dropout_seed, t, row0, s.B};
     if (s.keep_prob > 0.f && s.keep_prob < 1.f) {
