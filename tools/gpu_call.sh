@@ -21,7 +21,7 @@ case $what in
   wstamps)  timeout 300 python tools/wgrad_stamps.py > gpurun_out/${TAG}_wgrad_stamps.log 2>&1; echo "wstamps rc=$?"; tail -12 gpurun_out/${TAG}_wgrad_stamps.log;;
   traffic)  cd /tmp && export TMPDIR=/tmp
             for CNT in FETCH_SIZE WRITE_SIZE; do
-              (timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d $R/gpurun_out/${TAG}_pmc_$CNT -- python $R/tools/pmc_conv.py > $R/gpurun_out/${TAG}_pmc_$CNT.log 2>&1; echo "pmc $CNT rc=$?")
+              (timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $R/gpurun_out/${TAG}_pmc_$CNT -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-secondary > $R/gpurun_out/${TAG}_pmc_$CNT.log 2>&1; echo "pmc $CNT rc=$?")
             done
             cd $R
             F=$(ls gpurun_out/${TAG}_pmc_FETCH_SIZE/*/*_results.db | head -1); Wd=$(ls gpurun_out/${TAG}_pmc_WRITE_SIZE/*/*_results.db | head -1)

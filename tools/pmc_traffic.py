@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Turns the two PMC passes (FETCH_SIZE, WRITE_SIZE; rocprofv3 rocpd sqlite) over tools/pmc_conv.py into
-profiles/conv_nt_traffic.json.  Units/corrections per MI355X_MICROARCH.md section HBM: both counters are in KB;
+"""Turns the two PMC passes (FETCH_SIZE, WRITE_SIZE; rocprofv3 rocpd sqlite) over a few real training steps
+(`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-secondary`, see tools/gpu_call.sh `traffic`) into
+profiles/r02_conv_traffic.json.  Units/corrections per MI355X_MICROARCH.md section HBM: both counters are in KB;
 on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read, so it is doubled; WRITE_SIZE is taken
 as reported (uncalibrated).  Averages are per launch over every dispatch of the conv kernel in the workload
-(10 launch shapes x 3 repetitions)."""
+(the 10 launch shapes of a step x the steps run)."""
 import json, sqlite3, sys
 
 
@@ -22,7 +23,7 @@ def main():
     res = {"kernel": pat, "dispatches": nf, "fetch_size_kb_avg_raw": f, "write_size_kb_avg_raw": w,
            "fetch_bytes_per_launch": 2.0 * f * 1024.0, "write_bytes_per_launch": w * 1024.0,
            "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0,
-           "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported; rocprofv3 --pmc <counter> --kernel-trace -- python tools/pmc_conv.py"}
+           "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported; rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-secondary"}
     json.dump(res, open(out, "w"), indent=1)
     print(res)
 
