@@ -169,15 +169,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     }
     WSTAMP(61);
     // reduce into dW[(tap*Cin + ci)][co]
+    // Every workgroup of a tile adds into the same 73 728 addresses, and all workgroups reach this point together: walking
+    // the taps in the same order made them queue on the same few cache lines (the epilogue cost 70 k cycles, 12 % of the
+    // kernel).  Each workgroup starts at a different tap (the accumulator index stays a compile-time constant: two
+    // unrolled sweeps behind uniform predicates), which spreads the concurrent atomics over nine times as many lines
+    // (stamps: 70 k -> 47 k cycles on conv6, 77 k -> 69 k on conv2 where all 256 workgroups share one tile; the launch time moved
+    // within noise: what remains is the L2 atomic rate for 18.9 M lane-atomics per launch).
     const int co = co0 + wco * 32 + (lane & 31);
     if (co < Cout) {
+        const int rot = (int)(blockIdx.x % 9u);
+        // one per-lane base pointer, wave-uniform element offsets (Cin % 64 == 0: every ci of the tile exists)
+        float* const cbase = p.C + (long long)(ci0 + wci * 32 + 4 * (lane >> 5)) * p.ldc + co;
+        auto emit = [&](const f32x16& a, int t) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int e = 0; e < 16; ++e) atomicAdd(cbase + (t * p.Cin + (e & 3) + 8 * (e >> 2)) * p.ldc, a[e]);
+        };
+        // order rot, rot + 1, ..., 8, 0, ..., rot - 1 with compile-time accumulator indices: two unrolled sweeps, uniform branches
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ci = ci0 + wci * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (ci < p.Cin) atomicAdd(&p.C[((long long)t * p.Cin + ci) * p.ldc + co], acc[t][e]);
-            }
+        for (int t = 0; t < 9; ++t) if (t >= rot) emit(acc[t], t);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) if (t < rot) emit(acc[t], t);
     }
     WSTAMP(62);
 }
