@@ -207,7 +207,9 @@ class Engine(object):
         if ntok_dev is not None:
             if ntok_event is not None:
                 torch.cuda.current_stream(self.device).wait_event(ntok_event)
-            self._ntok_dev = ntok_dev          # keep alive until the kernel has run
+            self._ntok_dev = ntok_dev          # keep alive until the kernel has been enqueued
+            if ntok_dev.is_cuda:               # allocated on the count stream, read on this one: the allocator must not hand the
+                ntok_dev.record_stream(torch.cuda.current_stream(self.device))   # block to a later upload before this kernel ran
             self._ck(self.lib.lxo_ce_loss_fwd_bwd_dev(self.sref(), _p(self.ws), _p(self._formula), _p(self._lengths), _p(ntok_dev),
                                                       self._stream()), "ce_loss_dev")
         else:

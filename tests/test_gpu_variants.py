@@ -1,0 +1,56 @@
+"""-m gpu: differential tests of the kernel generations that sit behind A/B switches.  Each pair computes the same
+mathematics with different kernels, so they must agree far more tightly than either agrees with the f32 oracle:
+
+* fused conv + max pool epilogue with the one-byte routing mask (default)  vs  separate pool kernels that re-read the
+  activation (LXO_POOL_FUSED=0): the same bf16 values are pooled and routed; only the order of f32 atomics differs
+  (whose rounding noise the bf16 mirrors downstream amplify to ~1e-3 of a gradient's largest element);
+* conv1 + pool on the matrix cores (default)  vs  the VALU kernels with f32 weights (LXO_CONV1_MFMA=0): differs by the
+  bf16 rounding of 576 weights;
+* attention row blocks walked in alternating directions (default)  vs  always forward (LXO_ATT_ALT=0): summation order;
+* fused recurrent-step kernels (default)  vs  round 1's split-K kernels (step_kernels = 1).
+Odd image sizes exercise the clipped pool windows of both generations."""
+import os, subprocess, sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp, name, env, h, w, b):
+    out = os.path.join(str(tmp), name + ".npz")
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "variant_dump.py"), out, str(h), str(w), str(b)], env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return dict(np.load(out))
+
+
+def _compare(a, b, loss_rel, min_cos, max_rel):
+    la, lb = a["stats"][0] / a["stats"][1], b["stats"][0] / b["stats"][1]
+    assert a["stats"][1] == b["stats"][1]
+    assert abs(la - lb) <= loss_rel * abs(lb), (la, lb)
+    worst = (1.0, None, 0.0)
+    for k in a:
+        if k == "stats":
+            continue
+        x, y = a[k].reshape(-1).astype(np.float64), b[k].reshape(-1).astype(np.float64)
+        c = float(x @ y) / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-300)
+        r = float(np.abs(x - y).max() / (np.abs(y).max() + 1e-300))
+        if c < worst[0]:
+            worst = (c, k, r)
+        assert c > min_cos and r < max_rel, (k, c, r)
+    return worst
+
+
+@pytest.mark.parametrize("h,w", [(64, 256), (50, 150)])
+def test_kernel_generations_agree(tmp_path, h, w):
+    base = _run(tmp_path, "default", {}, h, w, 4)
+    for name, env, bars in (
+            ("pool_separate", {"LXO_POOL_FUSED": "0"}, (1e-5, 0.99999, 1e-2)),
+            ("conv1_valu", {"LXO_CONV1_MFMA": "0"}, (1e-3, 0.999, 5e-2)),
+            ("att_forward_only", {"LXO_ATT_ALT": "0"}, (1e-5, 0.99999, 1e-2)),
+            ("split_k_steps", {"LXO_STEP_KERNELS": "1"}, (1e-4, 0.9995, 5e-2))):
+        other = _run(tmp_path, name, env, h, w, 4)
+        worst = _compare(base, other, *bars)
+        print("%dx%d default vs %s: worst cosine %.8f (%s, max rel %.2e)" % (h, w, name, worst[0], worst[1], worst[2]))
