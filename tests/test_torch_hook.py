@@ -1,0 +1,87 @@
+"""The getModel() / torch.autograd.Function hook (latex_ocr_amd/model/img2seq_torch.py; reference scaffold
+/root/reference/model/base_torch.py:110-117, img2seq_torch.py:64-83,129-163).  CPU: the module runs the shipped HIP
+sources under hipsim; `-m gpu`: the same checks on the device in bf16."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _batch(n=2, V=11):
+    from latex_ocr_amd import synthetic
+    from latex_ocr_amd.model.utils.image import pad_batch_images
+    from latex_ocr_amd.model.utils.text import pad_batch_formulas
+    imgs, forms = synthetic.make_set(n, 32, 48, V, 2, 5, seed=21)
+    f, l = pad_batch_formulas(forms, V - 2, V - 1)
+    return pad_batch_images(imgs), f, l
+
+
+class _Vocab(object):
+    n_tok = 11
+
+
+class _Cfg(object):
+    dropout = 1.0
+    device = "cuda:0"
+    dims = dict(C=128, E=128, U=128, O=128, D=16)      # small widths: the CPU run interprets every kernel
+
+
+def _checks(model, owner, img, f, l, tol, full):
+    from latex_ocr_amd.model.img2seq_torch import Img2Seq
+    assert isinstance(model, torch.nn.Module) and isinstance(model, Img2Seq)
+    assert [p.numel() for p in model.parameters()] == [model.engine.n_params]
+    # forward = the engine's loss; backward = the engine's gradient buffer
+    loss = model(img, f, l)
+    assert loss.requires_grad and loss.dim() == 0
+    loss.backward()
+    g = model.flat.grad.detach().clone()
+    eng = model.engine
+    eng.forward(img, f); st = eng.loss(l, 1.0 / int(l.sum())).cpu().numpy(); eng.backward()
+    assert abs(float(loss.detach()) - st[0] / st[1]) <= tol * abs(st[0] / st[1])
+    ref = eng.grads.detach().clone()
+    assert float((g - ref).abs().max()) <= tol * float(ref.abs().max())
+    if full:        # a scaled loss scales the gradient (grad_out is honoured)
+        model.flat.grad = None
+        (3.0 * model(img, f, l)).backward()
+        assert float((model.flat.grad - 3.0 * ref).abs().max()) <= 3.0 * tol * float(ref.abs().max())
+    # torch.optim updates the engine's parameters in place; the next forward sees the new weights
+    before = model.flat.detach().clone()
+    owner.getOptimizer("sgd", lr=0.01)
+    l0 = owner.getLoss(img, f, l, training=True)
+    assert float((model.flat.detach() - before).abs().max()) > 0
+    assert model.engine.params.data_ptr() == model.flat.data_ptr()
+    l1 = owner.getLoss(img, f, l, training=False)
+    assert l1 < l0, (l0, l1)
+    if full:        # Adam from torch runs on the same parameter
+        owner.getOptimizer("adam", lr=1e-3)
+        assert owner.getLoss(img, f, l, training=True) == pytest.approx(l1, rel=1e-3)
+        assert owner.getLoss(img, f, l, training=False) < l1
+    views = model.named_views()
+    assert "Decoder/embedding_table" in views and sum(v.numel() for v in views.values()) == model.engine.n_params
+    assert views["Decoder/embedding_table"].data_ptr() >= model.flat.data_ptr()
+
+
+def test_getmodel_hook_under_hipsim():
+    from latex_ocr_amd import _abi
+    from latex_ocr_amd.model.img2seq_torch import Img2SeqModel
+    from simlib import SIM_SO
+    img, f, l = _batch(1)
+    owner = Img2SeqModel(_Cfg(), "/tmp/", _Vocab(), dtype="f32", lib=_abi.bind(ctypes.CDLL(SIM_SO)))
+    owner.device = torch.device("cpu")
+    model = owner.getModel("Img2Seq")
+    with pytest.raises(NotImplementedError):
+        owner.getModel("CNN")
+    _checks(model, owner, img, f, l, 1e-5, full=False)
+
+
+@pytest.mark.gpu
+def test_getmodel_hook_on_device_bf16():
+    from latex_ocr_amd.model.img2seq_torch import Img2SeqModel
+    img, f, l = _batch(4)
+    owner = Img2SeqModel(_Cfg(), "/tmp/", _Vocab(), dtype="bf16")
+    model = owner.getModel("Img2Seq")
+    _checks(model, owner, img, f, l, 2e-2, full=True)          # two bf16 evaluations of the same batch differ only by atomic order
+    ids = model.greedy(img, 10, max_iter=8)
+    assert np.asarray(ids).shape[0] == 4
