@@ -148,6 +148,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {                   // 16 pixels per K-step: row ty = ks>>2, x = (ks&3)*16 + 8h ..
             const int cur = ks & 1;                          // compile-time after unrolling
+            // Two waves share a SIMD's MFMA pipe; with the default (age-based) arbitration one runs ahead and then idles at
+            // the block barrier while the other finishes alone (2 k of a block's 8.3 k cycles in the stamps).  Priority falls
+            // as a wave advances through the block, so the wave that is behind wins the pipe and both arrive together.
+            if (ks == 0) __builtin_amdgcn_s_setprio(3);
+            else if (ks == 2) __builtin_amdgcn_s_setprio(2);
+            else if (ks == 4) __builtin_amdgcn_s_setprio(1);
+            else if (ks == 6) __builtin_amdgcn_s_setprio(0);
             if (ks + 1 < 8) read_ks(ks + 1, rb[cur ^ 1], rd[cur ^ 1]);
             __builtin_amdgcn_sched_barrier(0);              // reads of ks + 1 stay ahead of the MFMAs of ks; nothing is hoisted further (144 accumulator registers)
             const u32x4 bfr = {rb[cur][0][0], rb[cur][0][1], rb[cur][1][0], rb[cur][1][1]};
