@@ -762,40 +762,6 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     if (ntok_dev) inv_ntok = 1.0f / ntok_dev[0];      // data parallel: the global token count arrives by all-reduce, never through the host
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ce_sum = 0.f, n_sum = 0.f;
-    if (Vp <= 512) {
-        // the common vocabulary size: a wave holds its row in registers (8 values per lane, ONE round of unconditional loads
-        // together with the row's length and target), instead of three dependent passes over the row
-        for (int row = blockIdx.x * 4 + wave; row < T * B; row += gridDim.x * 4) {
-            const int t = row / B, b = row - t * B;
-            const float* lg = logits + (long long)row * Vp;
-            CT* dl = dlogits + (long long)row * Vp;
-            float x[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = lg[min(lane + 64 * k, Vp - 1)];
-            const int len_b = lengths[b];
-            int tgt = formula[(long long)b * T + t];
-            tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
-            const bool valid = t < len_b;
-            float m = -3.0e38f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { x[k] = lane + 64 * k < V ? x[k] : -3.0e38f; m = fmaxf(m, x[k]); }
-            m = wave_max(m);
-            float e[8], l = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { e[k] = lane + 64 * k < V ? expf(x[k] - m) : 0.f; l += e[k]; }
-            l = wave_sum(l);
-            const float lse = m + logf(l), scale = (valid ? inv_ntok : 0.f) / l;
-            float xt = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int j = lane + 64 * k;
-                if (j == tgt) xt = x[k];
-                if (j < Vp) dl[j] = from_f32<CT>(e[k] * scale - (j == tgt ? (valid ? inv_ntok : 0.f) : 0.f));
-            }
-            xt = wave_sum(xt);                                       // exactly one lane holds the target's logit
-            if (valid) { ce_sum += lse - xt; n_sum += 1.0f; }
-        }
-    } else
     for (int row = blockIdx.x * 4 + wave; row < T * B; row += gridDim.x * 4) {
         const int t = row / B, b = row - t * B;
         const float* lg = logits + (long long)row * Vp;
@@ -1198,7 +1164,7 @@ int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hi
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
                   const float* ntok_dev, int B, int T, int V, int Vp, hipStream_t st) {
     int g = cdiv(T * B, 4);
-    if (g > 2048) g = 2048;             // one row per wave at the benchmark size: the kernel is a latency chain, not a stream
+    if (g > 512) g = 512;
     if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, inv_ntok, ntok_dev, B, T, V, Vp);
     else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, inv_ntok, ntok_dev, B, T, V, Vp);
     DONE;
