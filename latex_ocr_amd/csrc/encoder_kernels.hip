@@ -519,9 +519,11 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const CT* __restr
 // Pool backward from the mask the fused conv + pool epilogue wrote (conv_igemm.hip, EPI 4): one byte per pooled element,
 // first-max position | 4 if the maximum was positive (ReLU).  Reads d_pooled + the mask instead of re-reading the
 // full-resolution activation (pool 2x2 on conv2: 369 MB instead of 603 MB); every load and store is unconditional in count.
+template <int PH, int PW>
 __global__ __launch_bounds__(256) void maxpool_mask_bwd_kernel(const unsigned char* __restrict__ mask, const bf16_t* __restrict__ dp,
                                                               bf16_t* __restrict__ dyo, float* __restrict__ db,
-                                                              int B, int H, int W, int C, int ph, int pw, int Ho, int Wo) {
+                                                              int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int ph = PH, pw = PW;           // compile-time window: the position loop unrolls into straight-line selects and stores
     __shared__ float dbs[512];
     for (int i = threadIdx.x; i < C; i += 256) dbs[i] = 0.f;
     __syncthreads();
@@ -532,32 +534,49 @@ __global__ __launch_bounds__(256) void maxpool_mask_bwd_kernel(const unsigned ch
     float gb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gb[e] = 0.f;
-    for (int pix = blockIdx.x * ppb + threadIdx.x / cgs; pix < npix; pix += gridDim.x * ppb) {
-        const int row = pix / Wo, ox = pix - row * Wo;
-        const int b = row / Ho, oy = row - b * Ho;
-        const u32x4 g4 = *reinterpret_cast<const u32x4*>(dp + (long long)pix * C + cg * 8);
-        const u32x2 m2 = *reinterpret_cast<const u32x2*>(mask + (long long)pix * C + cg * 8);
-        unsigned gm[4];                                              // d_pooled with the ReLU bit applied, still packed
+    // four pooled pixels per thread and iteration: their loads (unconditional, index clamped) are all requested before the first
+    // store, or the loop is one dependent load -> store round trip per pixel
+    constexpr int UNR = 4;
+    const int stride = gridDim.x * ppb;
+    for (int pix0 = blockIdx.x * ppb + threadIdx.x / cgs; pix0 < npix; pix0 += UNR * stride) {
+        u32x4 g4s[UNR]; u32x2 m2s[UNR];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const unsigned mlo = (m2[d >> 1] >> (16 * (d & 1))) & 0xffu, mhi = (m2[d >> 1] >> (16 * (d & 1) + 8)) & 0xffu;
-            const unsigned lo = (mlo & 4u) ? (g4[d] & 0xffffu) : 0u, hi = (mhi & 4u) ? (g4[d] & 0xffff0000u) : 0u;
-            gm[d] = lo | hi;
-            gb[2 * d] += __uint_as_float(lo << 16); gb[2 * d + 1] += __uint_as_float(hi);
+        for (int u = 0; u < UNR; ++u) {
+            const long long pc = min(pix0 + u * stride, npix - 1);
+            g4s[u] = *reinterpret_cast<const u32x4*>(dp + pc * C + cg * 8);
+            m2s[u] = *reinterpret_cast<const u32x2*>(mask + pc * C + cg * 8);
         }
-        for (int qy = 0; qy < ph; ++qy)
-            for (int qx = 0; qx < pw; ++qx) {
-                const int yy = oy * ph + qy, xx = ox * pw + qx;
-                if (yy >= H || xx >= W) continue;
-                const unsigned q = (unsigned)(qy * pw + qx);
-                u32x4 o;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const unsigned mlo = (m2[d >> 1] >> (16 * (d & 1))) & 3u, mhi = (m2[d >> 1] >> (16 * (d & 1) + 8)) & 3u;
-                    o[d] = (mlo == q ? (gm[d] & 0xffffu) : 0u) | (mhi == q ? (gm[d] & 0xffff0000u) : 0u);
-                }
-                *reinterpret_cast<u32x4*>(dyo + (((long long)b * H + yy) * W + xx) * C + cg * 8) = o;
+        for (int u = 0; u < UNR; ++u) {
+            const int pix = pix0 + u * stride;
+            if (pix >= npix) break;
+            const u32x4 g4 = g4s[u]; const u32x2 m2 = m2s[u];
+            const int row = pix / Wo, ox = pix - row * Wo;
+            const int b = row / Ho, oy = row - b * Ho;
+            unsigned gm[4];                                              // d_pooled with the ReLU bit applied, still packed
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned mlo = (m2[d >> 1] >> (16 * (d & 1))) & 0xffu, mhi = (m2[d >> 1] >> (16 * (d & 1) + 8)) & 0xffu;
+                const unsigned lo = (mlo & 4u) ? (g4[d] & 0xffffu) : 0u, hi = (mhi & 4u) ? (g4[d] & 0xffff0000u) : 0u;
+                gm[d] = lo | hi;
+                gb[2 * d] += __uint_as_float(lo << 16); gb[2 * d + 1] += __uint_as_float(hi);
             }
+#pragma unroll
+            for (int qy = 0; qy < ph; ++qy)
+#pragma unroll
+                for (int qx = 0; qx < pw; ++qx) {
+                    const int yy = oy * ph + qy, xx = ox * pw + qx;
+                    if (yy >= H || xx >= W) continue;
+                    const unsigned q = (unsigned)(qy * pw + qx);
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const unsigned mlo = (m2[d >> 1] >> (16 * (d & 1))) & 3u, mhi = (m2[d >> 1] >> (16 * (d & 1) + 8)) & 3u;
+                        o[d] = (mlo == q ? (gm[d] & 0xffffu) : 0u) | (mhi == q ? (gm[d] & 0xffff0000u) : 0u);
+                    }
+                    *reinterpret_cast<u32x4*>(dyo + (((long long)b * H + yy) * W + xx) * C + cg * 8) = o;
+                }
+        }
     }
     if (db) {
 #pragma unroll
@@ -835,8 +854,13 @@ int lxo_k_maxpool_mask_bwd(const unsigned char* mask, const void* dp, void* dy, 
     if (C % 8 || C > 512 || 256 % (C / 8)) return -2;
     const int Ho = (H + ph - 1) / ph, Wo = (W + pw - 1) / pw;
     const int ppb = 256 / (C / 8);
-    hipLaunchKernelGGL(maxpool_mask_bwd_kernel, dim3(grid_for((long long)B * Ho * Wo, ppb * 8, 2048)), dim3(256), 0, s,
-                       mask, (const bf16_t*)dp, (bf16_t*)dy, db, B, H, W, C, ph, pw, Ho, Wo);
+    const dim3 grid(grid_for((long long)B * Ho * Wo, ppb * 8, 2048));
+#define MB_ARGS mask, (const bf16_t*)dp, (bf16_t*)dy, db, B, H, W, C, Ho, Wo
+    if (ph == 2 && pw == 2) hipLaunchKernelGGL((maxpool_mask_bwd_kernel<2, 2>), grid, dim3(256), 0, s, MB_ARGS);
+    else if (ph == 2 && pw == 1) hipLaunchKernelGGL((maxpool_mask_bwd_kernel<2, 1>), grid, dim3(256), 0, s, MB_ARGS);
+    else if (ph == 1 && pw == 2) hipLaunchKernelGGL((maxpool_mask_bwd_kernel<1, 2>), grid, dim3(256), 0, s, MB_ARGS);
+    else return -2;
+#undef MB_ARGS
     return (int)hipGetLastError();
 }
 int lxo_k_maxpool_relu_bwd(int dt, const void* y, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
