@@ -2,9 +2,10 @@
 "gloo" for the CPU tests).  One process per GPU; samples are independent through encoder,
 decoder and loss, so the only exchanges are (1) the global token count that normalises the
 loss (model/img2seq.py:69-71 takes the mean over ALL unmasked tokens of the batch) and (2)
-the gradient sum.  Gradients are all-reduced in three buckets on a side HIP stream as soon
-as backward has finalised them (decoder first, then conv6-5, then conv4-1), overlapping the
-remaining encoder backward; Adam is replicated.
+the gradient sum.  Gradients are all-reduced in buckets on a side HIP stream as soon as
+backward has finalised them (y_W_o before the recurrence, the rest of the decoder after it,
+then one bucket per encoder layer from conv6 down; conv2 + conv1 last), overlapping the
+remaining backward; Adam is replicated.
 
 The step never synchronises the host: the token count is a sum of host-known integers, so each rank
 uploads its own count at the START of the step and all-reduces it on a dedicated stream while the forward

@@ -66,9 +66,15 @@ class Engine(object):
             if c.value:
                 name = self.lib.lxo_param_name_for(ctypes.byref(probe), i).decode()
                 assert self._offsets[name][:2] == (o.value, c.value), (name, self._offsets[name], o.value, c.value)
-        c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]
+        c3 = self._offsets["Encoder/convolutional_encoder/conv2d_2/kernel"][0]
+        c4 = self._offsets["Encoder/convolutional_encoder/conv2d_3/kernel"][0]
+        c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]       # (the cnn variant's strided conv belongs to layer 5's pass)
+        enc_names = [k for k in self._offsets if k.startswith("Encoder/") and k.endswith("/kernel")]
+        c6 = self._offsets[enc_names[-1]][0]                                          # the VALID conv in front of the decoder
         ywo = self._offsets["Decoder/AttentionCell/rnn/y_W_o"][0]        # the last variable: final before the recurrence runs
-        self.buckets = [(ywo, self.n_params), (first_dec, ywo), (c5, first_dec), (0, c5)]
+        # (range, encoder layers whose backward makes it final): a layer's kernel is final after its own pass, its bias no later
+        self.buckets = [(ywo, self.n_params), (first_dec, ywo)]
+        self.enc_buckets = [((6, 6), (c6, first_dec)), ((5, 5), (c5, c6)), ((4, 4), (c4, c5)), ((3, 3), (c3, c4)), ((2, 1), (0, c3))]
         # optional second stream for the half-batch interleave of the recurrent loop (LXO_DUAL_STREAM=1).
         # Measured slower than one stream in round 1 (18.8 vs 17.3 ms/step).  Round 2 measured why (tools/loop_probe.py,
         # DESIGN.md "launch cost"): the loop is bound by the device-side dependent-launch boundary, not by the host, and
@@ -241,14 +247,15 @@ class Engine(object):
                                                            _p(self.grads), act, st), "decoder_train_bwd_active")
         if phase_hook:
             phase_hook("decoder_bwd")
-        self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
-                                          6, 5, st), "encoder_bwd")
         if comm:
-            comm(*self.buckets[2])
-        self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
-                                          4, 1, st), "encoder_bwd")
-        if comm:
-            comm(*self.buckets[3])
+            # one all-reduce per encoder layer as its gradients become final: only conv2 + conv1 (0.3 MB) are left for the end
+            for (hi, lo), rng in self.enc_buckets:
+                self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
+                                                  hi, lo, st), "encoder_bwd")
+                comm(*rng)
+        else:
+            self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
+                                              6, 1, st), "encoder_bwd")
 
     METHODS = {"adam": 0, "sgd": 1, "adagrad": 2, "rmsprop": 3}
 
