@@ -708,7 +708,13 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
         if (use_halo && p.Cin % 64 == 0 && p.J % 8 == 0 && p.atomic && p.nbatch == 1) return lxo_launch_conv_wgrad(p, s);
         return launch_tn<bf16_t, true, bf16_t, bf16_t>(p, s);
     }
-    if (!a_f32 && !b_f32) return launch_tn<bf16_t, false, bf16_t, bf16_t>(p, s);
+    if (!a_f32 && !b_f32) {
+        static int use_tr = -1;                            // LXO_GEMM_TN_TR=0: the packing kernel for every dense TN GEMM (A/B)
+        if (use_tr < 0) { const char* e = getenv("LXO_GEMM_TN_TR"); use_tr = (e && e[0] == '0') ? 0 : 1; }
+        if (use_tr && p.atomic && p.nbatch == 1 && p.lda % 8 == 0 && p.ldb % 8 == 0 && (p.I + 7) / 8 * 8 <= p.lda && (p.J + 7) / 8 * 8 <= p.ldb &&
+            (((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0) return lxo_launch_gemm_tn_tr(p, s);
+        return launch_tn<bf16_t, false, bf16_t, bf16_t>(p, s);
+    }
     if (a_f32 && !b_f32) return launch_tn<bf16_t, false, float, bf16_t>(p, s);
     if (a_f32 && b_f32) return launch_tn<bf16_t, false, float, float>(p, s);
     return launch_tn<bf16_t, false, bf16_t, float>(p, s);
