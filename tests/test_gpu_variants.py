@@ -7,6 +7,8 @@ mathematics with different kernels, so they must agree far more tightly than eit
 * conv1 + pool on the matrix cores (default)  vs  the VALU kernels with f32 weights (LXO_CONV1_MFMA=0): differs by the
   bf16 rounding of 576 weights;
 * attention row blocks walked in alternating directions (default)  vs  always forward (LXO_ATT_ALT=0): summation order;
+* dense weight-gradient GEMMs with LDS-DMA tiles + transposing reads (default)  vs  the register-packing kernel
+  (LXO_GEMM_TN_TR=0): summation order;
 * fused recurrent-step kernels (default)  vs  round 1's split-K kernels (step_kernels = 1).
 Odd image sizes exercise the clipped pool windows of both generations."""
 import os, subprocess, sys
@@ -50,6 +52,7 @@ def test_kernel_generations_agree(tmp_path, h, w):
             ("pool_separate", {"LXO_POOL_FUSED": "0"}, (1e-5, 0.99999, 1e-2)),
             ("conv1_valu", {"LXO_CONV1_MFMA": "0"}, (1e-3, 0.999, 5e-2)),
             ("att_forward_only", {"LXO_ATT_ALT": "0"}, (1e-5, 0.99999, 1e-2)),
+            ("tn_packing_kernel", {"LXO_GEMM_TN_TR": "0"}, (1e-5, 0.99999, 1e-2)),
             ("split_k_steps", {"LXO_STEP_KERNELS": "1"}, (1e-4, 0.9995, 5e-2))):
         other = _run(tmp_path, name, env, h, w, 4)
         worst = _compare(base, other, *bars)
