@@ -66,7 +66,8 @@ def _checks(model, owner, img, f, l, tol, full):
 def test_getmodel_hook_under_hipsim():
     from latex_ocr_amd import _abi
     from latex_ocr_amd.model.img2seq_torch import Img2SeqModel
-    from simlib import SIM_SO
+    from simlib import SIM_SO, build_sim
+    build_sim()                                     # make (no-op when tests/hipsim/build is current)
     img, f, l = _batch(1)
     owner = Img2SeqModel(_Cfg(), "/tmp/", _Vocab(), dtype="f32", lib=_abi.bind(ctypes.CDLL(SIM_SO)))
     owner.device = torch.device("cpu")
