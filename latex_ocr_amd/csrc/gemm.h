@@ -54,6 +54,9 @@ int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_st
 // bf16 3x3 implicit-GEMM convolution, 256x128x64 tiles, LDS-DMA double buffering (conv_igemm.hip)
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s);
 
+// bf16 dense NT GEMM (plain product) with LDS-DMA staging (gemm_nt_dma.hip); -2 if the call does not qualify
+int lxo_launch_gemm_nt_dma(const GemmNT& p, int c_f32, hipStream_t s);
+
 // bf16 dense TN GEMM with row-major LDS tiles and transposing LDS reads (gemm_tn_tr.hip); -2 if the operands do not qualify
 int lxo_launch_gemm_tn_tr(const GemmTN& p, hipStream_t s);
 
