@@ -688,7 +688,7 @@ int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p,
         return launch_nt<bf16_t, false, float, float, 64, 64>(p, s);
     }
     const bool k64 = p.K % 64 == 0;
-    if (!a_f32 && k64 && plain && !p.bias && !p.accumulate && p.act == 0 && p.alpha == 1.f && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
+    if (!a_f32 && k64 && plain && !p.accumulate && p.act == 0 && p.alpha == 1.f && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
         (((uintptr_t)p.A | (uintptr_t)p.Bp) & 15) == 0) {
         static int use_dma = -1;                           // LXO_GEMM_NT_DMA=0: the register-staged kernel for every dense NT GEMM (A/B)
         if (use_dma < 0) { const char* e = getenv("LXO_GEMM_NT_DMA"); use_dma = (e && e[0] == '0') ? 0 : 1; }

@@ -5,8 +5,8 @@
 // LDS-DMA, two stages of 32 KB, the DMA of K-step k+1 in flight under the MFMAs of K-step k; a tile row is 128 bytes = eight
 // 16-byte chunks, stored XOR-swizzled by ((row >> 1) & 7) so that the 16-byte fragment reads of 32 consecutive rows spread
 // over all banks (the weight-stage layout of conv_halo2wg_kernel).  128 x 128 output tile, 4 waves as 2 x 2, each
-// 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.  Plain product only (no bias / activation): the fused epilogues stay
-// with gemm_nt_kernel.
+// 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.  Product + optional per-column bias only: the fused epilogues (activation,
+// addend, masks) stay with gemm_nt_kernel.
 #include "gemm.h"
 #include "api_util.h"
 
@@ -93,21 +93,22 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int n = n0 + wn * 64 + b * 32 + (lane & 31);
+        const float bias = p.bias ? p.bias[n < p.N ? n : 0] : 0.f;      // per output column (the LSTM bias of the x-part)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m < p.M && n < p.N) C[(long long)m * p.ldc + n] = from_f32<OT>(acc[a][b][e]);
+                if (m < p.M && n < p.N) C[(long long)m * p.ldc + n] = from_f32<OT>(acc[a][b][e] + bias);
             }
     }
 }
 
 }  // namespace
 
-// plain product, bf16 A and B (16-byte aligned, pitches multiples of 8), K % 64 == 0; c_f32 selects the output type
+// product (+ bias), bf16 A and B (16-byte aligned, pitches multiples of 8), K % 64 == 0; c_f32 selects the output type
 int lxo_launch_gemm_nt_dma(const GemmNT& p, int c_f32, hipStream_t s) {
-    if (p.conv || p.bias || p.addend || p.relu_ref || p.out_pre || p.colsum || p.accumulate || p.act || p.alpha != 1.f) return -2;
+    if (p.conv || p.addend || p.relu_ref || p.out_pre || p.colsum || p.accumulate || p.act || p.alpha != 1.f) return -2;
     if (p.K % 64 || p.lda % 8 || p.ldb % 8 || (((uintptr_t)p.A | (uintptr_t)p.Bp) & 15)) return -2;
     {   // per device, not per process (see conv_igemm.hip attr_needed)
         static bool done[64] = {};

@@ -69,7 +69,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     const int wid[6] = {P_CONV1_W, P_CONV2_W, P_CONV3_W, P_CONV4_W, P_CONV5_W, P_CONV6_W};
     for (int i = 0; i < 6; ++i) { convCin[i] = ci[i]; convCout[i] = co[i]; convW[i] = wid[i]; convB[i] = wid[i] + 1; }
     Vp = (V + 31) / 32 * 32;
-    Dp = (D + 31) / 32 * 32;
+    Dp = (D + 63) / 64 * 64;              // embedding rows padded to the 64-element K-step of the LDS-DMA GEMM (zero columns)
     Rp = (R + 7) / 8 * 8;
     XH = O + U; HC = U + C; OFF_HT = O + U; OFF_CTX = O + 2 * U; REC = O + 2 * U + C;
     const int WPAD = 128;
