@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Pins the DECODER half of the oracle (and the training graph end to end) to REFERENCE CODE ACTUALLY RUN HERE.
+
+tensorflow==1.12.2 cannot be installed in this container, but the reference's graph-BUILDING code is plain Python
+over ~70 `tf.*` symbols.  tests/tfshim/tensorflow is an eager torch-CPU stand-in for exactly those symbols; this
+script puts it on sys.path and imports the reference's UNCHANGED modules
+
+    /root/reference/model/img2seq.py:42-123      Img2SeqModel.build_base_component (placeholders, loss), add_optimizer
+    /root/reference/model/encoder.py:17-68       Encoder.__call__
+    /root/reference/model/components/positional.py:10-65
+    /root/reference/model/decoder.py:24-105      Decoder.__call__ (train graph via dynamic_rnn + decode graph)
+    /root/reference/model/components/attention_mechanism.py:7-153
+    /root/reference/model/components/attention_cell.py:11-102
+    /root/reference/model/components/dynamic_decode.py:17-74
+    /root/reference/model/components/greedy_decoder_cell.py:9-70
+    /root/reference/model/components/beam_search_decoder_cell.py:43-391
+
+feeds them the oracle's seed-0 weights (under the variable names the reference's scoping produces -- a mismatch with
+SURVEY Appendix B raises) and seeded synthetic crops, and writes tests/golden/ref_decoder.npz:
+train logits, loss / ce_words / n_words, the gradient of the loss w.r.t. every variable (autograd through the
+reference's forward code; per tensor: norm, sum, strided sample), greedy ids + logits, beam ids + parents +
+finished flags (k = 2, 3 with the diversity penalty, 5), the 5-step Adam loss trajectory of add_optimizer, and the
+variable names the graph code requested.  tests/test_oracle.py holds oracle/ref_model.py to these numbers.
+
+What remains RESTATED (TF primitives, tests/tfshim/tensorflow/__init__.py lists them): LSTMCell arithmetic, the
+conv / pool / dense / softmax / top_k / argmax / dropout / cross-entropy ops themselves, optimizer update formulas.
+Build container only: /root/reference does not exist on the GPU box; tests read the committed .npz.
+
+    python tests/golden/make_ref_decoder_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, "tests", "tfshim"))
+for name in ("nltk", "distance"):                       # model/evaluation/text.py:4-5, unused on this path
+    sys.modules.setdefault(name, types.ModuleType(name))
+
+import tensorflow as tf                                  # noqa: E402  (the stand-in)
+assert tf.__version__.endswith("shim")
+from model.img2seq import Img2SeqModel                   # noqa: E402  (the reference's modules)
+from model.utils.general import Config                   # noqa: E402
+from model.components import beam_search_decoder_cell as REF_BEAM   # noqa: E402
+from oracle import ref_model as R                        # noqa: E402
+from latex_ocr_amd import synthetic                      # noqa: E402
+from latex_ocr_amd.model.utils.image import pad_batch_images       # noqa: E402
+from latex_ocr_amd.model.utils.text import pad_batch_formulas      # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refgold                                           # noqa: E402
+from refgold import perturbed_params                     # noqa: E402
+
+
+class VocabStub(object):
+    def __init__(self, V):
+        self.n_tok, self.id_pad, self.id_end = V, V - 2, V - 1      # model/utils/text.py:12,60-61
+
+
+def model_config(decoding, max_len, beam_size=2, div_gamma=1, div_prob=0):
+    return Config({                                               # configs/model.json
+        "encoder_cnn": "vanilla", "positional_embeddings": True,
+        "attn_cell_config": {"cell_type": "lstm", "num_units": 512, "dim_e": 256, "dim_o": 512, "dim_embeddings": 80},
+        "decoding": decoding, "beam_size": beam_size, "div_gamma": div_gamma, "div_prob": div_prob,
+        "max_length_formula": max_len})
+
+
+def build(cfg, V, img, formula, lengths, weights=None, lr=1e-3, dropout=1.0):
+    """Runs the reference's build_base_component over the fed batch (eager: building IS running)."""
+    if weights is not None:
+        tf.shim_reset(weights)
+    else:
+        tf.shim_new_graph()
+    tf.feed({"img": img, "formula": formula, "formula_length": lengths, "dropout": np.float32(dropout), "lr": np.float32(lr)})
+    m = object.__new__(Img2SeqModel)            # BaseModel.__init__ only makes directories and a logger
+    m._config, m._vocab = cfg, VocabStub(V)
+    m.build_base_component()
+    return m
+
+
+_TRACE = []
+_orig_step = REF_BEAM.BeamSearchDecoderCell.step
+
+
+def _traced_step(self, time, state, embedding, finished):
+    out = _orig_step(self, time, state, embedding, finished)
+    _TRACE.append((out[0].parents.numpy().copy(), out[0].ids.numpy().copy(), out[3].numpy().copy()))
+    return out
+
+
+REF_BEAM.BeamSearchDecoderCell.step = _traced_step      # observation only: parents never leave `finalize`
+
+
+def grads_summary(m):
+    names = list(tf.shim_variables())
+    gs = torch.autograd.grad(m.loss.t, [tf.shim_variables()[n].t for n in names], retain_graph=True)
+    out = {}
+    for n, g in zip(names, gs):
+        g = g.detach().numpy()
+        key = n.replace("/", "__")
+        flat = g.reshape(-1)
+        out["gnorm__" + key] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        out["gsum__" + key] = np.float64(flat.astype(np.float64).sum())
+        out["gsamp__" + key] = flat[:: max(1, flat.size // 1500)].copy()
+    return out
+
+
+def train_toy_readout(V, out, steps=220, lr=1e-2):
+    """The "toy" weights (tests/refgold.py): only the small read-out subset is trained -- with torch autograd over the
+    oracle's decoder on frozen encoder features; this produces INPUT weights, nothing that is compared."""
+    from collections import OrderedDict
+    H, W = refgold.shape_of(V)
+    imgs, forms = refgold.toy_set(64, H, W, V, 3)
+    img = torch.from_numpy(pad_batch_images(imgs))
+    f, l = pad_batch_formulas(forms, V - 2, V - 1)
+    f, l = torch.from_numpy(f), torch.from_numpy(l)
+    P = perturbed_params(V)
+    with torch.no_grad():
+        enc = R.encoder(P, img)
+    Q = OrderedDict((k, (v.clone().requires_grad_(True) if k in refgold.TOY_TRAINED else v)) for k, v in P.items())
+    opt = torch.optim.Adam([Q[k] for k in refgold.TOY_TRAINED], lr=lr)
+    for s in range(steps):
+        loss, _, _ = R.loss_fn(R.decoder_train(Q, enc, f), f, l)
+        opt.zero_grad(); loss.backward(); opt.step()
+    print("toy read-out V=%d: loss %.4f after %d steps" % (V, float(loss.detach()), steps))
+    for k in refgold.TOY_TRAINED:
+        out["toyw_v%d__%s" % (V, k.replace("/", "__"))] = Q[k].detach().numpy().copy()
+
+
+def case(tag, V, P, imgs, forms, max_len, out, beams, greedy=True):
+    img = pad_batch_images(imgs)
+    f, l = pad_batch_formulas(forms, V - 2, V - 1)
+    out[tag + "img"], out[tag + "formula"], out[tag + "lengths"] = img, f, l
+    # ---- train graph + greedy decode graph
+    m = build(model_config("greedy", max_len), V, img, f, l, weights=P)
+    req = tf.shim_requested()
+    assert set(req) == set(P), (sorted(set(req) ^ set(P)))                 # the reference asked for exactly Appendix B's names
+    for k, shp in req.items():
+        assert shp is None or tuple(shp) == tuple(P[k].shape), (k, shp)
+    out[tag + "train_logits"] = m.pred_train.numpy()
+    out[tag + "loss"] = np.float64(m.loss.numpy())
+    out[tag + "ce_words"] = np.float64(m.ce_words.numpy())
+    out[tag + "n_words"] = np.int64(m.n_words.numpy())
+    for k, v in grads_summary(m).items():
+        out[tag + k] = v
+    if greedy:
+        ids = m.pred_test.ids.numpy()
+        out[tag + "greedy_ids"] = ids
+        out[tag + "greedy_logits"] = m.pred_test.logits.numpy()
+        first_end = [(list(r).index(V - 1) if (V - 1) in r else -1) for r in ids]
+        print(tag, "loss %.6f" % out[tag + "loss"], "greedy", ids.shape, "first END per row", first_end)
+    # ---- beam graphs
+    for k, gamma, prob in beams:
+        del _TRACE[:]
+        mb = build(model_config("beam_search", max_len, k, gamma, prob), V, img, f, l, weights=P)
+        ids = mb.pred_test.ids.numpy()                                     # [B, T', k]
+        btag = "%sbeam%d%s_" % (tag, k, "" if gamma == 1 else "div")
+        out[btag + "ids"] = ids
+        out[btag + "parents"] = np.stack([t[0] for t in _TRACE], axis=1)   # [B, T', k]
+        out[btag + "step_ids"] = np.stack([t[1] for t in _TRACE], axis=1)
+        out[btag + "finished"] = np.stack([t[2] for t in _TRACE], axis=1)
+        out[btag + "gamma_prob"] = np.array([gamma, prob], dtype=np.float64)
+        assert np.array_equal(ids, out[btag + "step_ids"])                 # quirk C-1: finalize never follows parents
+        par = out[btag + "parents"]
+        print(btag, ids.shape, "finished beams at the last step %d / %d" % (out[btag + "finished"][:, -1].sum(), ids.shape[0] * k),
+              "non-identity parents %d" % (par[:, 1:] != np.arange(k)[None, None, :]).sum())
+
+
+def adam_trajectory(tag, V, out, steps=5, clip=-1.0):
+    """img2seq.py:85-123 add_optimizer on a fresh graph per batch (variables and Adam slots persist)."""
+    imgs, forms = synthetic.make_set(4 * steps, 32, 128, V, 5, 12, seed=77)
+    P = perturbed_params(V)
+    losses = []
+    for s in range(steps):
+        img = pad_batch_images(imgs[4 * s:4 * s + 4])
+        f, l = pad_batch_formulas(forms[4 * s:4 * s + 4], V - 2, V - 1)
+        m = build(model_config("greedy", 2), V, img, f, l, weights=P if s == 0 else None, lr=1e-3)
+        losses.append(float(m.loss.numpy()))
+        m.add_optimizer("adam", m.lr, m.loss, clip)          # eager: minimize() applies the update now
+    out[tag + "losses"] = np.array(losses, dtype=np.float64)
+    out[tag + "clip"] = np.float64(clip)
+    fin = tf.shim_variables()
+    out[tag + "final_y_W_o"] = fin["Decoder/AttentionCell/rnn/y_W_o"].numpy().copy()
+    out[tag + "final_conv0_sample"] = fin["Encoder/convolutional_encoder/conv2d/kernel"].numpy().reshape(-1)[::7].copy()
+    print(tag, "losses", losses)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    out = {"bias_seed": np.int64(refgold.BIAS_SEED)}
+    for V in (11, 50):
+        train_toy_readout(V, out)
+    for V in (11, 50):
+        H, W = refgold.shape_of(V)
+        # (1) random-initialisation regime: train graph + gradients; at V = 50 also decode to the step bound of the
+        #     reference's own max_length_formula = 150 (nothing finishes: at most 152 steps, dynamic_decode.py:49-51)
+        imgs, forms = synthetic.make_set(3 if V == 11 else 4, H, W, V, 3 if V == 11 else 5, 7 if V == 11 else 12, seed=5 if V == 11 else 6)
+        case("v%d_init_" % V, V, perturbed_params(V), imgs, forms, 12 if V == 11 else 150, out,
+             beams=[(2, 1, 0)] if V == 50 else [], greedy=(V == 50))
+        # (2) "toy" weights: varied tokens, END at staggered steps, finished-beam masking, parents that move
+        imgs, forms = refgold.toy_set(6, H, W, V, 9)
+        case("v%d_toy_" % V, V, refgold.toy_params(V, out), imgs, forms, 30, out,
+             beams=[(2, 1, 0), (3, 0.7, 1.0), (5, 1, 0)])
+    adam_trajectory("adam_", 50, out)
+    adam_trajectory("adamclip_", 50, out, steps=3, clip=0.5)
+    out["variable_names"] = np.array(sorted(tf.shim_requested()))
+    np.savez_compressed(os.path.join(HERE, "ref_decoder.npz"), **out)
+    print("wrote ref_decoder.npz: %d arrays, %.1f KB" % (len(out), os.path.getsize(os.path.join(HERE, "ref_decoder.npz")) / 1e3))
+
+
+if __name__ == "__main__":
+    main()
