@@ -606,16 +606,29 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
 
 
 // ------------------------------------------------------------------------------------------
-// Two-workgroups-per-CU variant (the default for layers with Cout % 128 == 0; LXO_CONV_2WG=0 falls back): the same 8 x 32
-// pixel halo tile, but 128 channels wide, FOUR waves (each 2 tile rows x 128 channels = 2 x 4 MFMA
-// blocks, the same 0.75 ds_read_b128 per MFMA and 32 MFMAs per barrier) and 76 KB of LDS (ONE patch
-// buffer + two 128 x 64 weight stages), so that two workgroups share a CU: the prologue, the patch
-// reload between 64-channel slices and the epilogue of one workgroup run under the MFMAs of the other
-// instead of stalling a lone 160 KB workgroup.
+// Two-workgroups-per-CU variant (the default for layers with Cout % 64 == 0; LXO_CONV_2WG=0 falls back): an 8 x 32 pixel halo
+// tile x 128 (or 64) channels, FOUR waves, 76 KB of LDS, so that two workgroups share a CU and the prologue, the patch reload
+// between 64-channel slices and the epilogue of one run under the MFMAs of the other.
+//
+// Round 3: NO workgroup barrier inside a 64-channel slice.  In-kernel stamps of the round-2 loop (weight stages shared by
+// the four waves: `s_waitcnt vmcnt(0)` + `s_barrier` + the next stage's DMA issue + the first fragment reads at the head of
+// every K-step) showed 2.6 k cycles per K-step against 2 x 1.02 k of MFMA issue for the two waves of a SIMD: the two
+// co-resident workgroups fall into lockstep (the one that lags catches up while the leader sits in its bubble), so the
+// ~550-cycle head of a K-step is paid in full, 36 times per tile.  Now a wave owns one 32-CHANNEL block for ALL 8 tile rows
+// (8 MFMA accumulators of 32 pixels x 32 channels): its weight operand (32 channels x 64 k = 4 KB per tap) is PRIVATE --
+// DMA'd by the wave itself into its own two LDS stages, completion counted with `s_waitcnt vmcnt(4)`, no other wave
+// involved -- and the patch is read-only for the 9 taps of a slice.  The stream of a wave is then fully software-pipelined:
+// stage t+2 is requested when the last fragment of stage t has been read, the first fragments of tap t+1 are read under the
+// last MFMAs of tap t, and the only barriers left are the two around the patch reload (every 9 taps).  9 ds_read_b128 per
+// 8 MFMAs (8 pixel fragments + 1 weight fragment) instead of 6: 56 % of the LDS read rate at full MFMA rate.
+// With 64-channel tiles (conv2's data gradient) the four waves are 2 channel blocks x 2 row halves (4 accumulators each); the
+// two waves of a channel block each keep their own copy of the weights.
 constexpr int WTHR = 256, WPSLOTS = 11 * WTHR;                        // 2816 slots >= 340 * 8
 constexpr int WPATCHB = WPSLOTS * 16;                                  // 45056
+constexpr int WWSTAGE = 32 * CBK * 2;                                  // 4096: one wave's weight stage (32 channels x 64 k)
+constexpr int WLDS = WPATCHB + 4 * 2 * WWSTAGE;                        // 77824
 
-// NJ = 32-channel blocks per wave: 4 -> 128-channel tiles, 2 -> 64-channel tiles (Cout = 64: conv2's dgrad)
+// NJ = 32-channel blocks per tile: 4 -> 128-channel tiles, 2 -> 64-channel tiles (Cout = 64: conv2's dgrad)
 // EPI = which fused epilogue is compiled in: 0 bias + activation only; 1 + pre-addend copy + f32 addend (conv6 forward: timing
 // signal); 2 + ReLU mask + bias-gradient column sums (conv4 data gradient); 3 everything, decided at run time.  With the
 // optional operands behind run-time branches hipcc put `s_waitcnt vmcnt(0)` into every row iteration (it cannot count loads
@@ -623,8 +636,10 @@ constexpr int WPATCHB = WPSLOTS * 16;                                  // 45056
 // showed 6.3 k cycles per 64-row pass, 32 k per tile -- a quarter of a conv4 tile, more than half of a conv2 tile.
 template <int NJ, int EPI, int PH = 1, int PW = 1>
 __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
-    constexpr int WBN = 32 * NJ, WBSTAGE = WBN * CBK * 2;
+    constexpr int WBN = 32 * NJ;
+    constexpr int NWM = 4 / NJ, RI = QTH / NWM;                    // waves along the tile rows (1 or 2), tile rows per wave (8 or 4)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % NJ, wm = wave / NJ;                      // this wave's channel block / row group
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
@@ -635,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
     const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
     char* patch0 = lxo_conv_lds;
-    char* bst0 = lxo_conv_lds + WPATCHB;
+    const unsigned wst_off = WPATCHB + wave * 2 * WWSTAGE;         // this wave's two private weight stages
 
     const int sch = tid & 7;
     int a_src[11];
@@ -647,93 +662,133 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         const bool ok = prow < QPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         a_src[j] = ok ? (iy * p.W + ix) * p.Cin + ((sch ^ ((prow >> 1) & 7)) << 3) : -1;
     }
-    const int srow = tid >> 3;                                     // weight rows srow + 32 j, j < NJ (all < N: N % WBN == 0)
-    const bf16_t* b_base = Bp + (long long)(n0 + srow) * p.ldb + ((sch ^ ((srow >> 1) & 7)) << 3);
-    const long long b_step = 32ll * p.ldb;                        // (srow + 32 j) >> 1 & 7 == srow >> 1 & 7
+    // weight rows n0 + wn*32 + r, r = 8 j + (lane >> 3): LDS-DMA writes lane-linearly (1 KB = 8 rows per instruction), the
+    // 16-byte chunk swizzle ((r >> 1) & 7) is applied to the per-lane SOURCE chunk
+    int w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        w_src[j] = (n0 + wn * 32 + r) * p.ldb + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+    }
     auto issue_patch = [&](int c) {                                // 11 LDS-DMA per thread
-        char* dst = patch0 + wave * 1024;
 #pragma unroll
         for (int j = 0; j < 11; ++j) {
             const void* src = a_src[j] >= 0 ? (const void*)(A + a_src[j] + c * CBK) : (const void*)zline;
-            glds16(src, dst + 4096 * j);
+            LXO_GLDS16_HIDDEN(src, lxo_conv_lds, wave * 1024 + 4096 * j);
         }
     };
-    auto issue_b = [&](int t, int stage) {                         // NJ LDS-DMA per thread
-        const int c = t / 9, tap = t - 9 * c;
-        const bf16_t* src = b_base + tap * p.Cin + c * CBK;
-        char* dst = bst0 + stage * WBSTAGE + wave * 1024;
+    auto issue_w = [&](int c, int tap, int stage) {                // 4 LDS-DMA per lane: tap `tap` of slice c into this wave's `stage`
+        const bf16_t* src = Bp + tap * p.Cin + c * CBK;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) glds16(src + j * b_step, dst + 4096 * j);
+        for (int j = 0; j < 4; ++j) LXO_GLDS16_HIDDEN(src + w_src[j], lxo_conv_lds, wst_off + stage * WWSTAGE + 1024 * j);
     };
 
     // The accumulators START as the bias (alpha == 1 for every convolution): its loads overlap the first patch / weight
-    // DMA, and no epilogue has to fetch 64 per-lane bias values with the MFMA results waiting (5.6 k cycles in the stamps).
-    // Layout (MFMA operands swapped, see the K loop): acc[i][j][e] -> channel j*32 + 8*(e>>2) + 4*(lane>>5) + (e&3).
-    f32x16 acc[2][NJ];
+    // DMA, and no epilogue has to fetch per-lane bias values with the MFMA results waiting (5.6 k cycles in the stamps).
+    // Layout (MFMA operands swapped, see the K loop): acc[i][e] -> tile row wm*RI + i, column lane & 31,
+    // channel wn*32 + 8*(e>>2) + 4*(lane>>5) + (e&3).
+    const int khalf = lane >> 5;
+    f32x16 acc[RI];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int k = 0; k < 4; ++k) {
+        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 32 + 8 * k + 4 * khalf);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n0 + j * 32 + 8 * k + 4 * (lane >> 5));
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[0][j][4 * k + e] = bq[e]; acc[1][j][4 * k + e] = bq[e]; }
-        }
+            for (int e = 0; e < 4; ++e) acc[i][4 * k + e] = bq[e];
     }
 
-    const int a_prow0 = (wave * 2) * QPW + (lane & 31);             // this wave's two tile rows
-    const int b_row0 = lane & 31;
-    const int khalf = lane >> 5;
+    const int a_prow0 = (wm * RI) * QPW + (lane & 31);              // patch pixel of this lane for tile row wm*RI, tap (0, 0)
+    const char* const wst = lxo_conv_lds + wst_off;
+    const int w_lane = (lane & 31) * 128 + ((khalf ^ (((lane & 31) >> 1) & 7)) << 4);
 
     const int nchunk = p.Cin / CBK, nk = nchunk * 9;
 #define CSTAMP(i) do { if (p.dbg && tid == 0 && (i) < 64) p.dbg[(long long)bid * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
     CSTAMP(0);
     issue_patch(0);
-    issue_b(0, 0);
-    for (int t = 0; t < nk; ++t) {
-        const int c = t / 9, tap = t - 9 * c;
-        LXO_VMCNT(0);                                              // B(t) (and, at t == 0, the first patch) have landed
-        __builtin_amdgcn_s_barrier();
-        CSTAMP(1 + t);
-        if (tap == 0 && t > 0) {
-            // new 64-channel slice: every wave is past the old patch, so the single buffer can be refilled; the other
-            // workgroup of this CU computes while this one waits for it
-            issue_patch(c);
-            if (t + 1 < nk) { issue_b(t + 1, (t + 1) & 1); LXO_VMCNT(NJ); } else LXO_VMCNT(0);
-            __builtin_amdgcn_s_barrier();
-        } else if (t + 1 < nk) issue_b(t + 1, (t + 1) & 1);
-        const int kh = tap / 3, kw = tap - 3 * kh;
-        const char* bs = bst0 + (t & 1) * WBSTAGE;
-        const int prow_t = a_prow0 + kh * QPW + kw;
-        u32x4 af[2][2], bfr[2][NJ];
-        auto ldfrag = [&](int ks, u32x4 (&a2)[2], u32x4 (&b4)[NJ]) {
-            const int kc = ks * 2 + khalf;
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+
+    // Fragment addresses: chunk index kc = 2 ks + khalf, swizzled by ((row >> 1) & 7); (kc ^ s) << 4 == ((khalf ^ s) << 4) ^ (ks << 5),
+    // so one offset per (tap, tile row) and an XOR per K sub-step.  The offsets are recomputed per tap (5 VALU each) from a
+    // value the optimiser cannot see through: they depend only on the (compile-time) tap, and hoisting all 9 x RI of them out
+    // of the slice loop cost 148 spilled registers.
+    // Register plan: 16 RI accumulators + 4 RI pixel fragments (ONE buffer: fragment i of the next sub-step is requested right
+    // behind the MFMA that consumed fragment i, RI - 1 MFMAs before it is needed) + 2 x 4 weight fragments.
+    u32x4 af[RI], bfr[2];
+    int a_off[RI], w_off = 0;
+    auto a_off_of = [&](int i, int kh, int kw) {
+        int base = a_prow0;
+        asm volatile("" : "+v"(base));
+        const int prow = base + (i + kh) * QPW + kw;
+        return (((prow << 3) + (khalf ^ ((prow >> 1) & 7))) << 4);
+    };
+    auto fill = [&](int stage) {                                    // first fragments of tap 0 of a slice
+        w_off = w_lane + stage * WWSTAGE;
+        bfr[0] = *reinterpret_cast<const u32x4*>(wst + w_off);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int br = b_row0 + 32 * j;
-                b4[j] = *reinterpret_cast<const u32x4*>(bs + br * 128 + ((kc ^ ((br >> 1) & 7)) << 4));
+        for (int i = 0; i < RI; ++i) {
+            a_off[i] = a_off_of(i, 0, 0);
+            af[i] = *reinterpret_cast<const u32x4*>(patch0 + a_off[i]);
+        }
+    };
+
+    LXO_VMCNT(0);
+    __builtin_amdgcn_s_barrier();                                   // the patch is everybody's
+    fill(0);
+    for (int c = 0; c < nchunk; ++c) {
+        const bool last = c + 1 == nchunk;
+        const int par = c & 1;                                      // K-step t = 9 c + tap reads stage (c + tap) & 1
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            CSTAMP(1 + 9 * c + tap);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                bfr[(ks + 1) & 1] = *reinterpret_cast<const u32x4*>(wst + (w_off ^ ((ks + 1) << 5)));
+#pragma unroll
+                for (int i = 0; i < RI; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks & 1]),
+                                                                     __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
+                    af[i] = *reinterpret_cast<const u32x4*>(patch0 + (a_off[i] ^ ((ks + 1) << 5)));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int prow = prow_t + i * QPW;
-                a2[i] = *reinterpret_cast<const u32x4*>(patch0 + prow * 128 + ((kc ^ ((prow >> 1) & 7)) << 4));
+            // sub-step 3: every fragment of this tap has been requested.  Once they have arrived (lgkmcnt(0)) this wave's stage is
+            // free: request the tap after next into it, make sure the NEXT tap's stage has landed (the 4 newest requests may
+            // still fly), and read the next tap's first fragments behind the last 8 MFMAs of this one.
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0)
+            const int tn = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;     // tap after next: same slice, or the next one
+            if (tap + 2 < 9 || !last) { issue_w(tap + 2 < 9 ? c : c + 1, tn, (par + tap) & 1); LXO_VMCNT(4); }
+            else LXO_VMCNT(0);
+            if (tap + 1 < 9) {
+                w_off = w_lane + ((par + tap + 1) & 1) * WWSTAGE;
+                bfr[0] = *reinterpret_cast<const u32x4*>(wst + w_off);
             }
-        };
-        ldfrag(0, af[0], bfr[0]);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) ldfrag(ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks & 1][j]),
-                                                                        __builtin_bit_cast(bf16x8_t, af[ks & 1][i]), acc[i][j], 0, 0, 0);
+            for (int i = 0; i < RI; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[1]),
+                                                                 __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
+                if (tap + 1 < 9) {
+                    a_off[i] = a_off_of(i, (tap + 1) / 3, (tap + 1) % 3);
+                    af[i] = *reinterpret_cast<const u32x4*>(patch0 + a_off[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!last) {
+            // new 64-channel slice: every wave must be past the old patch before the single buffer is refilled; the other
+            // workgroup of this CU computes meanwhile
+            __builtin_amdgcn_s_barrier();
+            issue_patch(c + 1);
+            LXO_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            fill((par + 9) & 1);
         }
     }
     // The MFMA runs with the operand roles swapped (D = W X^T: rows = channels, columns = pixels), so
-    // acc[i][j][e] = pixel (tile row 2*wave + i, column lane & 31), channel j*32 + 8*(e>>2) + 4*khalf + (e&3):
+    // acc[i][e] = pixel (tile row wm*RI + i, column lane & 31), channel wn*32 + 8*(e>>2) + 4*khalf + (e&3):
     // a lane holds 4 CONSECUTIVE channels of one pixel per register quad, which is what both epilogues want.
 
     CSTAMP(1 + nk);
@@ -748,18 +803,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         LXO_LDS_BARRIER();                                              // every wave is past the patch and the weight stages
         CSTAMP(40);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 4; ++k) {
+                float v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * k + e], floor_q);
-                    const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(bt + (wave * 64 + i * 32 + (lane & 31)) * BP + (j * 32 + 8 * k + 4 * khalf) * 2) = pk;
-                }
-        }
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][4 * k + e], floor_q);
+                const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(bt + ((wm * RI + i) * 32 + (lane & 31)) * BP + (wn * 32 + 8 * k + 4 * khalf) * 2) = pk;
+            }
         CSTAMP(41);
         LXO_LDS_BARRIER();
         CSTAMP(42);
@@ -890,16 +942,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     for (int pass = 0; pass < 4; ++pass) {
         LXO_LDS_BARRIER();
         CSTAMP(40 + 3 * pass);
-        if (wave == pass) {
+        // the pass's two tile rows (2 pass, 2 pass + 1) live in accumulators 2 pass - wm RI + {0, 1} of the waves with wm == 2 pass / RI
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+        for (int pp = 0; pp < 4; ++pp) {
+            if (pp == pass && wm == (2 * pp) / RI) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const f32x4 q4 = {acc[i][j][4 * k], acc[i][j][4 * k + 1], acc[i][j][4 * k + 2], acc[i][j][4 * k + 3]};
-                        *reinterpret_cast<f32x4*>(&ot[(i * 32 + (lane & 31)) * OP + j * 32 + 8 * k + 4 * khalf]) = q4;
+                        const int ib = (2 * pp) % RI;          // a constant once the loop is unrolled
+                        const f32x4 q4 = {acc[ib + ii][4 * k], acc[ib + ii][4 * k + 1], acc[ib + ii][4 * k + 2], acc[ib + ii][4 * k + 3]};
+                        *reinterpret_cast<f32x4*>(&ot[(ii * 32 + (lane & 31)) * OP + wn * 32 + 8 * k + 4 * khalf]) = q4;
                     }
+            }
         }
         LXO_LDS_BARRIER();
         CSTAMP(41 + 3 * pass);
@@ -1008,7 +1063,7 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
     static int use_2wg = -1;
     if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }
     if (use_halo && use_2wg && (p.N % 64) == 0 && p.act != 2 && p.alpha == 1.f) {
-        constexpr int LDS4 = WPATCHB + 2 * 128 * CBK * 2, LDS2 = WPATCHB + 2 * 64 * CBK * 2;     // 77824, 61440
+        constexpr int LDS4 = WLDS, LDS2 = WLDS;                                                    // 77824: the patch + four waves' two private weight stages
         if (attr_needed(0)) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round-3 GPU-box driver: bash tools/gpu_r3.sh <tag> <what...>
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1
+for what in "$@"; do
+case $what in
+  refgold)  timeout 600 python -m pytest tests/test_gpu_refgold.py -m gpu -q -s > gpurun_out/${TAG}_refgold.log 2>&1; echo "refgold rc=$?"; grep -E "passed|failed|cosine|bf16|Error|assert" gpurun_out/${TAG}_refgold.log | tail -30;;
+  cstamps)  timeout 300 python tools/conv_stamps.py > gpurun_out/${TAG}_conv_stamps.log 2>&1; echo "cstamps rc=$?";;
+  rstamps)  timeout 300 python tools/rstep_stamps.py > gpurun_out/${TAG}_rstep_stamps.log 2>&1; echo "rstamps rc=$?";;
+  wstamps)  timeout 300 python tools/wgrad_stamps.py > gpurun_out/${TAG}_wgrad_stamps.log 2>&1; echo "wstamps rc=$?";;
+  *) bash tools/gpu_call.sh $TAG $what;;
+esac
+done
