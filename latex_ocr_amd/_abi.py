@@ -10,7 +10,7 @@ c_int, c_ll, c_size, c_float, c_void = ctypes.c_int, ctypes.c_longlong, ctypes.c
 P = ctypes.POINTER
 
 LXO_F32, LXO_BF16 = 0, 1
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")
+LIB_PATH = os.environ.get("LXO_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")   # the override is a measurement aid (diagnostic builds)
 
 
 class LxoShape(ctypes.Structure):

@@ -607,26 +607,49 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
 
 // ------------------------------------------------------------------------------------------
 // Two-workgroups-per-CU variant (the default for layers with Cout % 64 == 0; LXO_CONV_2WG=0 falls back): an 8 x 32 pixel halo
-// tile x 128 (or 64) channels, FOUR waves, 76 KB of LDS, so that two workgroups share a CU and the prologue, the patch reload
-// between 64-channel slices and the epilogue of one run under the MFMAs of the other.
+// tile x 128 (or 64) channels, FOUR waves, 72 KB of LDS, so that two workgroups share a CU and the prologue and the epilogue
+// of one run under the MFMAs of the other.
 //
-// Round 3: NO workgroup barrier inside a 64-channel slice.  In-kernel stamps of the round-2 loop (weight stages shared by
+// Round 3, step 1: NO workgroup barrier inside a channel slice.  In-kernel stamps of the round-2 loop (weight stages shared by
 // the four waves: `s_waitcnt vmcnt(0)` + `s_barrier` + the next stage's DMA issue + the first fragment reads at the head of
 // every K-step) showed 2.6 k cycles per K-step against 2 x 1.02 k of MFMA issue for the two waves of a SIMD: the two
 // co-resident workgroups fall into lockstep (the one that lags catches up while the leader sits in its bubble), so the
 // ~550-cycle head of a K-step is paid in full, 36 times per tile.  Now a wave owns one 32-CHANNEL block for ALL 8 tile rows
-// (8 MFMA accumulators of 32 pixels x 32 channels): its weight operand (32 channels x 64 k = 4 KB per tap) is PRIVATE --
-// DMA'd by the wave itself into its own two LDS stages, completion counted with `s_waitcnt vmcnt(4)`, no other wave
-// involved -- and the patch is read-only for the 9 taps of a slice.  The stream of a wave is then fully software-pipelined:
-// stage t+2 is requested when the last fragment of stage t has been read, the first fragments of tap t+1 are read under the
-// last MFMAs of tap t, and the only barriers left are the two around the patch reload (every 9 taps).  9 ds_read_b128 per
-// 8 MFMAs (8 pixel fragments + 1 weight fragment) instead of 6: 56 % of the LDS read rate at full MFMA rate.
-// With 64-channel tiles (conv2's data gradient) the four waves are 2 channel blocks x 2 row halves (4 accumulators each); the
-// two waves of a channel block each keep their own copy of the weights.
-constexpr int WTHR = 256, WPSLOTS = 11 * WTHR;                        // 2816 slots >= 340 * 8
-constexpr int WPATCHB = WPSLOTS * 16;                                  // 45056
-constexpr int WWSTAGE = 32 * CBK * 2;                                  // 4096: one wave's weight stage (32 channels x 64 k)
-constexpr int WLDS = WPATCHB + 4 * 2 * WWSTAGE;                        // 77824
+// (8 MFMA accumulators of 32 pixels x 32 channels): its weight operand is PRIVATE -- DMA'd by the wave itself into its own
+// LDS stages, completion counted with `s_waitcnt vmcnt(n)`, no other wave involved -- and the patch is read-only for the 9
+// taps of a slice.  The stream of a wave is fully software-pipelined: one pixel-fragment buffer (fragment i of the next
+// sub-step is requested right behind the MFMA that consumed fragment i), the first fragments of tap t+1 are read under the
+// last MFMAs of tap t.  Measured: K-steps 2.6 k -> 2.1 k cycles, but the single-buffered patch reload (barrier, 11 DMA per
+// thread, landing, barrier, first fragments) then stood out at 4 k cycles per slice, 12 % of a conv4 tile.
+// Step 2: 32-channel slices.  The patch of a slice is 27 KB, so TWO fit: slice c+1 lands (one 4 KB piece per tap) while
+// slice c is computed, and the only barrier left is one per slice (144 MFMAs per wave) with nothing to wait for but the other
+// three waves.  A wave's weight stage shrinks to 2 KB (32 channels x 32 k), three of them make a ring that keeps two taps of
+// requests in flight.
+// Step 3: an instruction diet.  A per-CU timeline of the stamps (tools/conv_timeline.py) showed the OLDER of the two
+// workgroups of a CU running a slice in 10.0 k cycles and the younger in 16.4 k against 4.6 k of MFMA issue each: 74 % of the
+// matrix pipe, and diagnostic builds without the weight DMA / the patch DMA / the pixel-fragment reads each gave a piece of
+// it back (8.4 k / 9.2 k / 5.65 k with all three removed).  tools/issue_probe.hip prices the non-matrix instructions: on a
+// SIMD shared by two waves every ds_read_b128 costs ~6 and every LDS-DMA request ~58 cycles of MATRIX-pipe time, and the
+// per-tap address arithmetic (5 VALU per fragment offset for the XOR swizzle, an XOR per second sub-step read, 64-bit adds
+// and a v_readfirstlane per DMA) came to ~5 VALU per MFMA -- VALU and MFMA share one issue port.  So:
+//   * patch pixels are 80 B apart in LDS (64 B of channels + 16 B unused): 16 consecutive pixels x 80 B hit 16 distinct
+//     16-byte slots of the 256-byte bank row (5 is odd), no XOR needed, and EVERY fragment address of a slice is ONE per-lane
+//     register + a compile-time immediate ((row + kh) * 34 + kw) * 80 + 32 ks: zero VALU per read, no offset registers.
+//     LDS-DMA writes lane-linearly, so the layout is produced on the source side: slot q = 5 pixel + chunk, every fifth
+//     slot is a dummy fetch;
+//   * weight requests use the scalar-base form (global_load_lds voff, s[base]): the tile base is wave-uniform SALU
+//     arithmetic, the per-lane byte offsets are two loop-invariant registers, M0 = a scalar + immediate;
+//   * the weight fragment addresses are two loop-invariant registers (+ immediate ring stage).
+// 9 ds_read_b128 per 8 MFMAs (8 pixel fragments + 1 weight fragment).  With 64-channel tiles (conv2's data gradient) the four
+// waves are 2 channel blocks x 2 row halves (4 accumulators each); the two waves of a channel block each keep their own
+// copy of the weights.
+constexpr int WTHR = 256;
+constexpr int WKC = 32;                                               // channels per slice
+constexpr int WPIX = 80;                                              // LDS bytes per patch pixel: 4 chunks of 8 channels + 1 unused
+constexpr int WPUNITS = QPROWS * 5;                                   // 1700 16-byte slots per patch
+constexpr int WPDMA = 7, WPATCHB = WPUNITS * 16;                      // 7 LDS-DMA per thread (the last one partial): 27200 B per patch
+constexpr int WWSTAGE = 32 * WKC * 2, WNST = 3;                       // a wave's weight stage: 32 channels x 32 k = 2048 B; ring of 3
+constexpr int WLDS = 2 * WPATCHB + 4 * WNST * WWSTAGE;                // 78976 (the epilogues need at most 69632)
 
 // NJ = 32-channel blocks per tile: 4 -> 128-channel tiles, 2 -> 64-channel tiles (Cout = 64: conv2's dgrad)
 // EPI = which fused epilogue is compiled in: 0 bias + activation only; 1 + pre-addend copy + f32 addend (conv6 forward: timing
@@ -638,7 +661,8 @@ template <int NJ, int EPI, int PH = 1, int PW = 1>
 __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
     constexpr int WBN = 32 * NJ;
     constexpr int NWM = 4 / NJ, RI = QTH / NWM;                    // waves along the tile rows (1 or 2), tile rows per wave (8 or 4)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches and SALU addressing
     const int wn = wave % NJ, wm = wave / NJ;                      // this wave's channel block / row group
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
@@ -649,38 +673,44 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + (long long)b * p.H * p.W * p.Cin;
     const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
     const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
-    char* patch0 = lxo_conv_lds;
-    const unsigned wst_off = WPATCHB + wave * 2 * WWSTAGE;         // this wave's two private weight stages
+    const unsigned wst_off = 2 * WPATCHB + wave * WNST * WWSTAGE;  // this wave's private weight ring
+    const unsigned m0base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lxo_conv_lds);
 
-    const int sch = tid & 7;
-    int a_src[11];
+    // patch slot s = tid + 256 j holds chunk s % 5 (4 = unused) of pixel s / 5; slots >= WPUNITS do not exist (last piece only)
+    int a_src[WPDMA];
 #pragma unroll
-    for (int j = 0; j < 11; ++j) {
-        const int prow = (tid >> 3) + 32 * j;
+    for (int j = 0; j < WPDMA; ++j) {
+        const int s = tid + WTHR * j;
+        const int prow = s / 5, ch = s - 5 * prow;
         const int py = prow / QPW, px = prow - py * QPW;
         const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
-        const bool ok = prow < QPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        a_src[j] = ok ? (iy * p.W + ix) * p.Cin + ((sch ^ ((prow >> 1) & 7)) << 3) : -1;
+        const bool ok = ch < 4 && prow < QPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        a_src[j] = ok ? (iy * p.W + ix) * p.Cin + (ch << 3) : -1;
     }
-    // weight rows n0 + wn*32 + r, r = 8 j + (lane >> 3): LDS-DMA writes lane-linearly (1 KB = 8 rows per instruction), the
-    // 16-byte chunk swizzle ((r >> 1) & 7) is applied to the per-lane SOURCE chunk
-    int w_src[4];
+    // weight rows n0 + wn*32 + r, r = 16 j + (lane >> 2) (1 KB = 16 rows per instruction), chunk swizzle ((r >> 2) & 3):
+    // per-lane BYTE offsets from the wave-uniform tile base
+    unsigned w_src[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = 8 * j + (lane >> 3);
-        w_src[j] = (n0 + wn * 32 + r) * p.ldb + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * j + (lane >> 2);
+        w_src[j] = (unsigned)(((n0 + wn * 32 + r) * p.ldb + (((lane & 3) ^ ((r >> 2) & 3)) << 3)) * 2);
     }
-    auto issue_patch = [&](int c) {                                // 11 LDS-DMA per thread
-#pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const void* src = a_src[j] >= 0 ? (const void*)(A + a_src[j] + c * CBK) : (const void*)zline;
-            LXO_GLDS16_HIDDEN(src, lxo_conv_lds, wave * 1024 + 4096 * j);
+    auto issue_patch_piece = [&](int c, int buf, int j) {          // piece j (4 KB per workgroup) of slice c into patch buffer buf
+        if (p.diag & 2) c = 0;
+        const void* src = a_src[j] >= 0 ? (const void*)(A + a_src[j] + c * WKC) : (const void*)zline;
+        if (j + 1 < WPDMA) LXO_GLDS16_HIDDEN(src, lxo_conv_lds, buf * WPATCHB + wave * 1024 + 4096 * j);
+        else if (wave * 64 + WTHR * j < WPUNITS) {                 // the partial piece: wave 3 has no slot in it, wave 2 a part of its lanes
+            if (tid + WTHR * j < WPUNITS) LXO_GLDS16_HIDDEN(src, lxo_conv_lds, buf * WPATCHB + wave * 1024 + 4096 * j);
         }
     };
-    auto issue_w = [&](int c, int tap, int stage) {                // 4 LDS-DMA per lane: tap `tap` of slice c into this wave's `stage`
-        const bf16_t* src = Bp + tap * p.Cin + c * CBK;
+    auto issue_patch = [&](int c, int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) LXO_GLDS16_HIDDEN(src + w_src[j], lxo_conv_lds, wst_off + stage * WWSTAGE + 1024 * j);
+        for (int j = 0; j < WPDMA; ++j) issue_patch_piece(c, buf, j);
+    };
+    auto issue_w = [&](int c, int tap, int stage) {                // 2 LDS-DMA per lane: tap `tap` of slice c into this wave's `stage`
+        const bf16_t* sb = (p.diag & 1) ? Bp : Bp + tap * p.Cin + c * WKC;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) LXO_GLDS16_SADDR(w_src[j], sb, lxo_conv_lds, m0base, wst_off + stage * WWSTAGE + 1024 * j);
     };
 
     // The accumulators START as the bias (alpha == 1 for every convolution): its loads overlap the first patch / weight
@@ -699,94 +729,91 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
             for (int e = 0; e < 4; ++e) acc[i][4 * k + e] = bq[e];
     }
 
-    const int a_prow0 = (wm * RI) * QPW + (lane & 31);              // patch pixel of this lane for tile row wm*RI, tap (0, 0)
-    const char* const wst = lxo_conv_lds + wst_off;
-    const int w_lane = (lane & 31) * 128 + ((khalf ^ (((lane & 31) >> 1) & 7)) << 4);
+    // per-lane LDS byte offsets: pixel fragments = a_lane (+ the patch buffer of the slice) + immediate; weight fragments of
+    // sub-step ks = w_lane[ks] + immediate ring stage
+    const int a_lane0 = ((wm * RI) * QPW + (lane & 31)) * WPIX + khalf * 16;
+    int w_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        w_lane[ks] = (int)wst_off + (lane & 31) * 64 + (((2 * ks + khalf) ^ (((lane & 31) >> 2) & 3)) << 4);
 
-    const int nchunk = p.Cin / CBK, nk = nchunk * 9;
+    const int nchunk = p.Cin / WKC;
 #define CSTAMP(i) do { if (p.dbg && tid == 0 && (i) < 64) p.dbg[(long long)bid * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
     CSTAMP(0);
-    issue_patch(0);
+    if (p.dbg && tid == 0) p.dbg[(long long)bid * 64 + 63] = __builtin_amdgcn_s_getreg(63492);      // HW_ID: which CU / SIMD this workgroup landed on
+    issue_patch(0, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
+    issue_w(0, 2, 2);
 
-    // Fragment addresses: chunk index kc = 2 ks + khalf, swizzled by ((row >> 1) & 7); (kc ^ s) << 4 == ((khalf ^ s) << 4) ^ (ks << 5),
-    // so one offset per (tap, tile row) and an XOR per K sub-step.  The offsets are recomputed per tap (5 VALU each) from a
-    // value the optimiser cannot see through: they depend only on the (compile-time) tap, and hoisting all 9 x RI of them out
-    // of the slice loop cost 148 spilled registers.
-    // Register plan: 16 RI accumulators + 4 RI pixel fragments (ONE buffer: fragment i of the next sub-step is requested right
-    // behind the MFMA that consumed fragment i, RI - 1 MFMAs before it is needed) + 2 x 4 weight fragments.
     u32x4 af[RI], bfr[2];
-    int a_off[RI], w_off = 0;
-    auto a_off_of = [&](int i, int kh, int kw) {
-        int base = a_prow0;
-        asm volatile("" : "+v"(base));
-        const int prow = base + (i + kh) * QPW + kw;
-        return (((prow << 3) + (khalf ^ ((prow >> 1) & 7))) << 4);
-    };
-    auto fill = [&](int stage) {                                    // first fragments of tap 0 of a slice
-        w_off = w_lane + stage * WWSTAGE;
-        bfr[0] = *reinterpret_cast<const u32x4*>(wst + w_off);
+    int a_lane = a_lane0;
+    auto fill = [&]() {                                             // first fragments of tap 0 of a slice (weight stage 0)
+        bfr[0] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + w_lane[0]);
 #pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            a_off[i] = a_off_of(i, 0, 0);
-            af[i] = *reinterpret_cast<const u32x4*>(patch0 + a_off[i]);
-        }
+        for (int i = 0; i < RI; ++i) af[i] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + a_lane + i * QPW * WPIX);
     };
 
     LXO_VMCNT(0);
     __builtin_amdgcn_s_barrier();                                   // the patch is everybody's
-    fill(0);
+    fill();
     for (int c = 0; c < nchunk; ++c) {
         const bool last = c + 1 == nchunk;
-        const int par = c & 1;                                      // K-step t = 9 c + tap reads stage (c + tap) & 1
+        CSTAMP(1 + c);
+        // K-step t = 9 c + tap reads weight stage t % 3 = tap % 3
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            CSTAMP(1 + 9 * c + tap);
+            constexpr int NP = WPDMA;
+            const int kh = tap / 3, kw = tap % 3;
+            // sub-step 0: the fragments of sub-step 1 are requested behind the MFMAs that consume their registers
+            bfr[1] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + w_lane[1] + (tap % 3) * WWSTAGE);
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                bfr[(ks + 1) & 1] = *reinterpret_cast<const u32x4*>(wst + (w_off ^ ((ks + 1) << 5)));
-#pragma unroll
-                for (int i = 0; i < RI; ++i) {
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks & 1]),
-                                                                     __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
-                    af[i] = *reinterpret_cast<const u32x4*>(patch0 + (a_off[i] ^ ((ks + 1) << 5)));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int i = 0; i < RI; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[0]),
+                                                                 __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
+                af[i] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + a_lane + ((i + kh) * QPW + kw) * WPIX + 32);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // sub-step 3: every fragment of this tap has been requested.  Once they have arrived (lgkmcnt(0)) this wave's stage is
-            // free: request the tap after next into it, make sure the NEXT tap's stage has landed (the 4 newest requests may
-            // still fly), and read the next tap's first fragments behind the last 8 MFMAs of this one.
-            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0)
-            const int tn = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;     // tap after next: same slice, or the next one
-            if (tap + 2 < 9 || !last) { issue_w(tap + 2 < 9 ? c : c + 1, tn, (par + tap) & 1); LXO_VMCNT(4); }
-            else LXO_VMCNT(0);
-            if (tap + 1 < 9) {
-                w_off = w_lane + ((par + tap + 1) & 1) * WWSTAGE;
-                bfr[0] = *reinterpret_cast<const u32x4*>(wst + w_off);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            // sub-step 1: behind its first MFMA (whose operands prove that every fragment of THIS tap's stage has arrived) the
+            // stage is refilled with the weights three taps ahead: the ring keeps two taps (~2 k cycles) of requests in
+            // flight.  Late in the sub-step: make sure the NEXT tap's stage has landed and read its first weight fragment.
+            const int t3 = tap + 3 < 9 ? tap + 3 : tap + 3 - 9;     // three taps ahead: same slice, or the next one
+            const int kh1 = (tap + 1) / 3, kw1 = (tap + 1) % 3;
 #pragma unroll
             for (int i = 0; i < RI; ++i) {
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[1]),
                                                                  __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
-                if (tap + 1 < 9) {
-                    a_off[i] = a_off_of(i, (tap + 1) / 3, (tap + 1) % 3);
-                    af[i] = *reinterpret_cast<const u32x4*>(patch0 + a_off[i]);
+                if (i == 0 && (tap + 3 < 9 || !last)) issue_w(tap + 3 < 9 ? c : c + 1, t3, tap % 3);
+                if (i == RI - 3) {
+                    // Requests newer than the next tap's weights (issued two taps ago): two taps of weights (none / one near
+                    // the end of the last slice) and the patch pieces issued in the last two taps.  The patch of the NEXT
+                    // slice is requested one piece per tap (taps 0..6), each right behind this wait: `vmcnt` counts in
+                    // order, so a piece gets three taps to land before a wait needs it.  Wave 3 has no share of piece 6.
+                    const int npa = ((tap - 2 >= 0 && tap - 2 < NP) ? 1 : 0) + ((tap - 1 >= 0 && tap - 1 < NP) ? 1 : 0);
+                    const int npb = ((tap - 2 >= 0 && tap - 2 < NP - 1) ? 1 : 0) + ((tap - 1 >= 0 && tap - 1 < NP - 1) ? 1 : 0);
+                    if (tap + 3 < 9 || !last) {
+                        const int np = last ? 0 : (wave == 3 ? npb : npa);
+                        if (np == 0) LXO_VMCNT(4); else if (np == 1) LXO_VMCNT(5); else LXO_VMCNT(6);
+                    } else if (tap + 2 < 9) LXO_VMCNT(2);
+                    else LXO_VMCNT(0);
+                    if (tap + 1 < 9) bfr[0] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + w_lane[0] + ((tap + 1) % 3) * WWSTAGE);
+                    if (tap < NP && !last) issue_patch_piece(c + 1, (c + 1) & 1, tap);
                 }
+                if (tap + 1 < 9) af[i] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + a_lane + ((i + kh1) * QPW + kw1) * WPIX);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (!last) {
-            // new 64-channel slice: every wave must be past the old patch before the single buffer is refilled; the other
-            // workgroup of this CU computes meanwhile
+            // next slice: its patch (requested piece by piece during this one) and its first weight stage have landed once
+            // only the two newest requests (the second and third tap's weights) are outstanding; the barrier makes the other
+            // waves' patch pieces visible and tells that every wave is past the buffer that is refilled next
+            LXO_VMCNT(4);
             __builtin_amdgcn_s_barrier();
-            issue_patch(c + 1);
-            LXO_VMCNT(0);
-            __builtin_amdgcn_s_barrier();
-            fill((par + 9) & 1);
+            a_lane = a_lane0 + ((c + 1) & 1) * WPATCHB;
+            fill();
         }
     }
+    const int nk = nchunk;                                          // stamp slots: 1 + slice
     // The MFMA runs with the operand roles swapped (D = W X^T: rows = channels, columns = pixels), so
     // acc[i][e] = pixel (tile row wm*RI + i, column lane & 31), channel wn*32 + 8*(e>>2) + 4*khalf + (e&3):
     // a lane holds 4 CONSECUTIVE channels of one pixel per register quad, which is what both epilogues want.
@@ -923,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         for (int it = 0; it < 256 / RPQ; ++it) {
             const int row = tid / CHQ + RPQ * it;                       // 0..255: tile row row >> 5, column row & 31
             const int ty = row >> 5, tx = row & 31;
-            if (oy0 + ty < p.Ho && ox0 + tx < p.Wo) *reinterpret_cast<u32x4*>(tile0 + (ty * p.Wo + tx) * p.ldc) = q4[it];
+            if (oy0 + ty < p.Ho && ox0 + tx < p.Wo && !(p.diag & 4)) *reinterpret_cast<u32x4*>(tile0 + (ty * p.Wo + tx) * p.ldc) = q4[it];
         }
         CSTAMP(2 + nk);
         return;
@@ -1057,6 +1084,7 @@ extern "C" int lxo_conv_debug(unsigned long long* buf) { g_conv_dbg = buf; retur
 int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
     GemmNT p = p0;
     p.dbg = g_conv_dbg;
+    { static int diag = -1; if (diag < 0) { const char* e = getenv("LXO_CONV_DIAG"); diag = e ? atoi(e) : 0; } p.diag = diag; }
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
     static int use_halo = -1;
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }

@@ -26,6 +26,7 @@ struct GemmNT {
     // the activated tile, pool_mask (one byte per pooled element) = first-max position (qy * pw + qx) | 4 if the maximum is > 0;
     // C may be null (the full-resolution activation is then never written: nothing else reads it)
     void* pool_out; unsigned char* pool_mask; int pool_h, pool_w;
+    int diag;                  // measurement aid (LXO_CONV_DIAG, wrong results): 1 weights always from slice 0 / tap 0, 2 patch always slice 0, 4 no output stores
 };
 
 // C[I,J] (+)= sum_m A[m,I] * B[m,J]      ("TN": reduction over rows)

@@ -90,6 +90,15 @@ LXO_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
                  : "=&s"(keep_m0_) : "v"(gsrc), "s"(dst_m0_) : "memory"); } while (0)
 #endif
 
+// The same with a SCALAR base and a 32-bit per-lane byte offset (`global_load_lds_dwordx4 voff, s[base]`): when the base is wave-uniform
+// (a weight tile) the request costs no VALU address arithmetic at all.  m0base = readfirstlane of the LDS array's address (taken once);
+// (lds_base, byte_off) name the same destination for the tests/hipsim build.
+#ifndef LXO_GLDS16_SADDR
+#define LXO_GLDS16_SADDR(voff, sbase, lds_base, m0base, byte_off) do { unsigned keep_m0_; \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_m0_) : "v"(voff), "s"(sbase), "s"((m0base) + (unsigned)(byte_off)) : "memory"); } while (0)
+#endif
+
 // dtype codes of the C ABI (include/lxo.h)
 #ifndef LXO_F32
 #define LXO_F32 0

@@ -114,6 +114,7 @@ template <class T> inline T __builtin_amdgcn_readfirstlane_sim(T v) {
 }
 #define __builtin_amdgcn_readfirstlane(v) __builtin_amdgcn_readfirstlane_sim(v)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
+#define __builtin_amdgcn_s_getreg(n) (0u)
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hipsim::wave_sync()
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
@@ -288,6 +289,7 @@ template <class G, class Lp> inline void hipsim_global_load_lds(G g, Lp l, unsig
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipsim_global_load_lds(g, l, size, off, aux)
 // csrc/lxo_common.h: the inline-asm LDS-DMA
 #define LXO_GLDS16_HIDDEN(gsrc, lds_base, byte_off) hipsim_global_load_lds((const void*)(gsrc), (char*)(lds_base) + (byte_off), 16, 0, 0)
+#define LXO_GLDS16_SADDR(voff, sbase, lds_base, m0base, byte_off) hipsim_global_load_lds((const void*)((const char*)(sbase) + (voff)), (char*)(lds_base) + (byte_off), 16, 0, 0)
 
 // ---- host API subset used by the C-ABI layer ----
 inline hipError_t hipGetLastError() { return hipSuccess; }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Measurement aid: per-K-step timestamps of conv_halo2wg_kernel (one launch of conv4 forward: B=64, 32x128, 256 -> 256).
+"""Measurement aid: per-slice timestamps of conv_halo2wg_kernel (one launch of conv4 forward: B=64, 32x128, 256 -> 256).
 For the first workgroups to start on each CU slot: cycles from kernel start to the first K-step (prologue), the gaps between
 consecutive K-step barriers (split by position inside the 9-tap slice), K loop end -> epilogue end."""
 import ctypes, os, sys
@@ -29,19 +29,19 @@ for name, h, w, ci, co in (("conv4 fwd", 32, 128, 256, 256), ("conv2 fwd", 64, 2
     torch.cuda.synchronize()
     raw.lxo_conv_debug(ctypes.c_void_p(0))
     d = dbg.cpu().numpy().reshape(nwg, 64)
-    nk = 9 * ci // 64
-    rel = d[:, :nk + 3] - d[:, :1]
+    ns = ci // 32                                      # 32-channel slices: stamp 1 + c at the head of slice c, 1 + ns after the K loop
+    rel = d[:, :ns + 3] - d[:, :1]
     pro = rel[:, 1]
-    gaps = np.diff(rel[:, 1:nk + 2], axis=1)          # nk gaps: K-step t start -> K-step t+1 start (last: -> K loop end)
-    epi = rel[:, nk + 2] - rel[:, nk + 1]
-    tot = rel[:, nk + 2]
-    print("== %s: %d workgroups, %d K-steps per tile" % (name, nwg, nk))
-    print("   prologue (start -> first K-step)  median %7d  p10 %7d  p90 %7d" % (np.median(pro), np.percentile(pro, 10), np.percentile(pro, 90)))
-    for pos in range(9):
-        g = gaps[:, pos::9].ravel()
-        print("   K-step at tap %d                  median %7d  p10 %7d  p90 %7d" % (pos, np.median(g), np.percentile(g, 10), np.percentile(g, 90)))
+    gaps = np.diff(rel[:, 1:ns + 2], axis=1)          # ns gaps: slice c start -> slice c + 1 start (last: -> K loop end)
+    epi = rel[:, ns + 2] - rel[:, ns + 1]
+    tot = rel[:, ns + 2]
+    print("== %s: %d workgroups, %d slices of 9 taps x 16 MFMAs per tile" % (name, nwg, ns))
+    print("   prologue (start -> first slice)   median %7d  p10 %7d  p90 %7d" % (np.median(pro), np.percentile(pro, 10), np.percentile(pro, 90)))
+    for c in range(ns):
+        g = gaps[:, c]
+        print("   slice %d (144 MFMAs per wave)      median %7d  p10 %7d  p90 %7d" % (c, np.median(g), np.percentile(g, 10), np.percentile(g, 90)))
     print("   epilogue                          median %7d  p10 %7d  p90 %7d" % (np.median(epi), np.percentile(epi, 10), np.percentile(epi, 90)))
-    for col, nm in ((40, "all waves out of the K loop"), (41, "own bf16 tile written"), (42, "all tiles in LDS"), (nk + 2, "rows stored")):
-        v = d[:, col] - d[:, nk + 1]
+    for col, nm in ((40, "all waves out of the K loop"), (41, "own bf16 tile written"), (42, "all tiles in LDS"), (ns + 2, "rows stored")):
+        v = d[:, col] - d[:, ns + 1]
         print("   epilogue: %-28s median %7d  (since this wave left the K loop)" % (nm, np.median(v)))
-    print("   whole tile                        median %7d   (32 MFMA x 32 cycles x %d K-steps = %d cycles of MFMA issue per wave)" % (np.median(tot), nk, 1024 * nk))
+    print("   whole tile                        median %7d   (144 MFMA x 32 cycles x %d slices = %d cycles of MFMA issue per wave)" % (np.median(tot), ns, 4608 * ns))

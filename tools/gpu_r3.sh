@@ -7,6 +7,8 @@ for what in "$@"; do
 case $what in
   refgold)  timeout 600 python -m pytest tests/test_gpu_refgold.py -m gpu -q -s > gpurun_out/${TAG}_refgold.log 2>&1; echo "refgold rc=$?"; grep -E "passed|failed|cosine|bf16|Error|assert" gpurun_out/${TAG}_refgold.log | tail -30;;
   cstamps)  timeout 300 python tools/conv_stamps.py > gpurun_out/${TAG}_conv_stamps.log 2>&1; echo "cstamps rc=$?";;
+  cdiag)    for d in 1 2 4 7; do LXO_CONV_DIAG=$d timeout 300 python tools/conv_stamps.py 2>&1 | grep -v amdgpu | head -17 > gpurun_out/${TAG}_conv_diag$d.log; echo "diag $d rc=$?"; done;;
+  ctimeline) timeout 300 python tools/conv_timeline.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_conv_timeline.log; echo "timeline rc=$?";;
   rstamps)  timeout 300 python tools/rstep_stamps.py > gpurun_out/${TAG}_rstep_stamps.log 2>&1; echo "rstamps rc=$?";;
   wstamps)  timeout 300 python tools/wgrad_stamps.py > gpurun_out/${TAG}_wgrad_stamps.log 2>&1; echo "wstamps rc=$?";;
   *) bash tools/gpu_call.sh $TAG $what;;
