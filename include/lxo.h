@@ -19,7 +19,12 @@ extern "C" {
 #define LXO_BF16 1
 
 const char* lxo_last_error(void);
+/* ABI version of this header.  Bumped whenever lxo_shape grows or an entry point changes (round 3: 3).  A binding must check
+ * lxo_version() == LXO_ABI_VERSION and lxo_shape_size() == sizeof(its own lxo_shape) before the first call: a caller built
+ * against an older header passes a shorter struct and the library would read past its end. */
+#define LXO_ABI_VERSION 3
 int lxo_version(void);
+int lxo_shape_size(void);
 
 /* ---- building blocks (exposed for parity tests and for bindings that want
  *      the encoder / projections alone) ---- */
@@ -129,6 +134,13 @@ size_t lxo_workspace_bytes(const lxo_shape* s);
 /* offset/size of a named workspace region (tests and bindings read activations,
  * logits, loss statistics and attention weights through this) */
 int lxo_ws_region(const lxo_shape* s, const char* name, size_t* offset, size_t* bytes);
+/* element type of a workspace region for this shape: LXO_F32, LXO_BF16, LXO_I32 or LXO_U8 (negative: unknown name).
+ * Matters for "d_img", the hand-over between lxo_decoder_train_bwd and lxo_encoder_bwd: f32 mode = the f32 gradient w.r.t. the
+ * encoder output; bf16 mode = d_y6, that gradient with conv6's ReLU mask already applied, stored as bf16 (and conv6's bias
+ * gradient already accumulated) -- a caller that drives lxo_encoder_bwd on its own must write the region in THAT form. */
+#define LXO_I32 2
+#define LXO_U8 3
+int lxo_ws_region_dtype(const lxo_shape* s, const char* name);
 
 /* refresh the compute-dtype GEMM operand copies from the f32 master parameters
  * (call after every optimizer step / checkpoint load) */
@@ -214,6 +226,18 @@ int lxo_greedy_decode(const lxo_shape* s, const float* params, const void* wpack
  * its tf.py_func hook (attention_mechanism.py:96-105) for visualize_attention.py. */
 int lxo_greedy_decode_attn(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                            int id_end, int max_iter, int32_t* ids_out, float* alpha_out, int* steps_out, void* stream);
+/* The same loops ONE STEP AT A TIME: the calls behind the reference's decoder-cell protocol (dynamic_decode.py:35-36,43-44:
+ * decoder_cell.initialize() / .step(time, state, inputs, finished); greedy_decoder_cell.py:46-66,
+ * beam_search_decoder_cell.py:113-187).  latex_ocr_amd/model/components/ wraps them in cell objects with the reference's
+ * method names.  The cell state (c, h, o, running log-probs, finished flags, the ids fed back) stays in ws.
+ *   lxo_decode_begin: initialize() -- attention set-up and initial states for s->beam hypotheses per image (1 = greedy).
+ *   lxo_decode_step:  step(time) -- writes column `time` of ids_out int32 [B, max_steps(, beam)] (and parents_out, beam only;
+ *     may be NULL), copies the per-row finished flags (int32 [B * beam], 0 / 1, after this step, before the loop's own
+ *     `time >= maximum_iterations` OR) to finished_host and the number of unfinished rows to *unfinished_host (either may be
+ *     NULL; with unfinished_host the call synchronises the stream). */
+int lxo_decode_begin(const lxo_shape* s, const float* params, const void* wpack, void* ws, void* stream);
+int lxo_decode_step(const lxo_shape* s, const float* params, const void* wpack, void* ws, int id_end, int time,
+                    int32_t* ids_out, int32_t* parents_out, int32_t* finished_host, int* unfinished_host, void* stream);
 /* dynamic_decode + BeamSearchDecoderCell (beam_search_decoder_cell.py:98-250),
  * reference-faithful finalize (parents not followed): ids_out int32 [B, max_steps, beam],
  * parents_out same shape (may be NULL). */

@@ -13,6 +13,10 @@ LXO_F32, LXO_BF16 = 0, 1
 LIB_PATH = os.environ.get("LXO_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")   # the override is a measurement aid (diagnostic builds)
 
 
+ABI_VERSION = 3          # include/lxo.h LXO_ABI_VERSION
+LXO_I32, LXO_U8 = 2, 3
+
+
 class LxoShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("B", "H", "W", "T", "V", "C", "E", "U", "O", "D", "dtype", "beam", "max_steps")] + \
                [("keep_prob", c_float), ("dropout_seed", c_int), ("div_gamma", c_float), ("div_prob", c_float), ("div_seed", c_int),
@@ -25,6 +29,8 @@ def bind(lib):
     sig = {
         "lxo_last_error": (ctypes.c_char_p, []),
         "lxo_version": (c_int, []),
+        "lxo_shape_size": (c_int, []),
+        "lxo_ws_region_dtype": (c_int, [S, ctypes.c_char_p]),
         "lxo_gemm_nt": (c_int, [c_int] * 4 + [c_void] * 3 + [c_int] * 6 + [c_void, c_int, c_float, c_int, c_void]),
         "lxo_gemm_tn": (c_int, [c_int] * 3 + [c_void] * 3 + [c_int] * 8 + [c_void]),
         "lxo_conv3x3": (c_int, [c_int, c_void, c_void, c_void, c_void] + [c_int] * 9 + [c_void]),
@@ -60,6 +66,8 @@ def bind(lib):
         "lxo_optimizer_step": (c_int, [c_int, c_ll, c_void, c_void, c_void, c_float, c_void, c_void]),
         "lxo_greedy_decode": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, P(c_int), c_void]),
         "lxo_greedy_decode_attn": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, P(c_int), c_void]),
+        "lxo_decode_begin": (c_int, [S, c_void, c_void, c_void, c_void]),
+        "lxo_decode_step": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, c_void, P(c_int), c_void]),
         "lxo_beam_decode": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, P(c_int), c_void]),
     }
     missing = []
@@ -71,14 +79,19 @@ def bind(lib):
             continue
         fn.restype, fn.argtypes = res, args
     lib._lxo_missing = missing
+    if not missing:
+        # a library built from another revision of include/lxo.h would read past (or short of) the struct this module passes
+        if lib.lxo_version() != ABI_VERSION or lib.lxo_shape_size() != ctypes.sizeof(LxoShape):
+            raise RuntimeError("liblxo ABI mismatch: library version %d / lxo_shape %d bytes, binding version %d / %d bytes"
+                               % (lib.lxo_version(), lib.lxo_shape_size(), ABI_VERSION, ctypes.sizeof(LxoShape)))
     return lib
 
 
-ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_timing_enable", "lxo_timing_count", "lxo_timing_get", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name", "lxo_param_name_for",
+ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_shape_size", "lxo_ws_region_dtype", "lxo_timing_enable", "lxo_timing_count", "lxo_timing_get", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name", "lxo_param_name_for",
                 "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
                 "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_set_side_stream", "lxo_set_encoder_side_stream", "lxo_decoder_train_fwd", "lxo_decoder_train_fwd_active", "lxo_decoder_train_bwd_active",
                 "lxo_ce_loss_fwd_bwd", "lxo_ce_loss_fwd_bwd_dev", "lxo_decoder_train_bwd", "lxo_decoder_train_bwd_part", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",
-                "lxo_greedy_decode", "lxo_greedy_decode_attn", "lxo_beam_decode"]
+                "lxo_greedy_decode", "lxo_greedy_decode_attn", "lxo_beam_decode", "lxo_decode_begin", "lxo_decode_step"]
 
 _lib = None
 

@@ -13,7 +13,8 @@ static int fail(int code, const char* what) {
 #define CHECK_LAUNCH(expr, what) do { int rc_ = (expr); if (rc_ != 0) return fail(rc_, what); } while (0)
 
 extern "C" const char* lxo_last_error(void) { return g_err; }
-extern "C" int lxo_version(void) { return 1; }
+extern "C" int lxo_version(void) { return LXO_ABI_VERSION; }
+extern "C" int lxo_shape_size(void) { return (int)sizeof(lxo_shape); }
 
 extern "C" int lxo_gemm_nt(int dt, int a_f32, int c_f32, int small, const void* A, const void* Bp, void* C,
                            int M, int N, int K, int lda, int ldb, int ldc, const float* bias, int act,
@@ -59,6 +60,24 @@ extern "C" int lxo_ws_region(const lxo_shape* s, const char* name, size_t* offse
             if (bytes) *bytes = P.wbytes[i];
             return 0;
         }
+    return fail(-1, "unknown workspace region");
+}
+extern "C" int lxo_ws_region_dtype(const lxo_shape* s, const char* name) {
+    if (!s || !name) return fail(-1, "lxo_ws_region_dtype");
+    const bool bf = s->dtype == LXO_BF16;
+    static const char* const kCompute[] = {"p1", "y2", "p2", "y3", "y4", "p4", "y5", "p5", "y6", "img", "att_img", "emb_in", "dlogits",
+                                           "d_att_img", "g0", "g1", "g2", "cols", "dec_emb", "dec_txe"};
+    static const char* const kBf16[] = {"recb", "gb", "dzb"};
+    static const char* const kI32[] = {"dec_ids", "dec_flags", "beam_par"};
+    static const char* const kU8[] = {"m2", "m4", "m5"};
+    for (const char* n : kCompute) if (strcmp(name, n) == 0) return bf ? LXO_BF16 : LXO_F32;
+    for (const char* n : kBf16) if (strcmp(name, n) == 0) return LXO_BF16;
+    for (const char* n : kI32) if (strcmp(name, n) == 0) return LXO_I32;
+    for (const char* n : kU8) if (strcmp(name, n) == 0) return LXO_U8;
+    // "d_img": the hand-over from the decoder backward to the encoder backward.  f32 mode: the f32 gradient w.r.t. the encoder
+    // output; bf16 mode: d_y6 (that gradient with conv6's ReLU mask applied, bf16; conv6's bias gradient is already in grads)
+    if (strcmp(name, "d_img") == 0) return bf ? LXO_BF16 : LXO_F32;
+    for (int i = 0; i < W_COUNT; ++i) if (strcmp(name, lxo_ws_name(i)) == 0) return LXO_F32;
     return fail(-1, "unknown workspace region");
 }
 extern "C" int lxo_pack_weights(const lxo_shape* s, const float* params, void* wpack, void* stream) {
@@ -157,6 +176,18 @@ extern "C" int lxo_greedy_decode_attn(const lxo_shape* s, const float* params, c
                                       int id_end, int max_iter, int32_t* ids_out, float* alpha_out, int* steps_out, void* stream) {
     MAKE_PLAN(P, s);
     CHECK_LAUNCH(lxo_impl_greedy_decode(P, params, wpack, ws, id_end, max_iter, ids_out, alpha_out, steps_out, (hipStream_t)stream), "lxo_greedy_decode_attn");
+    return 0;
+}
+extern "C" int lxo_decode_begin(const lxo_shape* s, const float* params, const void* wpack, void* ws, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_decode_begin(P, params, wpack, ws, (hipStream_t)stream), "lxo_decode_begin");
+    return 0;
+}
+extern "C" int lxo_decode_step(const lxo_shape* s, const float* params, const void* wpack, void* ws, int id_end, int time,
+                               int32_t* ids_out, int32_t* parents_out, int32_t* finished_host, int* unfinished_host, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_decode_step(P, params, wpack, ws, id_end, time, ids_out, parents_out, finished_host, unfinished_host, (hipStream_t)stream),
+                 "lxo_decode_step");
     return 0;
 }
 extern "C" int lxo_beam_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT p) {
     issue(0, 0);
     for (int k0 = 0, it = 0; k0 < p.K; k0 += 64, ++it) {        // K % 64 == 0 (checked by the launcher)
         const int stage = it & 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): only this K-step's DMA is outstanding here
+        __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) + lgkmcnt(0): every ds_read of the stage the NEXT DMA overwrites has retired before any wave passes the barrier (gfx950 barriers carry no implicit wait); only this K-step's DMA is outstanding here
         __builtin_amdgcn_s_barrier();
         if (k0 + 64 < p.K) issue(k0 + 64, stage ^ 1);
         const char* sa = lxo_ntdma_lds + stage * NSTAGE;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmTN p) {
     issue(mbeg, 0);
     for (int m0 = mbeg, it = 0; m0 < mend; m0 += TBR, ++it) {
         const int stage = it & 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): only this tile's DMA is outstanding here
+        __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) + lgkmcnt(0): every ds_read of the stage the NEXT DMA overwrites has retired before any wave passes the barrier (gfx950 barriers carry no implicit wait); only this tile's DMA is outstanding here
         __builtin_amdgcn_s_barrier();
         if (m0 + TBR < mend) issue(m0 + TBR, stage ^ 1);
         const char* sb = lxo_tntr_lds + stage * TSTAGE;

@@ -551,6 +551,49 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
     return 0;
 }
 
+// ---- the decode loop one step at a time: what the reference's cell protocol (dynamic_decode.py:34-61: initialize / step /
+// finalize) is bound to.  State (c, h, o, running log-probs, finished flags, previous ids) stays in the workspace. ----
+int lxo_impl_decode_begin(const Plan& P, const float* prm, const void* wp, void* ws, hipStream_t st) {
+    const int B = P.s.B, k = P.s.beam > 1 ? P.s.beam : 1, nv = B * k;
+    if (P.s.max_steps < 1 || k > 16) return -5;
+    RC(attention_prepare(P, prm, wp, ws, k, st));
+    if (fused_steps(P)) RC(mirror_oh(P, ws, 0, nv, st));
+    HIPRC(hipMemsetAsync(P.ws<int>(ws, W_DEC_FLAGS), 0, 256 + (size_t)nv * 4, st));
+    if (k > 1) HIPRC(hipMemsetAsync(P.ws<float>(ws, W_BEAM_LP), 0, (size_t)nv * 4, st));
+    if (fused_steps(P)) RC(decode_token_table(P, prm, wp, ws, st));
+    return 0;
+}
+
+int lxo_impl_decode_step(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int time,
+                         int* ids_out, int* parents_out, int* finished_out, int* unfinished_host, hipStream_t st) {
+    const int B = P.s.B, k = P.s.beam > 1 ? P.s.beam : 1, nv = B * k, ms = P.s.max_steps, U = P.s.U;
+    if (time < 0 || time >= ms) return -5;
+    int* flags = P.ws<int>(ws, W_DEC_FLAGS);
+    int* finished = flags + 64;
+    int* ids_step = P.ws<int>(ws, W_DEC_IDS);
+    HIPRC(hipMemsetAsync(flags, 0, sizeof(int), st));
+    const int cur = (time + 1) & 1;
+    RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st));
+    if (k == 1) {
+        RC(lxo_k_argmax(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, id_end, ids_step, ids_out, ms, time, finished, flags, st));
+    } else {
+        int* par_step = P.ws<int>(ws, W_BEAM_PAR);
+        float* tmp = P.ws<float>(ws, W_BEAM_TMP);
+        float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
+        RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, P.s.div_gamma, P.s.div_prob, P.s.div_seed, tmp,
+                           P.ws<float>(ws, W_BEAM_LP), finished, ids_step, par_step, ids_out, parents_out, ms, flags, st));
+        RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
+                             tmp, tmp + (size_t)nv * P.XH, nv, st));
+        if (fused_steps(P)) RC(mirror_oh(P, ws, (size_t)cur * nv, nv, st));
+    }
+    if (finished_out) HIPRC(hipMemcpyAsync(finished_out, finished, (size_t)nv * 4, hipMemcpyDeviceToHost, st));
+    if (unfinished_host) {
+        HIPRC(hipMemcpyAsync(unfinished_host, flags, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPRC(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
 int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter,
                          int* ids_out, int* parents_out, int* steps_out, hipStream_t st) {
     const int B = P.s.B, k = P.s.beam, ms = P.s.max_steps, nv = B * k, U = P.s.U;

@@ -26,7 +26,10 @@ class DataParallel(object):
         # token-count exchange: its own stream (never queued behind gradient buckets), pinned staging ring
         self.cnt_stream = torch.cuda.Stream(self.device) if self.cuda else None
         self._cnt_pin = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(4)] if self.cuda else None
+        self._cnt_ev = [None] * 4              # event behind each slot's last H2D copy: the host must not rewrite a slot the copy has not read
         self._cnt_i = 0
+        self.grad_dtype = None                 # None = reduce gradients as f32 (34.5 MB); torch.bfloat16 halves the bytes (opt-in, see reduce_range_fn)
+        self.exposed_ms = []                   # (start, end) event pairs around finish(): the all-reduce time the compute stream waited for
 
     def sum_count_async(self, n_local):
         """-> (device float32 tensor [1] holding the sum of n_local over ranks, event or None).  Asynchronous w.r.t. the
@@ -35,11 +38,17 @@ class DataParallel(object):
             t = torch.tensor([float(n_local)], dtype=torch.float32)
             td.all_reduce(t, op=td.ReduceOp.SUM)
             return t, None
-        pin = self._cnt_pin[self._cnt_i % len(self._cnt_pin)]
+        slot = self._cnt_i % len(self._cnt_pin)
         self._cnt_i += 1
+        pin = self._cnt_pin[slot]
+        if self._cnt_ev[slot] is not None:     # a non-syncing caller may run more than 4 steps ahead of the device
+            self._cnt_ev[slot].synchronize()
         pin[0] = float(n_local)
         with torch.cuda.stream(self.cnt_stream):
             t = pin.to(self.device, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.cnt_stream)
+            self._cnt_ev[slot] = copied
             td.all_reduce(t, op=td.ReduceOp.SUM)
             ev = torch.cuda.Event()
             ev.record(self.cnt_stream)
@@ -65,22 +74,52 @@ class DataParallel(object):
         td.barrier()
 
     def reduce_range_fn(self, flat):
-        """-> comm(lo, hi): sum flat[lo:hi] over ranks, asynchronously w.r.t. the compute stream."""
+        """-> comm(lo, hi): sum flat[lo:hi] over ranks, asynchronously w.r.t. the compute stream.
+        With grad_dtype = torch.bfloat16 (LXO_DP_BF16=1; off by default) a bucket travels as bf16 (17.3 MB per step instead
+        of 34.5 MB): rounded once before the sum, summed by the collective in bf16, widened back.  Relative error of a summed
+        gradient element <= (world + 1) * 2^-9 of the largest addend; tests/test_dp_gloo.py states the bound it holds."""
         def comm(lo, hi):
             seg = flat[lo:hi]
             if not self.cuda:
-                td.all_reduce(seg, op=td.ReduceOp.SUM)
+                if self.grad_dtype is not None:
+                    low = seg.to(self.grad_dtype)
+                    td.all_reduce(low, op=td.ReduceOp.SUM)
+                    seg.copy_(low)
+                else:
+                    td.all_reduce(seg, op=td.ReduceOp.SUM)
                 return
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                td.all_reduce(seg, op=td.ReduceOp.SUM)
+                if self.grad_dtype is not None:
+                    low = seg.to(self.grad_dtype)
+                    td.all_reduce(low, op=td.ReduceOp.SUM)
+                    seg.copy_(low)
+                else:
+                    td.all_reduce(seg, op=td.ReduceOp.SUM)
             self._pending = True
         return comm
 
-    def finish(self):
-        """Make the compute stream wait for every bucket before the optimizer reads the gradients."""
+    def finish(self, timed=False):
+        """Make the compute stream wait for every bucket before the optimizer reads the gradients.  timed: bracket the wait
+        with events on the compute stream (bench.py reports the exposed all-reduce time from them)."""
         if self.cuda and self._pending:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            cur = torch.cuda.current_stream(self.device)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.side)
+                e1.record(cur)
+                self.exposed_ms.append((e0, e1))
+            else:
+                cur.wait_stream(self.side)
             self._pending = False
+
+    def exposed_allreduce_ms(self):
+        """Mean milliseconds per step the compute stream spent waiting in finish(timed=True) (call after a synchronize)."""
+        if not self.exposed_ms:
+            return None
+        v = [a.elapsed_time(b) for a, b in self.exposed_ms]
+        self.exposed_ms = []
+        return sum(v) / len(v)

@@ -402,30 +402,6 @@ class Engine(object):
                 flops_tot += flops; t_tot += sec
         return flops_tot, t_tot, out
 
-    def time_attention(self, B, R, reps=20):
-        """HIP-event timing of the attention stream (scores + softmax + context) for B samples."""
-        E, C = self.dims["E"], self.dims["C"]
-        ct = torch.bfloat16 if self.dtype == _abi.LXO_BF16 else torch.float32
-        att_img = torch.randn(B, R, E, dtype=ct, device=self.device)
-        img = torch.randn(B, R, C, dtype=ct, device=self.device)
-        f32 = dict(dtype=torch.float32, device=self.device)
-        att_h = torch.randn(B, E, **f32); beta = torch.randn(E, **f32) * 0.1
-        Rp = (R + 7) // 8 * 8
-        alpha = torch.empty(B, Rp, **f32); part = torch.empty(B * 32 * (C + 2), **f32); ctx = torch.empty(B, C, **f32)
-        st = self._stream()
-        args = (self.dtype, _p(att_img), _p(img), _p(att_h), _p(beta), _p(alpha), _p(part), _p(ctx), C, B, R, E, C, 1, st)
-        for _ in range(3):
-            self._ck(self.lib.lxo_attention_fwd(*args), "attention_fwd")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream(self.device))
-        for _ in range(reps):
-            self._ck(self.lib.lxo_attention_fwd(*args), "attention_fwd")
-        e1.record(torch.cuda.current_stream(self.device))
-        e1.synchronize()
-        sec = e0.elapsed_time(e1) * 1e-3 / reps
-        nbytes = float(B) * R * (E + C) * att_img.element_size()
-        return nbytes, sec
-
     # --------------------------------------------------------------- decode --
     def _encode_only(self, img, beam):
         B, H, W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
@@ -462,6 +438,35 @@ class Engine(object):
         n = steps.value
         a = alpha[:n, :, :R].permute(1, 0, 2).reshape(B, n, Hp, Wp).cpu().numpy()
         return ids[:, :n].cpu().numpy(), a
+
+    # one step at a time: what model/components (the reference's decoder-cell protocol) drives
+    def decode_begin(self, img, beam_size=1, max_steps=152, div_gamma=1.0, div_prob=0.0, div_seed=0):
+        """initialize(): encoder + attention set-up + initial states for beam_size hypotheses per image."""
+        if self.max_steps < max_steps:
+            self.max_steps, self.ws = int(max_steps), None
+        B = self._encode_only(img, int(beam_size))
+        self.shape.div_gamma, self.shape.div_prob = float(div_gamma or 0.0), float(div_prob or 0.0)
+        self.shape.div_seed = int(div_seed) & 0x7FFFFFFF
+        k = max(1, int(beam_size))
+        shp = (B, self.max_steps) if k == 1 else (B, self.max_steps, k)
+        self._dec_ids = torch.zeros(*shp, dtype=torch.int32, device=self.device)
+        self._dec_par = torch.zeros(*shp, dtype=torch.int32, device=self.device) if k > 1 else None
+        self._dec_fin = np.zeros(B * k, dtype=np.int32)
+        self._ck(self.lib.lxo_decode_begin(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), self._stream()), "decode_begin")
+        return B
+
+    def decode_step(self, time, id_end):
+        """step(time): -> (ids [B] or [B, k], parents or None, finished bool [B(, k)], logits f32 [B(, k), V])."""
+        un = ctypes.c_int(0)
+        self._ck(self.lib.lxo_decode_step(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(time),
+                                          _p(self._dec_ids), _p(self._dec_par), self._dec_fin.ctypes.data_as(ctypes.c_void_p),
+                                          ctypes.byref(un), self._stream()), "decode_step")
+        ids = self._dec_ids[:, time].cpu().numpy()
+        par = self._dec_par[:, time].cpu().numpy() if self._dec_par is not None else None
+        fin = self._dec_fin.astype(bool).reshape(ids.shape)
+        Vp = (self.n_tok + 31) // 32 * 32
+        logits = self.region("dec_logits", "f32", (ids.size, Vp))[:, :self.n_tok].cpu().numpy().reshape(ids.shape + (self.n_tok,))
+        return ids, par, fin, logits
 
     def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False, div_gamma=1.0, div_prob=0.0, div_seed=0):
         """ids int32 [B, T', k] as pred_test.ids of the beam graph before the transpose at img2seq.py:241.

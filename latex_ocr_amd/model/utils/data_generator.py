@@ -34,7 +34,7 @@ class DataGenerator(object):
     def __init__(self, path_formulas, dir_images, path_matching, bucket=False,
                  form_prepro=lambda s: s.strip().split(" "), iter_mode="data",
                  img_prepro=lambda x: x, max_iter=None, max_len=None,
-                 bucket_size=20, imread=_imread):
+                 bucket_size=20, imread=_imread, reference_bucket_quirk=True):
         self._path_formulas = path_formulas
         self._dir_images = dir_images
         self._path_matching = path_matching
@@ -46,6 +46,7 @@ class DataGenerator(object):
         self._bucket = bucket
         self._bucket_size = bucket_size
         self._imread = imread
+        self._reference_bucket_quirk = bool(reference_bucket_quirk)
         self._length = None
         self._formulas = load_formulas(path_formulas)
         self._data_generator = DataGeneratorFile(path_matching)
@@ -53,19 +54,25 @@ class DataGenerator(object):
             self._data_generator = self.bucket(bucket_size)
 
     def bucket(self, bucket_size):
-        """One full pass; emit groups of `bucket_size` same-shape images as
-        they fill, leftovers at the end in first-seen shape order.
-        Reference: data_generator.py:84-122 (also sets the dataset length)."""
+        """One full pass; emit groups of `bucket_size` same-shape images as they fill, leftovers at the end in first-seen
+        shape order.  Reference: data_generator.py:84-122 (also sets the dataset length).
+        Reference quirk, found by running the reference's own class (tests/golden/make_ref_datagen_golden.py) and kept by
+        default: its flush loop `for (img_path, formula_id) in data_buckets[s]` (:107-108) re-binds the names of the CURRENT
+        example, so the example that arrives at a full bucket is lost and the LAST element of the flushed bucket opens the new
+        one instead (one duplicate + one dropped sample per flush).  reference_bucket_quirk=False buckets without it."""
         out, buckets = [], {}
         old_mode, self._iter_mode = self._iter_mode, "full"
         n = 0
         for img, _, img_path, formula_id in self:
             n += 1
             group = buckets.setdefault(img.shape, [])
+            cur = (img_path, formula_id)
             if len(group) == bucket_size:
                 out.extend(group)
+                if self._reference_bucket_quirk:
+                    cur = group[-1]
                 group.clear()
-            group.append((img_path, formula_id))
+            group.append(cur)
         for group in buckets.values():
             out.extend(group)
         self._iter_mode = old_mode

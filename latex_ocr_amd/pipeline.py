@@ -115,9 +115,10 @@ class ShardedBuckets(object):
     A tail smaller than `world` examples is dropped on every rank (a rank with no data would desynchronise the
     collectives); `dropped` counts them."""
 
-    def __init__(self, dataset, batch_size, world=1, rank=0):
+    def __init__(self, dataset, batch_size, world=1, rank=0, n_steps=None):
         self.dataset, self.batch_size, self.world, self.rank = dataset, int(batch_size), int(world), int(rank)
         self.dropped = 0
+        self._n_steps = n_steps            # known from an earlier pass over the same set (len() then costs nothing)
 
     def _groups(self):
         groups, order = {}, []
@@ -132,15 +133,18 @@ class ShardedBuckets(object):
     def __len__(self):
         """Optimisation steps one pass takes: sum over shape buckets of ceil(n_bucket / (batch_size * world)), minus the
         dropped tails -- NOT ceil(N / (batch_size * world)): the LR schedule and the global batch counter are scaled by
-        this number (train.py, Img2SeqModel._run_train)."""
+        this number (train.py, Img2SeqModel._run_train).  One pass over the dataset that keeps only a COUNT per image shape,
+        never the images (the reference's DataGenerator.__len__ also iterates, data_generator.py:206-215)."""
         if getattr(self, "_n_steps", None) is None:
-            groups, order = self._groups()
+            counts, order = {}, []
+            for img, _ in self.dataset:
+                key = tuple(np.asarray(img).shape)
+                if key not in counts:
+                    counts[key] = 0
+                    order.append(key)
+                counts[key] += 1
             gb = self.batch_size * self.world
-            n = 0
-            for key in order:
-                m = len(groups[key])
-                n += m // gb + (1 if (m % gb) >= self.world else 0)
-            self._n_steps = n
+            self._n_steps = sum(counts[k] // gb + (1 if (counts[k] % gb) >= self.world else 0) for k in order)
         return self._n_steps
 
     def __iter__(self):

@@ -59,3 +59,45 @@ def toy_set(n, H, W, V, seed):
 
 def shape_of(V):
     return (32, 128) if V >= 50 else (32, 48)
+
+
+def write_mixed_dataset(root, n=23, seed=31):
+    """A tiny on-disk dataset in the reference's format with THREE image shapes interleaved (so that same-shape bucketing
+    re-orders it) and formulas of 2..9 tokens: PNG images, formulas file, matching file "<img> <formula_idx>"."""
+    import os
+    from PIL import Image
+    rng = np.random.Generator(np.random.PCG64(seed))
+    shapes = [(8, 16), (8, 24), (12, 16)]
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    with open(os.path.join(root, "formulas.txt"), "w") as ff, open(os.path.join(root, "matching.txt"), "w") as fm:
+        for i in range(n):
+            h, w = shapes[int(rng.integers(0, 3))]
+            img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            Image.fromarray(img).save(os.path.join(root, "images", "%d.png" % i))
+            L = int(rng.integers(2, 10))
+            ff.write(" ".join("t%d" % int(t) for t in rng.integers(0, 12, size=L)) + "\n")
+            fm.write("%d.png %d\n" % (i, i))
+    return os.path.join(root, "formulas.txt"), os.path.join(root, "images") + "/", os.path.join(root, "matching.txt")
+
+
+DATAGEN_CASES = [dict(bucket=False), dict(bucket=True, bucket_size=3), dict(bucket=True, bucket_size=4, max_len=6),
+                 dict(bucket=False, max_iter=7, max_len=7), dict(bucket=True, bucket_size=2, iter_mode="full", max_iter=9)]
+
+
+def run_datagen(DataGenerator, root, greyscale):
+    """Drives a DataGenerator class (the reference's or ours) over the mixed dataset; -> JSON-able trace per case."""
+    import zlib
+    pf, di, pm = write_mixed_dataset(root)
+    out = []
+    for kw in DATAGEN_CASES:
+        ds = DataGenerator(pf, di, pm, img_prepro=greyscale, form_prepro=lambda s: [int(t[1:]) for t in s.strip().split(" ")], **kw)
+        items = []
+        for inst in ds:
+            img, form = inst[0], inst[1]
+            rec = {"shape": list(np.asarray(img).shape), "crc": zlib.crc32(np.ascontiguousarray(img).tobytes()) & 0xFFFFFFFF,
+                   "dtype": str(np.asarray(img).dtype), "formula": [int(t) for t in form]}
+            if len(inst) == 4:
+                rec["path"], rec["id"] = inst[2], str(inst[3])
+            items.append(rec)
+        out.append({"kw": {k: v for k, v in kw.items()}, "items": items, "len": len(ds)})
+    return out

@@ -111,3 +111,38 @@ def test_decode_vs_reference_code_bf16_agreement():
     agree5 = float((b5[:, :n5, 0] == w5[:, :n5, 0]).mean())
     print("bf16 vs reference code: greedy agreement %.4f (steps %d vs %d), beam-5 best-hypothesis agreement %.4f" % (agree, ids.shape[1], want.shape[1], agree5))
     assert agree >= 0.95 and agree5 >= 0.9
+
+
+@pytest.mark.parametrize("V", [11, 50])
+def test_cell_protocol_vs_reference_code_f32(V):
+    """The reference's decoder-cell protocol (dynamic_decode over GreedyDecoderCell / BeamSearchDecoderCell:
+    initialize / step / finalize, latex_ocr_amd/model/components over lxo_decode_begin / lxo_decode_step) reproduces the
+    reference code's ids, step counts, per-step logits and finished flags."""
+    from latex_ocr_amd.model.components import AttentionCell, GreedyDecoderCell, BeamSearchDecoderCell, dynamic_decode
+    tag = "v%d_toy_" % V
+    eng = Engine(V, dtype="f32", seed=0)
+    eng.load_params(_weights(V, "toy"))
+    img = REFDEC[tag + "img"]
+    cfg = {"dim_e": 256, "dim_o": 512, "num_units": 512, "dim_embeddings": 80}
+    cell = AttentionCell(eng, img, cfg, V)
+    out, _ = dynamic_decode(GreedyDecoderCell(cell, V - 1), 31)
+    want = REFDEC[tag + "greedy_ids"]
+    assert out.ids.shape == want.shape and np.array_equal(out.ids, want)
+    wl = REFDEC[tag + "greedy_logits"]
+    assert np.abs(out.logits - wl).max() <= 5e-5 * max(1.0, np.abs(wl).max())
+    for k in (2, 5):
+        btag = "%sbeam%d_" % (tag, k)
+        bout, _ = dynamic_decode(BeamSearchDecoderCell(cell, V - 1, beam_size=k), 31)
+        assert bout.ids.shape == REFDEC[btag + "ids"].shape and np.array_equal(bout.ids, REFDEC[btag + "ids"])
+    # the penalised beam (k = 3, gamma .7, applied with probability 1) and the optional true back-trace
+    gamma, prob = [float(x) for x in REFDEC[tag + "beam3div_gamma_prob"]]
+    dout, _ = dynamic_decode(BeamSearchDecoderCell(cell, V - 1, beam_size=3, div_gamma=gamma, div_prob=prob), 31)
+    assert np.array_equal(dout.ids, REFDEC[tag + "beam3div_ids"])
+    tb, _ = dynamic_decode(BeamSearchDecoderCell(cell, V - 1, beam_size=5, backtrace=True), 31)
+    ids, par = REFDEC[tag + "beam5_ids"], REFDEC[tag + "beam5_parents"]
+    B, T, k = ids.shape
+    for b in range(B):                                    # follow the reference's own parents backwards by hand
+        cur = np.arange(k)
+        for t in range(T - 1, -1, -1):
+            assert np.array_equal(tb.ids[b, t], ids[b, t][cur])
+            cur = par[b, t][cur]

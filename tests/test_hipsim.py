@@ -109,6 +109,30 @@ def test_greedy_and_beam_f32_vs_golden():
     assert np.array_equal(bids[:, :n], GOLD["beam_ids"]) and np.array_equal(bpar[:, :n], GOLD["beam_parents"])
 
 
+def test_decode_one_step_at_a_time_equals_the_loops():
+    """lxo_decode_begin / lxo_decode_step (what the cell protocol of model/components is bound to) against the same golden ids
+    as the device-side loops, with the host doing dynamic_decode.py:38-51's loop."""
+    img = GOLD["img"]
+    for beam, want_ids, want_par in ((1, GOLD["greedy_ids"], None), (2, GOLD["beam_ids"], GOLD["beam_parents"])):
+        S = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, beam=beam, max_steps=9)
+        S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+        S.ck(S.L.lxo_decode_begin(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), None), "begin")
+        shp = (2, 9) if beam == 1 else (2, 9, beam)
+        ids = np.zeros(shp, np.int32); par = np.zeros(shp, np.int32); fin = np.zeros(2 * beam, np.int32)
+        time, finished = 0, np.zeros(2 * beam, bool)
+        while not finished.all():
+            un = ctypes.c_int(-1)
+            S.ck(S.L.lxo_decode_step(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), 10, time, ptr(ids), ptr(par) if beam > 1 else None,
+                                     ptr(fin), ctypes.byref(un), None), "step")
+            assert un.value == int((fin == 0).sum())
+            finished = np.logical_or(time >= 8, fin.astype(bool))
+            time += 1
+        assert time == want_ids.shape[1]
+        assert np.array_equal(ids[:, :time], want_ids)
+        if want_par is not None:
+            assert np.array_equal(par[:, :time], want_par)
+
+
 def test_adam_and_clip():
     L = lib()
     rng = np.random.default_rng(0)

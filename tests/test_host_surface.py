@@ -115,3 +115,19 @@ def test_encoder_out_hw_and_attention_overlay(tmp_path):
     gif = VA.vis_attention_gif(img, alphas, str(tmp_path / "vis"), "a b c")
     assert len(files) == 3 and all(os.path.exists(f) for f in files + [gif])
     assert Image.open(files[0]).size == (240, 40)
+
+
+def test_data_generator_vs_reference_class(tmp_path):
+    """DataGenerator (matching file, greyscale prepro, max_len filter, max_iter, same-shape bucketing in groups of bucket_size,
+    "full" iteration mode, len()) against a trace of the REFERENCE's own class (data_generator.py:35-215) over the same seeded
+    on-disk dataset (tests/golden/make_ref_datagen_golden.py; scipy.misc.imread supplied by PIL)."""
+    import json
+    import refgold
+    from latex_ocr_amd.model.utils.data_generator import DataGenerator
+    from latex_ocr_amd.model.utils.image import greyscale
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "data_generator.json")))
+    got = refgold.run_datagen(DataGenerator, str(tmp_path), greyscale)
+    assert len(got) == len(want) == len(refgold.DATAGEN_CASES)
+    for g, w in zip(got, want):
+        assert g["kw"] == w["kw"] and g["len"] == w["len"], (g["kw"], g["len"], w["len"])
+        assert g["items"] == w["items"], g["kw"]
