@@ -222,6 +222,83 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
     dt = timed(lambda: engc.beam_decode(cimg, V - 1, 5, max_iter=151), 5, warm=1)
     out["decode_beam5_trained_to_end"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": int(bids.shape[1]), "tokens_per_s": round(ntok / dt, 0),
                                           "batch": B, "beam": 5}
+    # ---- the input pipeline in the loop (the reference feeds fresh host arrays every step, img2seq.py:160-169): Prefetcher =
+    #      background pad_batch_images / pad_batch_formulas into pinned buffers + H2D on the copy stream, `depth` batches ahead ----
+    from latex_ocr_amd.pipeline import Prefetcher
+    from latex_ocr_amd.model.utils.data_generator import ListDataset
+    pool_i, pool_f = synthetic.make_set(256, H, W, V, 30, 101, seed=4321)
+    nsteps = 50
+    idx = [(s * B + j) % 256 for s in range(nsteps + 4) for j in range(B)]
+    ds = ListDataset([pool_i[i] for i in idx], [pool_f[i] for i in idx])
+    t_host = time.perf_counter()
+    for s in range(4):                                   # host cost of one batch on ONE thread: pad images + formulas (+ pinning is in the loader)
+        pad_batch_images(ds.images[s * B:(s + 1) * B]); pad_batch_formulas(ds.formulas[s * B:(s + 1) * B], V - 2, V - 1)
+    t_host = (time.perf_counter() - t_host) / 4
+    feed = iter(Prefetcher(ds, B, V - 2, V - 1, device=dev, depth=3))
+    for _ in range(4):
+        b = next(feed); eng_train.train_step(b.img, b.formula, b.lengths, 1e-3, sync_loss=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); n = 0
+    for b in feed:
+        eng_train.train_step(b.img, b.formula, b.lengths, 1e-3, sync_loss=False); n += 1
+    torch.cuda.synchronize()
+    dtp = (time.perf_counter() - t0) / max(n, 1)
+    out["pipeline_fed"] = {"img_per_s": round(B / dtp, 1), "ms_per_step": round(dtp * 1e3, 3), "steps": n, "host_pad_ms_per_batch": round(t_host * 1e3, 2),
+                           "h2d_bytes_per_batch": int(B * H * W + B * 101 * 4),
+                           "note": "fresh host lists every step through latex_ocr_amd.pipeline.Prefetcher (depth 3): padding on a background thread, pinned staging, copy stream; T varies per batch (batch-max + 1)"}
+    return out
+
+
+def cpu_baselines_secondary(eng_train, torch, dev, V):
+    """The CPU side of the non-training configurations, bounded samples, never `value`:
+    beam-5 decode tokens/s of the oracle (beam_search_decoder_cell.py:123-187 restated) and configs[0] end to end
+    (1 epoch of 5 Adam steps at batch 20 on 100 crops of 32x128, V = 50, then greedy decode of all 100 crops) on both sides."""
+    from latex_ocr_amd import synthetic
+    from latex_ocr_amd.engine import Engine
+    from latex_ocr_amd.model.utils.general import minibatches
+    from latex_ocr_amd.model.utils.image import pad_batch_images
+    from latex_ocr_amd.model.utils.text import pad_batch_formulas
+    from oracle import ref_model as R
+    out = {}
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    # ---- beam 5 on the CPU: batch 2, 128x512, V = 500, 20 steps (END never emitted: the untrained weights of the GPU 'bound' run) ----
+    imgs, _ = synthetic.make_set(2, 128, 512, V, 3, 5, seed=8)
+    img = torch.from_numpy(pad_batch_images(imgs))
+    P = R.init_params(V, 0)
+    t0 = time.perf_counter()
+    ids, _ = R.beam_decode(P, img, -1, 5, max_iter=19)
+    dt = time.perf_counter() - t0
+    out["cpu_baseline_decode_beam5"] = {"value": round(2 * ids.shape[1] / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+                                        "sample": "oracle/ref_model.py beam_decode (torch-CPU f32), batch 2, beam 5, 128x512, V=%d, %d steps incl. the encoder; tokens = B x steps as in secondary.decode_beam5_bound" % (V, ids.shape[1])}
+    # ---- configs[0] end to end on both sides ----
+    Vs = 50
+    imgs, forms = synthetic.config1()
+    def run_cpu():
+        P = R.init_params(Vs, 0); opt = R.AdamTF(P)
+        for bi, bf in minibatches(zip(imgs, forms), 20):
+            f, l = pad_batch_formulas(bf, Vs - 2, Vs - 1)
+            R.train_step(P, opt, torch.from_numpy(pad_batch_images(bi)), torch.from_numpy(f), torch.from_numpy(l), 1e-3)
+        return R.greedy_decode(P, torch.from_numpy(pad_batch_images(imgs)), Vs - 1, max_iter=151).shape[1]
+    def run_gpu(dtype):
+        eng = Engine(Vs, dtype=dtype, device=dev, seed=0)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for bi, bf in minibatches(zip(imgs, forms), 20):
+            f, l = pad_batch_formulas(bf, Vs - 2, Vs - 1)
+            eng.train_step(pad_batch_images(bi), f, l, 1e-3)
+        n = eng.greedy_decode(pad_batch_images(imgs), Vs - 1, max_iter=151).shape[1]
+        torch.cuda.synchronize()
+        return time.perf_counter() - t, n
+    t0 = time.perf_counter(); ncpu = run_cpu(); tcpu = time.perf_counter() - t0
+    run_gpu("bf16")                                      # warm-up (kernel attributes, allocator)
+    tg, ng = run_gpu("bf16")
+    out["config1_end_to_end"] = {"gpu_seconds": round(tg, 4), "cpu_seconds": round(tcpu, 3), "cpu_cores": cores, "decode_steps": [int(ng), int(ncpu)],
+                                 "sample": "configs[0]: 100 synthetic 32x128 crops, V=50: 1 epoch (5 Adam steps, batch 20, host padding and uploads included) + greedy decode of the 100 crops to the bound; GPU = bf16 engine, CPU = oracle port (torch-CPU f32)"}
     return out
 
 
@@ -372,6 +449,11 @@ def main():
                         out["secondary"] = {"error": repr(e)}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
+                if not args.no_secondary:
+                    try:
+                        out.update(cpu_baselines_secondary(eng, torch, dev, V))
+                    except Exception as e:
+                        out["cpu_baselines_secondary_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if dist is not None:
         import torch.distributed as td

@@ -169,6 +169,61 @@ def test_beam5_f32_ids_and_parents(end_checkpoint):
     assert np.array_equal(ids, rid.numpy()) and np.array_equal(par, rpar.numpy())
 
 
+def test_trained_checkpoint_loss_f32_and_bf16(end_checkpoint):
+    """The training loss in the TRAINED regime at the benchmark image size: the END-emitting checkpoint on fresh crops, f32 mode
+    and bf16 mode against the oracle (at random initialisation the loss is ln 500 + epsilon whatever the decoder does)."""
+    _oracle_threads()
+    imgs, forms = count_set(8, 21)
+    img = pad_batch_images(imgs); f, l = pad_batch_formulas(forms, V - 2, V - 1)
+    P = {k: torch.from_numpy(v.copy()) for k, v in end_checkpoint.items()}
+    ref, _, _ = R.forward_loss(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l))
+    ref = float(ref)
+    out = {}
+    for dt in ("f32", "bf16"):
+        eng = Engine(V, dtype=dt, seed=0)
+        eng.load_params(end_checkpoint)
+        eng.forward(img, f)
+        st = eng.loss(l, 1.0 / int(l.sum())).cpu().numpy()
+        out[dt] = st[0] / st[1]
+    print("trained checkpoint, 128x512: oracle loss %.6f, f32 %.6f, bf16 %.6f (ln V = %.3f)" % (ref, out["f32"], out["bf16"], np.log(V)))
+    assert ref < 0.5 * np.log(V)
+    # the count-down task is learnt to a loss of ~3e-4, so the bars are absolute + relative: f32 2e-5 rel (+1e-6), bf16 1e-2 rel (+1e-5)
+    assert abs(out["f32"] - ref) <= 2e-5 * ref + 1e-6
+    assert abs(out["bf16"] - ref) <= 1e-2 * ref + 1e-5
+
+
+def test_beam5_batch64_f32_identical_and_bf16_agreement(end_checkpoint):
+    """configs[4] at the shape the bench times: beam 5 on B = 64 images (320 decoder rows): f32 ids + parents identical to the
+    oracle, bf16 agreement on the best hypothesis reported and held to 0.98; greedy bf16 on the same 64 crops with the oracle's
+    top1 - top2 margin printed for every token that differs."""
+    _oracle_threads()
+    imgs, forms = count_set(64, 77)
+    img = pad_batch_images(imgs)
+    e32 = Engine(V, dtype="f32", seed=0); e32.load_params(end_checkpoint)
+    P = oracle_params(e32)
+    rid, rpar = R.beam_decode(P, torch.from_numpy(img), V - 1, 5, max_iter=151)
+    ids, par = e32.beam_decode(img, V - 1, 5, max_iter=151, return_parents=True)
+    assert ids.shape == tuple(rid.shape), (ids.shape, tuple(rid.shape))
+    assert np.array_equal(ids, rid.numpy()) and np.array_equal(par, rpar.numpy())
+    e16 = Engine(V, dtype="bf16", seed=0); e16.load_params(end_checkpoint)
+    b16 = e16.beam_decode(img, V - 1, 5, max_iter=151)
+    n = min(b16.shape[1], rid.shape[1])
+    agree_best = float((b16[:, :n, 0] == rid.numpy()[:, :n, 0]).mean())
+    agree_all = float((b16[:, :n] == rid.numpy()[:, :n]).mean())
+    print("beam 5, B = 64: %d steps (bf16 %d); bf16 vs oracle agreement: best hypothesis %.4f, all five %.4f" % (rid.shape[1], b16.shape[1], agree_best, agree_all))
+    assert agree_best >= 0.98
+    g16 = e16.greedy_decode(img, V - 1, max_iter=151)
+    gref, logits = R.greedy_decode(P, torch.from_numpy(img), V - 1, max_iter=151, return_logits=True)
+    gref = gref.numpy()
+    assert g16.shape == gref.shape, (g16.shape, gref.shape)
+    bad = np.argwhere(g16 != gref)
+    for b, t in bad[:12]:
+        top2 = torch.topk(logits[b, t], 2).values
+        print("greedy bf16 mismatch row %d step %d: hip %d oracle %d, oracle top1-top2 margin %.3e" % (b, t, g16[b, t], gref[b, t], float(top2[0] - top2[1])))
+    print("greedy bf16, 64 crops at 128x512: agreement %.4f (%d of %d tokens differ)" % (float((g16 == gref).mean()), len(bad), gref.size))
+    assert (g16 == gref).mean() >= 0.99
+
+
 def test_beam5_f32_random_weights_bounded():
     """The same path at the step bound (random weights never emit END): 24 steps, 8 x 5 hypotheses."""
     _oracle_threads()

@@ -6,6 +6,7 @@ export PYTHONUNBUFFERED=1
 for what in "$@"; do
 case $what in
   refgold)  timeout 600 python -m pytest tests/test_gpu_refgold.py -m gpu -q -s > gpurun_out/${TAG}_refgold.log 2>&1; echo "refgold rc=$?"; grep -E "passed|failed|cosine|bf16|Error|assert" gpurun_out/${TAG}_refgold.log | tail -30;;
+  trained)  timeout 1500 python -m pytest tests/test_gpu_trained.py tests/test_gpu_benchcfg.py tests/test_gpu_refgold.py -m gpu -q -s --durations=12 > gpurun_out/${TAG}_trained.log 2>&1; echo "trained rc=$?"; grep -E "passed|failed|loss|agreement|beam 5|margin|Error|assert|cosine|s call" gpurun_out/${TAG}_trained.log | tail -60;;
   cstamps)  timeout 300 python tools/conv_stamps.py > gpurun_out/${TAG}_conv_stamps.log 2>&1; echo "cstamps rc=$?";;
   cdiag)    for d in 1 2 4 7; do LXO_CONV_DIAG=$d timeout 300 python tools/conv_stamps.py 2>&1 | grep -v amdgpu | head -17 > gpurun_out/${TAG}_conv_diag$d.log; echo "diag $d rc=$?"; done;;
   ctimeline) timeout 300 python tools/conv_timeline.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_conv_timeline.log; echo "timeline rc=$?";;
