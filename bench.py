@@ -89,6 +89,36 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def pin_rank_to_numa(local_rank, world, torch):
+    """One host thread per GPU drives ~3 ms of launch work per step: give every rank its own cores, the ones local to ITS GPU's
+    NUMA node when sysfs tells (pci local_cpulist), else an even slice of the cores this process may use.  Best effort."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return None
+    local = None
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        txt = open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        local = [c for c in avail if c in cpus]
+    except Exception:
+        local = None
+    pool = local if local else avail
+    per = max(1, len(pool) // max(1, world))
+    # ranks sharing a NUMA node (or the whole pool) take consecutive slices by local rank
+    mine = pool[(local_rank * per) % len(pool):][:per] or pool
+    try:
+        os.sched_setaffinity(0, mine)
+    except Exception:
+        return None
+    return {"cores": len(mine), "numa_local": bool(local)}
+
+
 # ------------------------------------------------------------------ measurement helpers (rank 0, after the timed region) ----
 def timing_records(lib):
     import ctypes
@@ -357,12 +387,16 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = "cuda:%d" % local_rank
         sync = torch.cuda.synchronize
+        pinned = pin_rank_to_numa(local_rank, world, torch) if world > 1 else None
         if world > 1 or os.environ.get("LXO_FORCE_DIST") == "1":
             import torch.distributed as td
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
             from latex_ocr_amd.dist import DataParallel
             dist = DataParallel(device=dev)
+            dist.time_finish = True                              # event pair around the wait for the gradient buckets
+            if os.environ.get("LXO_DP_BF16") == "1":
+                dist.grad_dtype = torch.bfloat16                 # opt-in: gradients cross xGMI as bf16 (17 MB instead of 34.5 MB)
         B, H, W, V = args.batch, args.height, args.width, args.vocab
         eng = Engine(V, dtype=args.dtype, device=dev, seed=0)
         imgs, forms = synthetic.make_set(B, H, W, V, 30, 101, seed=1234 + rank)
@@ -379,6 +413,8 @@ def main():
     if dist is not None:
         dist.barrier()
     sync()
+    if dist is not None and getattr(dist, "exposed_ms", None) is not None:
+        dist.exposed_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -387,7 +423,17 @@ def main():
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    dp_info = None
     if dist is not None:
+        # per-rank step time and exposed all-reduce wait, gathered before the MAX that defines `value`
+        mine = torch.zeros(world, 2, dtype=torch.float64, device=dev)
+        ex = dist.exposed_allreduce_ms() if not args.sim else None
+        mine[rank, 0] = dt / args.steps * 1e3
+        mine[rank, 1] = -1.0 if ex is None else ex
+        dist.all_reduce(mine)
+        dp_info = {"per_rank_ms_per_step": [round(float(x), 3) for x in mine[:, 0].tolist()],
+                   "exposed_allreduce_ms_per_step": [round(float(x), 3) for x in mine[:, 1].tolist()],
+                   "gradient_dtype": "bf16" if getattr(dist, "grad_dtype", None) is not None else "f32"}
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce_max(tt)
         dt = float(tt.item())
@@ -403,6 +449,8 @@ def main():
                                    "T=%d (lengths U{30..100}), Adam" % (B, H, W, V, T),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
         }
+        if dp_info is not None:
+            out["data_parallel"] = dict(dp_info, rank_cpu_pinning=(pinned if not args.sim else None))
         if args.sim:
             out["config"]["workload"] = "TEST ONLY (--sim): hipsim-interpreted kernels on CPU, gloo, tiny shapes"
         if not args.sim and not args.no_extras:

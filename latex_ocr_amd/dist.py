@@ -101,9 +101,10 @@ class DataParallel(object):
             self._pending = True
         return comm
 
-    def finish(self, timed=False):
+    def finish(self, timed=None):
         """Make the compute stream wait for every bucket before the optimizer reads the gradients.  timed: bracket the wait
         with events on the compute stream (bench.py reports the exposed all-reduce time from them)."""
+        timed = getattr(self, "time_finish", False) if timed is None else timed
         if self.cuda and self._pending:
             cur = torch.cuda.current_stream(self.device)
             if timed:
