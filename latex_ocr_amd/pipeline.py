@@ -49,29 +49,50 @@ class Prefetcher(object):
     def _source(self):
         return self.batches if self.batches is not None else minibatches(self.dataset, self.batch_size)
 
+    def _pinned_slot(self, nbytes_img, nbytes_f):
+        """A ring of depth + 2 pinned staging slots, grown on demand and REUSED: a fresh pin_memory() per batch costs a
+        hipHostMalloc + page locking of 4 MB every step (measured: 32 ms per step with it, against a 10.8 ms training step)."""
+        if not hasattr(self, "_ring"):
+            self._ring, self._ring_i = [], 0
+        n = self.depth + 2
+        if len(self._ring) < n:
+            self._ring.append({"img": None, "f": None, "ev": None})
+            slot = self._ring[-1]
+        else:
+            slot = self._ring[self._ring_i % n]
+            self._ring_i += 1
+            if slot["ev"] is not None:
+                slot["ev"].synchronize()               # its previous asynchronous copies have read the buffers
+        if slot["img"] is None or slot["img"].numel() < nbytes_img:
+            slot["img"] = torch.empty(nbytes_img, dtype=torch.uint8).pin_memory()
+        if slot["f"] is None or slot["f"].numel() < nbytes_f:
+            slot["f"] = torch.empty(max(nbytes_f, 4096), dtype=torch.uint8).pin_memory()
+        return slot
+
     def _stage(self, imgs, forms):
-        img = torch.from_numpy(pad_batch_images(imgs))
+        img = pad_batch_images(imgs)
         f, l = pad_batch_formulas(forms, self.id_pad, self.id_end)
-        f = torch.from_numpy(np.ascontiguousarray(f, dtype=np.int32))
+        f = np.ascontiguousarray(f, dtype=np.int32)
         b = Batch()
         b.lengths, b.n_tokens, b.size, b.ready = np.asarray(l), int(np.sum(l)), len(imgs), None
         if self.cuda:
-            img, f = img.pin_memory(), f.pin_memory()
+            slot = self._pinned_slot(img.nbytes, f.nbytes)
+            pi = slot["img"][:img.nbytes].view(torch.uint8).reshape(img.shape)
+            pf = slot["f"][:f.nbytes].view(torch.int32).reshape(f.shape)
+            pi.numpy()[...] = img
+            pf.numpy()[...] = f
             with torch.cuda.stream(self.copy_stream):
-                b.img = img.to(self.device, non_blocking=True)
-                b.formula = f.to(self.device, non_blocking=True)
+                b.img = pi.to(self.device, non_blocking=True)
+                b.formula = pf.to(self.device, non_blocking=True)
                 b.ready = torch.cuda.Event()
                 b.ready.record(self.copy_stream)
-            self._pinned.append((img, f, b.ready))   # the pinned sources must outlive their asynchronous copies
-            while len(self._pinned) > self.depth + 2:
-                self._pinned.pop(0)[2].synchronize()
+            slot["ev"] = b.ready
         else:
-            b.img, b.formula = img, f
+            b.img, b.formula = torch.from_numpy(img), torch.from_numpy(f)
         return b
 
     def __iter__(self):
         q = queue.Queue(maxsize=self.depth)
-        self._pinned = []
         stop = threading.Event()
         END = object()
 
