@@ -293,6 +293,8 @@ template <class G, class Lp> inline void hipsim_global_load_lds(G g, Lp l, unsig
 
 // ---- host API subset used by the C-ABI layer ----
 inline hipError_t hipGetLastError() { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 2; return hipSuccess; }      // 2 "CUs": the persistent conv grid (4 workgroups) then walks several tiles
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipsim"; }
