@@ -640,6 +640,12 @@ __global__ __launch_bounds__(512) void conv_halo256_kernel(GemmNT p, int tiles_n
 //   * weight requests use the scalar-base form (global_load_lds voff, s[base]): the tile base is wave-uniform SALU
 //     arithmetic, the per-lane byte offsets are two loop-invariant registers, M0 = a scalar + immediate;
 //   * the weight fragment addresses are two loop-invariant registers (+ immediate ring stage).
+// Measured and rejected: a PERSISTENT grid (two workgroups per CU walking the tiles; the per-CU timeline shows ~3.6 k idle
+// cycles between the end of a workgroup and the start of its successor on the same CU slot): conv roofline 0.506 vs 0.564.
+// gfx950 counts stores in vmcnt, in order, so the first DMA wait of the next tile also waits for the acknowledgement of the
+// previous tile's 64 KB of output stores (gap 8-9 k cycles, epilogue 9.6 k instead of 5.8 k), which a workgroup that simply
+// ends never pays; the loop-carried state also pushed the kernel into scratch (34-58 spill instructions per tile = +65 MB
+// of HBM writes per launch in the PMC pass).
 // 9 ds_read_b128 per 8 MFMAs (8 pixel fragments + 1 weight fragment).  With 64-channel tiles (conv2's data gradient) the four
 // waves are 2 channel blocks x 2 row halves (4 accumulators each); the two waves of a channel block each keep their own
 // copy of the weights.
@@ -657,15 +663,14 @@ constexpr int WLDS = 2 * WPATCHB + 4 * WNST * WWSTAGE;                // 78976 (
 // optional operands behind run-time branches hipcc put `s_waitcnt vmcnt(0)` into every row iteration (it cannot count loads
 // it may or may not have issued), so each 16-byte store waited for the previous one's acknowledgement: in-kernel stamps
 // showed 6.3 k cycles per 64-row pass, 32 k per tile -- a quarter of a conv4 tile, more than half of a conv2 tile.
-// One tile of the kernel below: `bid` of `nblk` virtual blocks (the XCD-aware block -> tile map keys on bid & 7, which a
-// workgroup keeps over its tiles because the persistent grid is a multiple of 8).
-template <int NJ, int EPI, int PH, int PW>
-LXO_DEV void conv_halo2wg_tile(const GemmNT& p, int tiles_n, int tiles_x, int tiles_y, int bid, int nblk) {
+template <int NJ, int EPI, int PH = 1, int PW = 1>
+__global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y) {
     constexpr int WBN = 32 * NJ;
     constexpr int NWM = 4 / NJ, RI = QTH / NWM;                    // waves along the tile rows (1 or 2), tile rows per wave (8 or 4)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches and SALU addressing
     const int wn = wave % NJ, wm = wave / NJ;                      // this wave's channel block / row group
+    const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
     const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
@@ -1065,20 +1070,6 @@ LXO_DEV void conv_halo2wg_tile(const GemmNT& p, int tiles_n, int tiles_x, int ti
     }
 }
 
-// The kernel: the grid walks the tiles, one workgroup per tile by default.  With one workgroup per tile the per-CU timeline of
-// the in-kernel stamps (tools/conv_timeline.py) shows ~3.6 k idle cycles between the end of a workgroup and the start of its
-// successor on the same CU slot (8 % of a conv4 tile), so a PERSISTENT grid (two workgroups per CU, LXO_CONV_PERSIST=1) was
-// tried -- and measured slower (conv roofline 0.506 vs 0.564): gfx950 counts stores in vmcnt, in order, so the first DMA wait
-// of the next tile also waits for the acknowledgement of the previous tile's 64 KB of output stores (gap 8-9 k cycles, epilogue
-// 9.6 k instead of 5.8 k), which a workgroup that simply ends never pays.
-template <int NJ, int EPI, int PH = 1, int PW = 1>
-__global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tiles_n, int tiles_x, int tiles_y, int ntiles) {
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-        if (vb != (int)blockIdx.x) LXO_LDS_BARRIER();               // every wave is done with the previous tile's LDS staging tile
-        conv_halo2wg_tile<NJ, EPI, PH, PW>(p, tiles_n, tiles_x, tiles_y, vb, ntiles);
-    }
-}
-
 }  // namespace
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of the loaded code object: set it once per
@@ -1126,23 +1117,18 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
             if (epi != 0 || p.N % 128 || !p.pool_mask || p.pool_h < 1 || p.pool_h > 2 || p.pool_w < 1 || p.pool_w > 2 || p.pool_h * p.pool_w == 1) return -2;
             epi = 4;
         } else if (!p.C) return -2;
-        const int nt4 = B * tiles_x * tiles_y * (p.N / 128), nt2 = B * tiles_x * tiles_y * (p.N / 64);
-        static int persist = -1;                                    // LXO_CONV_PERSIST=1: two workgroups per CU walk the tiles (A/B, measured slower); default: one workgroup per tile
-        if (persist < 0) { const char* e = getenv("LXO_CONV_PERSIST"); persist = (e && e[0] == '1') ? 1 : 0; }
-        static int pgrid = 0;
-        if (!pgrid) { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); pgrid = 2 * (cus > 0 ? cus : 256); pgrid -= pgrid % 8; if (pgrid < 8) pgrid = 8; }
-        const dim3 g4(persist && nt4 > pgrid ? pgrid : nt4), g2(persist && nt2 > pgrid ? pgrid : nt2);
+        const dim3 g4(B * tiles_x * tiles_y * (p.N / 128)), g2(B * tiles_x * tiles_y * (p.N / 64));
         if (p.N % 128 == 0) {
-            if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 0>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y, nt4);
-            else if (epi == 1) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y, nt4);
-            else if (epi == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y, nt4);
-            else if (epi == 4 && p.pool_h == 2 && p.pool_w == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 2, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y, nt4);
-            else if (epi == 4 && p.pool_h == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 2, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y, nt4);
-            else if (epi == 4) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 1, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y, nt4);
-            else hipLaunchKernelGGL((conv_halo2wg_kernel<4, 3>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y, nt4);
+            if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 0>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 1) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 4 && p.pool_h == 2 && p.pool_w == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 2, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 4 && p.pool_h == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 2, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else if (epi == 4) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 4, 1, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
+            else hipLaunchKernelGGL((conv_halo2wg_kernel<4, 3>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
         } else {
-            if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 0>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y, nt2);
-            else hipLaunchKernelGGL((conv_halo2wg_kernel<2, 3>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y, nt2);
+            if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 0>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+            else hipLaunchKernelGGL((conv_halo2wg_kernel<2, 3>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
         }
         return (int)hipGetLastError();
     }
