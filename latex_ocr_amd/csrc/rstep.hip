@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void rstep_kernel(RStep p) {
         } else if constexpr (EPI == RS_CARRY) {
             // v = d_z K[D:]^T: columns < O are d_o carried to step t-1, the rest d_h carried to step t-1
             const int O = p.O;
-            if (p.first) { st4(p.out + (long long)m * p.ldo + n, v); return; }   // t == 0: raw carries for the initial-state gradients
+            if (p.first) { st4(p.out + (long long)m * p.ldo + n, v); STAMP(6); return; }   // t == 0: raw carries for the initial-state gradients
             if (n < O) {
                 // g_{t-1} = (d_o from the logits (e0) + d_o carry) * dropout mask * (1 - tanh^2), tanh from o_{t-1} (e1)   (attention_cell.py:82-83 backward)
 #pragma unroll

@@ -31,7 +31,7 @@ for epi, label in ((2, "LSTM_FWD"), (1, "TANH_O"), (0, "PLAIN (last launch: B1 i
     torch.cuda.synchronize()
     lib.lxo_rstep_debug(ctypes.c_void_p(0), -1)
     d = dbg.cpu().numpy().reshape(256, 8)
-    d = d[d[:, 0] != 0]
+    d = d[(d[:, 0] != 0) & (d[:, 6] != 0)]           # workgroups whose stamping thread ran the epilogue
     grid = len(d)
     rel = d[:, :7] - d[:, :1]
     print("== %s, %d workgroups: cycles since the workgroup's own start, min / median / max" % (label, grid))
