@@ -719,21 +719,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         for (int j = 0; j < 2; ++j) LXO_GLDS16_SADDR(w_src[j], sb, lxo_conv_lds, m0base, wst_off + stage * WWSTAGE + 1024 * j);
     };
 
-    // The accumulators START as the bias (alpha == 1 for every convolution): its loads overlap the first patch / weight
-    // DMA, and no epilogue has to fetch per-lane bias values with the MFMA results waiting (5.6 k cycles in the stamps).
-    // Layout (MFMA operands swapped, see the K loop): acc[i][e] -> tile row wm*RI + i, column lane & 31,
-    // channel wn*32 + 8*(e>>2) + 4*(lane>>5) + (e&3).
     const int khalf = lane >> 5;
-    f32x16 acc[RI];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 32 + 8 * k + 4 * khalf);
-#pragma unroll
-        for (int i = 0; i < RI; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][4 * k + e] = bq[e];
-    }
 
     // per-lane LDS byte offsets: pixel fragments = a_lane (+ the patch buffer of the slice) + immediate; weight fragments of
     // sub-step ks = w_lane[ks] + immediate ring stage
@@ -751,6 +737,24 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
     issue_w(0, 2, 2);
+
+    // The accumulators START as the bias (alpha == 1 for every convolution): its loads are issued BEHIND the first patch /
+    // weight DMA requests (in front of them the accumulator initialisation made every tile wait a memory round trip before its
+    // first request), and no epilogue has to fetch per-lane bias values with the MFMA results waiting (5.6 k cycles in the stamps).
+    // Layout (MFMA operands swapped, see the K loop): acc[i][e] -> tile row wm*RI + i, column lane & 31,
+    // channel wn*32 + 8*(e>>2) + 4*(lane>>5) + (e&3).
+    f32x16 acc[RI];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // unconditional load (a null bias reads the zero line): a load behind a branch makes hipcc wait for it on the spot
+        const float* bsrc = p.bias ? p.bias + n0 + wn * 32 + 8 * k + 4 * khalf : reinterpret_cast<const float*>(lxo_zero_line);
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bsrc);
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][4 * k + e] = bq[e];
+    }
+
 
     u32x4 af[RI], bfr[2];
     int a_lane = a_lane0;
