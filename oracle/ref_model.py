@@ -4,14 +4,21 @@ CPU restatement (PyTorch-CPU, float32) of the reference's image->LaTeX hot
 path.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
 `cpu_baseline` leg may import this module, and only as the checker.
 
-PARITY UNPINNED: the reference's arithmetic lives in tensorflow==1.12.2
-(/root/reference/requirements.txt:1), which is absent from /root/reference and
-cannot be imported here (Python 3.10, no wheel, no network), and the reference
-ships no tests, golden vectors or fixtures for this path.
-The restatement therefore follows the reference's graph-building code line by
-line (citations below) plus TF-1.12's published op semantics (marked +TF), and
-is cross-checked against an independent float64 NumPy restatement
-(`oracle/np_micro.py`) and the geometry known-answers of SURVEY.md section 4.
+PINNED TO REFERENCE CODE RUN IN THE BUILD CONTAINER (both halves):
+  * encoder + positional signal: the reference's own PyTorch statement of the conv stack,
+    /root/reference/model/components/seq2seq_torch.py:24-55,113-156 (tests/golden/make_ref_encoder_golden.py ->
+    tests/golden/ref_encoder.npz);
+  * the whole training graph and both decode graphs: the reference's UNCHANGED graph-building code
+    (model/img2seq.py:42-123, encoder.py, decoder.py, components/{attention_mechanism,attention_cell,dynamic_decode,
+    greedy_decoder_cell,beam_search_decoder_cell,positional}.py) executed under tests/tfshim, an eager torch-CPU stand-in
+    for the ~70 tf.* symbols it touches (tests/golden/make_ref_decoder_golden.py -> tests/golden/ref_decoder.npz: train
+    logits, loss, every parameter gradient, greedy ids + logits, beam 2 / 3 (diversity penalty) / 5 ids + parents, Adam loss
+    trajectories, the variable names the reference's scoping produces).  tests/test_oracle.py holds this module to them.
+Still RESTATED (TF-1.12 primitives whose source is not under /root/reference: tensorflow==1.12.2, requirements.txt:1,
+cannot be installed here -- Python 3.10, no wheel, no network): LSTMCell arithmetic (gate order i,j,f,o, forget_bias 1.0),
+the conv / pool / dense / softmax / top_k / argmax / dropout / cross-entropy ops themselves, SAME-padding geometry, the
+optimizer update formulas, glorot initialisation.  The reference ships no tests or golden vectors of its own for this path
+(SURVEY.md section 8c).  An independent float64 NumPy restatement (`oracle/np_micro.py`) cross-checks the arithmetic.
 
 Reference files followed (all under /root/reference/):
   model/encoder.py:25-68                      encoder()
