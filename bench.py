@@ -459,12 +459,12 @@ def main():
             roof = roofline_from_records(recs, ("conv_fwd", "conv_dgrad"),
                                          "conv_halo2wg_kernel (bf16 implicit-GEMM 3x3 conv, halo tiles): the 10 conv forward / data-gradient launches of a step (conv2/4/5 forward include their fused max pool; FLOPs count the convolution only)",
                                          "mfma", MFMA_BF16_PEAK, "TFLOP/s")
-            tpath = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
             if roof is not None and os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = "profiles/r02_conv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over real training steps (tools/gpu_call.sh traffic), FETCH x2 (gfx950)"
+                    roof["traffic_source"] = "profiles/r03_conv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over real training steps (tools/gpu_call.sh traffic), FETCH x2 (gfx950)"
                 except Exception:
                     pass
             out["roofline"] = roof

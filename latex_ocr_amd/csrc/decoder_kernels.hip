@@ -466,6 +466,145 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const float* __re
         alpha[(long long)v * Rp + rr] = expf(alpha[(long long)v * Rp + rr] - m) * inv;
 }
 
+// ---- forward attention WITHOUT a merge step (round 3 experiment, opt-in: LXO_ATT_SPLIT=1; measured SLOWER than part + combine:
+// 11.1 + 12.2 us against 16.6 + 4.9 us per decoder step -- the scores kernel moves 28 MB in one burst per workgroup and pays the
+// launch ramp, the att_h / beta round trip and the tail without anything to overlap them with, i.e. the fixed costs twice) ----
+// The part / combine pair splits a sample's regions over workgroups, so the softmax needs a second launch that merges the
+// chunk partials (4.9 us per decoder step for 1 MB of data).  Here the two streams are split instead: (1) the scores
+// e[v][r] = sum_k beta_k tanh(att_img[r][k] + att_h[k]) need only `att_img` (a third of the bytes) and no merge at all;
+// (2) the context is split over CHANNEL slices of 64: every workgroup of a sample recomputes the softmax statistics from the
+// <= 1024 raw scores (868 exps) and accumulates its 64 channels of sum_r alpha_r img[r][:] -- no cross-workgroup step.
+// Rows are fetched in 16-byte pieces (scores: 32 lanes per 512-byte row, two rows per instruction; context: 8 lanes per
+// 128-byte row segment, eight rows per instruction), ATT_U instructions in flight per wave.
+template <typename CT, int ATT_U>
+__global__ __launch_bounds__(512) void attn_scores_kernel(const CT* __restrict__ att_img, const float* __restrict__ att_h,
+                                                         const float* __restrict__ beta, float* __restrict__ raw,
+                                                         int R, int Rp, int E, int beam, int rows_per) {
+    constexpr int EPL = 16 / (int)sizeof(CT);                  // elements per lane and load: 8 (bf16) / 4 (f32)
+    const int ch = blockIdx.x, v = blockIdx.y, bi = v / beam;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lpr = (E + EPL - 1) / EPL;                       // lanes per row (E <= 64 * EPL: one instruction covers >= 1 row)
+    const int rpi = 64 / lpr;                                  // rows per load instruction
+    const int rl = lane / lpr, kl = (lane - rl * lpr) * EPL;   // this lane's row within the instruction, first k
+    const int r0 = ch * rows_per;
+    const int n = min(R, r0 + rows_per) - r0;
+    if (n <= 0) return;
+    const CT* ai = att_img + ((long long)bi * R + r0) * E;
+    const bool kok = rl < rpi && kl < E;
+    const int kc = kok ? kl : 0;
+    float ah[EPL], bt[EPL];
+    {
+        const float* ap = att_h + (long long)v * E + kc;
+        const float* bp = beta + kc;
+#pragma unroll
+        for (int j = 0; j < EPL; j += 4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + j), b4 = *reinterpret_cast<const f32x4*>(bp + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ah[j + e] = a4[e]; bt[j + e] = kok ? b4[e] : 0.f; }
+        }
+    }
+    const int rows_it = ATT_W * ATT_U * rpi;                    // rows a workgroup covers per iteration
+    for (int base = 0; base < n; base += rows_it) {
+        float x[ATT_U][EPL];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {                      // unconditional (clamped) loads: all ATT_U requests in flight together
+            const int r = min(base + (u * ATT_W + wave) * rpi + rl, n - 1);
+            if constexpr (EPL == 8) load8(ai + (long long)r * E + kc, x[u]);
+            else load4(ai + (long long)r * E + kc, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) a = fmaf(tanh_ct<CT>(x[u][j] + ah[j]), bt[j], a);
+            for (int o = 1; o < lpr; o <<= 1) a += __shfl_xor(a, o);      // lpr is a power of two (E = 256: 32 / 64 lanes)
+            const int r = base + (u * ATT_W + wave) * rpi + rl;
+            if (kok && kl == 0 && r < n) raw[(long long)v * Rp + r0 + r] = a;
+        }
+    }
+}
+
+template <typename CT, int ATT_U>
+__global__ __launch_bounds__(512) void attn_ctx_kernel(const CT* __restrict__ img, const float* __restrict__ raw, float* __restrict__ alpha,
+                                                      float* __restrict__ ctx, int ldctx, bf16_t* __restrict__ ctxb, int ldcb,
+                                                      int R, int Rp, int C, int beam) {
+    constexpr int EPL = 16 / (int)sizeof(CT);                  // channels per lane: 8 (bf16) / 4 (f32)
+    constexpr int LPR = 64 / EPL;                              // lanes per 64-channel row segment: 8 / 16
+    constexpr int RPI = 64 / LPR;                              // rows per load instruction: 8 / 4
+    __shared__ float sc[1024];
+    __shared__ float red[ATT_W];
+    __shared__ float accs[ATT_W][64];
+    const int sl = blockIdx.x, ns = gridDim.x, v = blockIdx.y, bi = v / beam;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // softmax statistics of the whole sample (every slice recomputes them: R <= 1024 scores)
+    const float* rv = raw + (long long)v * Rp;
+    const float e0 = rv[min(tid, R - 1)], e1 = rv[min(tid + 512, R - 1)];
+    float m = fmaxf(tid < R ? e0 : -3.0e38f, tid + 512 < R ? e1 : -3.0e38f);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < ATT_W; ++w) m = fmaxf(m, red[w]);
+    const float p0 = tid < R ? expf(e0 - m) : 0.f, p1 = tid + 512 < R ? expf(e1 - m) : 0.f;
+    float l = wave_sum(p0 + p1);
+    __syncthreads();
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_W; ++w) l += red[w];
+    const float inv = 1.0f / l;
+    if (tid < R) sc[tid] = p0 * inv;
+    if (tid + 512 < R) sc[tid + 512] = p1 * inv;
+    // the normalised weights (kept for the backward pass / the visualisation export): slice s writes its share of the rows
+    const int rq = (R + ns - 1) / ns;
+    if (tid < R && tid / rq == sl) alpha[(long long)v * Rp + tid] = p0 * inv;
+    if (tid + 512 < R && (tid + 512) / rq == sl) alpha[(long long)v * Rp + tid + 512] = p1 * inv;
+    __syncthreads();
+    // context of this slice's 64 channels
+    const int rl = lane / LPR, cl = (lane - rl * LPR) * EPL;
+    const CT* im = img + (long long)bi * R * C + sl * 64 + cl;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    constexpr int ROWS_IT = ATT_W * ATT_U * RPI;
+    for (int base = 0; base < R; base += ROWS_IT) {
+        float x[ATT_U][EPL];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int r = min(base + (u * ATT_W + wave) * RPI + rl, R - 1);
+            if constexpr (EPL == 8) load8(im + (long long)r * C, x[u]);
+            else load4(im + (long long)r * C, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int r = base + (u * ATT_W + wave) * RPI + rl;
+            const float w = r < R ? sc[r] : 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(w, x[u][e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] += __shfl_xor(acc[e], o);
+    }
+    if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) accs[wave][cl + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_W; ++w) t += accs[w][tid];
+        const int c = sl * 64 + tid;
+        ctx[(long long)v * ldctx + c] = t;
+        if (ctxb) ctxb[(long long)v * ldcb + c] = f2bf(t);
+    }
+}
+
 // ---- attention backward (per step): d_e and d_att_h in one pass; d_img / d_att_img are deferred ----
 template <typename CT, int KCT, int ATT_U>
 __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
@@ -1114,6 +1253,20 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     dim3 grid(nch, nv);
+    static int split = -1;      // LXO_ATT_SPLIT=1: scores + softmax-context, no merge launch (A/B, measured slower); default: part + combine
+    if (split < 0) { const char* e = getenv("LXO_ATT_SPLIT"); split = (e && e[0] == '1') ? 1 : 0; }
+    const int epl = dt == LXO_BF16 ? 8 : 4;
+    if (split && ahs.n == 0 && att_h && R <= 1024 && C % 64 == 0 && E % epl == 0 && E <= 64 * epl && ((E / epl) & (E / epl - 1)) == 0) {
+        // raw scores travel through the `part` scratch (>= nv * Rp floats); alpha receives the normalised weights
+        if (dt == LXO_BF16) {
+            hipLaunchKernelGGL((attn_scores_kernel<bf16_t, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, att_h, beta, part, R, Rp, E, beam, rows_per);
+            hipLaunchKernelGGL((attn_ctx_kernel<bf16_t, 8>), dim3(C / 64, nv), dim3(512), 0, st, (const bf16_t*)img, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, beam);
+        } else {
+            hipLaunchKernelGGL((attn_scores_kernel<float, 8>), grid, dim3(512), 0, st, (const float*)att_img, att_h, beta, part, R, Rp, E, beam, rows_per);
+            hipLaunchKernelGGL((attn_ctx_kernel<float, 8>), dim3(C / 64, nv), dim3(512), 0, st, (const float*)img, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, beam);
+        }
+        DONE;
+    }
 #define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per, rev
     if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }

@@ -11,6 +11,8 @@ mathematics with different kernels, so they must agree far more tightly than eit
   (LXO_GEMM_TN_TR=0): summation order;
 * dense projections (att_img, logits, d_o) with LDS-DMA staging (default)  vs  the register-staged kernel
   (LXO_GEMM_NT_DMA=0): the same products in the same order per output element;
+* forward attention as part + combine (default)  vs  scores kernel + softmax-context kernel without a merge launch
+  (LXO_ATT_SPLIT=1): summation order;
 * fused recurrent-step kernels (default)  vs  round 1's split-K kernels (step_kernels = 1).
 Odd image sizes exercise the clipped pool windows of both generations."""
 import os, subprocess, sys
@@ -56,6 +58,7 @@ def test_kernel_generations_agree(tmp_path, h, w):
             ("att_forward_only", {"LXO_ATT_ALT": "0"}, (1e-5, 0.99999, 1e-2)),
             ("tn_packing_kernel", {"LXO_GEMM_TN_TR": "0"}, (1e-5, 0.99999, 1e-2)),
             ("nt_register_staged", {"LXO_GEMM_NT_DMA": "0"}, (1e-5, 0.99999, 1e-2)),
+            ("att_scores_then_context", {"LXO_ATT_SPLIT": "1"}, (1e-5, 0.99999, 1e-2)),
             ("split_k_steps", {"LXO_STEP_KERNELS": "1"}, (1e-4, 0.9995, 5e-2))):
         other = _run(tmp_path, name, env, h, w, 4)
         worst = _compare(base, other, *bars)
