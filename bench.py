@@ -252,6 +252,16 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
     dt = timed(lambda: engc.beam_decode(cimg, V - 1, 5, max_iter=151), 5, warm=1)
     out["decode_beam5_trained_to_end"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": int(bids.shape[1]), "tokens_per_s": round(ntok / dt, 0),
                                           "batch": B, "beam": 5}
+    # ---- the optional row-BiLSTM encoder (north_star names it; not in the reference; off in the headline) ----
+    engr = Engine(V, dtype="bf16", device=dev, seed=0, dims=dict(row_bilstm=True))
+    imgs, forms = synthetic.make_set(B, H, W, V, 30, 101, seed=1234)
+    imgr = torch.from_numpy(pad_batch_images(imgs)).to(dev)
+    fr, lr_ = pad_batch_formulas(forms, V - 2, V - 1)
+    fr_d = torch.from_numpy(fr).to(dev)
+    dt = timed(lambda: engr.train_step(imgr, fr_d, lr_, 1e-3, sync_loss=False), 5)
+    out["encoder_row_bilstm"] = {"ms_per_step": round(dt * 1e3, 3), "img_per_s": round(B / dt, 1),
+                                 "note": "same workload with the optional row encoder (bidirectional LSTM, 256 units per direction, over the 14 rows x 62 positions of every feature map) between conv6 and the decoder"}
+    del engr
     # ---- the input pipeline in the loop (the reference feeds fresh host arrays every step, img2seq.py:160-169): Prefetcher =
     #      background pad_batch_images / pad_batch_formulas into pinned buffers + H2D on the copy stream, `depth` batches ahead ----
     from latex_ocr_amd.pipeline import Prefetcher

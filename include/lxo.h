@@ -117,6 +117,11 @@ typedef struct lxo_shape {
      * epilogues (csrc/rstep.hip: 9 dependent launches per training step pair); 1 = the split-K slab GEMMs + separate
      * point-wise kernels of round 1 (13 launches; also what the *_active entry points and the side-stream interleave use) */
     int step_kernels;
+    /* optional row encoder between the CNN and the decoder (north_star's "row-BiLSTM encoder"; ABSENT from the reference, whose
+     * encoder.py:4 imports GRUCell / LSTMCell and never uses them -- off by default, outside the parity contract): 1 = every
+     * row of the H' x W' feature map is run through a bidirectional TF-style LSTMCell (C/2 units per direction, zero initial
+     * state) along W'; the concatenated outputs replace the features the attention reads.  Needs C in {256, 512}. */
+    int encoder_rnn;
 } lxo_shape;
 
 /* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF

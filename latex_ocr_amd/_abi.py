@@ -20,7 +20,7 @@ LXO_I32, LXO_U8 = 2, 3
 class LxoShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("B", "H", "W", "T", "V", "C", "E", "U", "O", "D", "dtype", "beam", "max_steps")] + \
                [("keep_prob", c_float), ("dropout_seed", c_int), ("div_gamma", c_float), ("div_prob", c_float), ("div_seed", c_int),
-                ("encoder_cnn", c_int), ("no_positional", c_int), ("step_kernels", c_int)]
+                ("encoder_cnn", c_int), ("no_positional", c_int), ("step_kernels", c_int), ("encoder_rnn", c_int)]
 
 
 def bind(lib):

@@ -16,3 +16,6 @@ int lxo_impl_decode_step(const Plan& P, const float* prm, const void* wp, void* 
 int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, int* parents_out, int* steps_out, hipStream_t st);
 int lxo_impl_set_side_stream(hipStream_t s);
 int lxo_impl_set_encoder_side_stream(hipStream_t s);
+// optional row-BiLSTM encoder (model_rowenc.hip): features in ws region "img" in place; backward: "d_img" (f32) in place + parameter gradients
+int lxo_impl_rowenc_fwd(const Plan& P, const float* prm, const void* wp, void* ws, hipStream_t st);
+int lxo_impl_rowenc_bwd(const Plan& P, const float* prm, const void* wp, void* ws, float* grads, hipStream_t st);

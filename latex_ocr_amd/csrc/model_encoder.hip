@@ -1,6 +1,6 @@
 // Host orchestration of the encoder: weight packing, forward, backward.
 // Reference graph: model/encoder.py:25-68 (+ positional.py:42-64).
-#include "plan.h"
+#include "impl.h"
 #include "gemm.h"
 #include "encoder_kernels.h"
 #include "api_util.h"
@@ -54,6 +54,16 @@ int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t
     cp(P.poff[P_OWC], P.koff[K_OW] + (size_t)U * P.ldOW * P.esz, C, O, P.ldOW, O);
     tr(P.poff[P_YWO], P.koff[K_YWO_T], O, V, O, 0, O);
     cp(P.poff[P_YWO], P.koff[K_YWO], O, V, P.Vp, P.Vp);
+    if (P.rnn) {        // row encoder: TF LSTMCell kernel [(C + Ur)][4Ur], rows 0..C-1 = x-part, the rest = h-part
+        const int Ur = P.Ur;
+        for (int d = 0; d < 2; ++d) {
+            const long long k = P.poff[P_ROWF_K + 2 * d];
+            tr(k, P.koff[K_ROWX_T + d], C, 4 * Ur, C, 0, C);
+            cp(k, P.koff[K_ROWX + d], C, 4 * Ur, 4 * Ur, 4 * Ur);
+            tr(k + (long long)C * 4 * Ur, P.koff[K_ROWH_T + d], Ur, 4 * Ur, Ur, 0, Ur);
+            cp(k + (long long)C * 4 * Ur, P.koff[K_ROWH + d], Ur, 4 * Ur, 4 * Ur, 4 * Ur);
+        }
+    }
     return lxo_k_pack_batch(dt, tab, blocks, prm, wp, st);
 }
 
@@ -161,6 +171,7 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
     if (pos) RC(lxo_k_timing_signal(P.ws<float>(ws, W_POS), P.Hp, P.Wp, C, st));
     RC(conv_fwd(P, P.ws<void>(ws, W_P5), P.pk(wp, K_CONV6_F), prm + P.poff[P_CONV6_B], P.ws<void>(ws, W_IMG), P.H6, P.W5, C, C, true,
                 pos ? P.ws<float>(ws, W_POS) : nullptr, P.R, P.ws<void>(ws, W_Y6), st));
+    if (P.rnn) RC(lxo_impl_rowenc_fwd(P, prm, wp, ws, st));        // optional row-BiLSTM over the feature rows (not in the reference; off by default)
     return 0;
 }
 
@@ -212,6 +223,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         pending[xi] = true;
         return 0;
     };
+    if (P.rnn && last_layer >= 6) RC(lxo_impl_rowenc_bwd(P, prm, wp, ws, grads, st));   // "d_img" -> gradient w.r.t. conv6's output (+ timing signal: pass-through)
     for (int l = last_layer; l >= first_layer; --l) {
         void* const X = l >= 2 ? G[XB[l]] : nullptr;
         void* const Y = l >= 2 ? G[YB[l]] : nullptr;

@@ -12,6 +12,7 @@ enum ParamId {
     P_CONV5_W, P_CONV5_B,
     P_CONVS_W, P_CONVS_B,          // encoder_cnn == "cnn": the (2,4) stride-2 conv of encoder.py:54-56 (count 0 otherwise)
     P_CONV6_W, P_CONV6_B,
+    P_ROWF_K, P_ROWF_B, P_ROWB_K, P_ROWB_B,   // optional row-BiLSTM encoder (lxo_shape.encoder_rnn; count 0 otherwise): TF LSTMCell kernel [(C + C/2)][4 C/2] + bias, forward / backward direction
     P_EMB, P_START, P_ATT_IMG, P_WC0, P_BC0, P_WH0, P_BH0, P_WO0, P_BO0,
     P_LSTM_K, P_LSTM_B, P_ATT_H, P_BETA, P_OWH, P_OWC, P_YWO, P_COUNT
 };
@@ -34,6 +35,10 @@ enum PackId {
     K_YWO,         // [O][Vp]
     K_CONVS_F,     // [C][8C]   strided conv, tap-major rows (cnn encoder only)
     K_CONVS_D,     // [8C][C]
+    K_ROWX_T, K_ROWX_T1,   // row encoder (fw, bw): x-part of the LSTM kernel as [4Ur][C]      (ZX = X Kx)
+    K_ROWH_T, K_ROWH_T1,   //   h-part as [4Ur][Ur]                                            (step GEMM h_prev Kh)
+    K_ROWH, K_ROWH1,       //   h-part as stored [Ur][4Ur]                                     (carry GEMM d_z Kh^T)
+    K_ROWX, K_ROWX1,       //   x-part as stored [C][4Ur]                                      (d_X = d_Z Kx^T)
     K_COUNT
 };
 
@@ -47,6 +52,9 @@ enum WsId {
     // decode-only
     W_DEC_IDS, W_DEC_FLAGS, W_DEC_EMB, W_DEC_ZX, W_DEC_LOGITS, W_BEAM_LP, W_BEAM_PAR, W_BEAM_TMP,
     W_COLS,        // cnn encoder only: im2col of the strided conv [B*H6*W5][8C], reused for its column gradient
+    // row encoder only (time-major = [W'][B*H'][.]): input copy, x-part pre-activations (reused for d_X), gates, cell states, outputs (+ bf16 mirror),
+    // d_z (+ mirror), upstream gradient, carried d_c, a zero block
+    W_RXT, W_RZX, W_RG, W_RC, W_RH, W_RHB, W_RDZ, W_RDZB, W_RDH, W_RDCC, W_RZERO,
     W_M2, W_M4, W_M5,   // bf16 mode: pool masks of conv2 / conv4 / conv5 (one byte per pooled element; fused conv + pool epilogue)
     W_COUNT
 };
@@ -58,6 +66,8 @@ struct Plan {
     // encoder geometry
     int H1, W1, H2, W2, H4, W5, H6, Hp, Wp, R;   // conv5 runs at H4 x W2, conv6 reads H6 x W5 (vanilla: H6 == H4)
     bool cnn;                                    // encoder_cnn == "cnn": no pools after conv4/conv5, (2,4)/2 conv instead
+    bool rnn;                                    // encoder_rnn: row-BiLSTM between conv6 and the decoder
+    int Ur;                                      //   units per direction (C / 2)
     int convCin[6], convCout[6], convW[6], convB[6];   // per 3x3 layer: channels and ParamIds
     int Vp, Dp, Rp, XH, HC, REC;   // padded V / D / R (row pitches), O+U, U+C, record width O+2U+C
     int OFF_HT, OFF_CTX;           // record = [o | h | h~ | ctx]: [o|h] feeds the LSTM, [h~|ctx] the attention and o projection
@@ -84,7 +94,7 @@ struct Plan {
     // bf16 mode: conv2 / conv4 / conv5 pool in their own epilogue and leave a routing mask; the full-resolution activations
     // y2 / y4 / y5 are then never written (LXO_POOL_FUSED=0 restores the separate pool kernels for A/B runs)
     bool pool_fused() const;
-    bool dimg_masked() const { return bf && s.E % 32 == 0; }
+    bool dimg_masked() const { return bf && s.E % 32 == 0 && !rnn; }   // with the row encoder "d_img" is the gradient w.r.t. ITS output: plain f32
     template <class T> T* ws(void* base, WsId id) const { return reinterpret_cast<T*>(static_cast<char*>(base) + woff[id]); }
     const void* pk(const void* base, PackId id) const { return static_cast<const char*>(base) + koff[id]; }
     void* pk(void* base, PackId id) const { return static_cast<char*>(base) + koff[id]; }

@@ -12,6 +12,8 @@ static const char* kParamNames[P_COUNT] = {
     "Encoder/convolutional_encoder/conv2d_4/kernel", "Encoder/convolutional_encoder/conv2d_4/bias",
     "Encoder/convolutional_encoder/conv2d_strided/kernel", "Encoder/convolutional_encoder/conv2d_strided/bias",
     "Encoder/convolutional_encoder/conv2d_5/kernel", "Encoder/convolutional_encoder/conv2d_5/bias",
+    "Encoder/row_encoder/bidirectional_rnn/fw/lstm_cell/kernel", "Encoder/row_encoder/bidirectional_rnn/fw/lstm_cell/bias",
+    "Encoder/row_encoder/bidirectional_rnn/bw/lstm_cell/kernel", "Encoder/row_encoder/bidirectional_rnn/bw/lstm_cell/bias",
     "Decoder/embedding_table", "Decoder/start_token",
     "Decoder/AttentionCell/att_img/kernel",
     "Decoder/AttentionCell/att_mechanism/W_c_0", "Decoder/AttentionCell/att_mechanism/b_c_0",
@@ -46,6 +48,7 @@ static const char* kWsNames[W_COUNT] = {
     "recb", "gb", "dzb", "carry_h", "dec_tx", "dec_txe",
     "dec_ids", "dec_flags", "dec_emb", "dec_zx", "dec_logits", "beam_lp", "beam_par", "beam_tmp",
     "cols",
+    "rxt", "rzx", "rg", "rc", "rh", "rhb", "rdz", "rdzb", "rdh", "rdcc", "rzero",
     "m2", "m4", "m5",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
@@ -60,6 +63,8 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     H1 = cd2(s.H); W1 = cd2(s.W);          // after conv1's 2x2 pool      (encoder.py:34)
     H2 = cd2(H1); W2 = cd2(W1);            // after conv2's 2x2 pool      (encoder.py:39)
     cnn = s.encoder_cnn != 0;
+    rnn = s.encoder_rnn != 0;
+    Ur = C / 2;
     H4 = cnn ? H2 : cd2(H2);               // after conv4's (2,1) pool    (encoder.py:47; "cnn": no pool)
     W5 = cd2(W2);                          // after conv5's (1,2) pool    (encoder.py:52) / the stride-2 conv (:54-56)
     H6 = cnn ? cd2(H2) : H4;               // rows conv6 reads
@@ -79,6 +84,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     long long cnt[P_COUNT];
     for (int i = 0; i < 6; ++i) { cnt[convW[i]] = 9LL * ci[i] * co[i]; cnt[convB[i]] = co[i]; }
     cnt[P_CONVS_W] = cnn ? 8LL * C * C : 0; cnt[P_CONVS_B] = cnn ? C : 0;
+    cnt[P_ROWF_K] = cnt[P_ROWB_K] = rnn ? (long long)(C + Ur) * 4 * Ur : 0; cnt[P_ROWF_B] = cnt[P_ROWB_B] = rnn ? 4LL * Ur : 0;
     cnt[P_EMB] = (long long)V * D; cnt[P_START] = D; cnt[P_ATT_IMG] = (long long)C * E;
     cnt[P_WC0] = (long long)C * U; cnt[P_BC0] = U; cnt[P_WH0] = (long long)C * U; cnt[P_BH0] = U;
     cnt[P_WO0] = (long long)C * O; cnt[P_BO0] = O;
@@ -101,6 +107,10 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     kb[K_OW_T] = (size_t)O * ldOWT * esz; kb[K_OW] = (size_t)HC * ldOW * esz;
     kb[K_YWO_T] = (size_t)V * O * esz; kb[K_YWO] = (size_t)O * Vp * esz;
     kb[K_CONVS_F] = cnn ? (size_t)8 * C * C * esz : 0; kb[K_CONVS_D] = kb[K_CONVS_F];
+    for (int d = 0; d < 2; ++d) {
+        kb[K_ROWX_T + d] = rnn ? (size_t)4 * Ur * C * esz : 0; kb[K_ROWX + d] = kb[K_ROWX_T + d];
+        kb[K_ROWH_T + d] = rnn ? (size_t)4 * Ur * Ur * esz : 0; kb[K_ROWH + d] = kb[K_ROWH_T + d];
+    }
     ktotal = 0;
     for (int i = 0; i < K_COUNT; ++i) { koff[i] = ktotal; ktotal += al256(kb[i] + 64); }
 
@@ -116,6 +126,15 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_COLS] = cnn ? BL * H6 * W5 * 8 * C * esz : 0;
     wb[W_Y6] = BL * R * C * esz;          wb[W_IMG] = BL * R * C * esz;
     wb[W_POS] = (size_t)R * C * f4;
+    if (rnn) {
+        const size_t TM = (size_t)B * (Hp > 0 ? Hp : 0) * (Wp > 0 ? Wp : 0), Mr = (size_t)B * (Hp > 0 ? Hp : 0);
+        wb[W_RXT] = TM * C * esz;
+        wb[W_RZX] = 2 * TM * 4 * Ur * f4;             // also holds d_X (TM x C f32) in the backward pass
+        wb[W_RG] = 2 * TM * 4 * Ur * f4; wb[W_RC] = 2 * TM * Ur * f4; wb[W_RH] = 2 * TM * Ur * f4;
+        wb[W_RHB] = bf ? 2 * TM * Ur * 2 : 0;
+        wb[W_RDZ] = 2 * TM * 4 * Ur * f4; wb[W_RDZB] = bf ? 2 * TM * 4 * Ur * 2 : 0;
+        wb[W_RDH] = TM * C * f4; wb[W_RDCC] = 2 * Mr * Ur * f4; wb[W_RZERO] = Mr * 4 * Ur * f4;
+    }
     wb[W_M2] = bf ? BL * H2 * W2 * 128 : 0;
     wb[W_M4] = (bf && !cnn) ? BL * H4 * W2 * 256 : 0;
     wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
@@ -214,6 +233,7 @@ int Plan::validate(char* msg, size_t n) const {
     BAD(s.dtype != LXO_F32 && s.dtype != LXO_BF16, "dtype");
     BAD(s.E > 1024 || s.C > 512, "E <= 1024, C <= 512");
     BAD(R > 16384, "more than 16384 regions");
+    BAD(s.encoder_rnn && s.C != 512 && s.C != 256, "encoder_rnn needs C in {256, 512} (C/2 units per direction, multiples of 128)");
 #undef BAD
     return 0;
 }

@@ -69,7 +69,7 @@ class Engine(object):
         c3 = self._offsets["Encoder/convolutional_encoder/conv2d_2/kernel"][0]
         c4 = self._offsets["Encoder/convolutional_encoder/conv2d_3/kernel"][0]
         c5 = self._offsets["Encoder/convolutional_encoder/conv2d_4/kernel"][0]       # (the cnn variant's strided conv belongs to layer 5's pass)
-        enc_names = [k for k in self._offsets if k.startswith("Encoder/") and k.endswith("/kernel")]
+        enc_names = [k for k in self._offsets if k.startswith("Encoder/convolutional_encoder/") and k.endswith("/kernel")]
         c6 = self._offsets[enc_names[-1]][0]                                          # the VALID conv in front of the decoder
         ywo = self._offsets["Decoder/AttentionCell/rnn/y_W_o"][0]        # the last variable: final before the recurrence runs
         # (range, encoder layers whose backward makes it final): a layer's kernel is final after its own pass, its bias no later
@@ -99,6 +99,7 @@ class Engine(object):
         sh.encoder_cnn = 1 if d.get("cnn") else 0                 # configs/model.json encoder_cnn (encoder.py:46-56)
         sh.no_positional = 0 if d.get("positional", True) else 1  # positional_embeddings (encoder.py:60-65)
         sh.step_kernels = self.step_kernels
+        sh.encoder_rnn = 1 if d.get("row_bilstm") else 0        # optional row-BiLSTM encoder (not in the reference; off by default)
         return sh
 
     def _stream(self):

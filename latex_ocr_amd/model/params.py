@@ -31,7 +31,9 @@ def dims_from_config(config):
         raise NotImplementedError("encoder_cnn=%r (model/encoder.py knows 'vanilla' and 'cnn')" % (enc,))
     return dict(C=512, E=ac.get("dim_e", 256), U=ac.get("num_units", 512),
                 O=ac.get("dim_o", 512), D=ac.get("dim_embeddings", 80), cnn=(enc == "cnn"),
-                positional=bool(getattr(config, "positional_embeddings", True)))
+                positional=bool(getattr(config, "positional_embeddings", True)),
+                # optional row encoder (north_star's row-BiLSTM; NOT in the reference, off unless configs/model.json says "encoder_rnn": "bilstm")
+                row_bilstm=(getattr(config, "encoder_rnn", None) in ("bilstm", "BiLSTM", True)))
 
 
 def param_specs(n_tok, dims=None):
@@ -46,6 +48,11 @@ def param_specs(n_tok, dims=None):
         scope = "Encoder/convolutional_encoder/conv2d" + ("" if i == 0 else "_%d" % i)
         specs.append((scope + "/kernel", shp, "glorot"))
         specs.append((scope + "/bias", (shp[3],), "zeros"))
+    if d.get("row_bilstm"):  # optional row encoder: a bidirectional TF LSTMCell (C/2 units per direction) over every feature-map row
+        R_ = "Encoder/row_encoder/bidirectional_rnn/"
+        for dr in ("fw", "bw"):
+            specs.append((R_ + dr + "/lstm_cell/kernel", (C + C // 2, 4 * (C // 2)), "glorot"))
+            specs.append((R_ + dr + "/lstm_cell/bias", (4 * (C // 2),), "zeros"))
     specs += [
         ("Decoder/embedding_table", (V, D), "embed"),
         ("Decoder/start_token", (D,), "embed"),

@@ -40,6 +40,7 @@ import torch
 import torch.nn.functional as F
 
 DEFAULT_DIMS = dict(C=512, E=256, U=512, O=512, D=80)
+ROW_ = "Encoder/row_encoder/bidirectional_rnn/"
 CONV_CHANNELS = [(1, 64), (64, 128), (128, 256), (256, 256), (256, 512), (512, 512)]
 
 
@@ -59,6 +60,10 @@ def param_specs(V, dims=None):
         sfx = "" if i == 0 else "_%d" % i
         specs.append(("Encoder/convolutional_encoder/conv2d%s/kernel" % sfx, shp, "glorot"))
         specs.append(("Encoder/convolutional_encoder/conv2d%s/bias" % sfx, (shp[3],), "zeros"))
+    if d.get("row_bilstm"):     # optional row encoder of the product (NOT in the reference: no reference line to cite)
+        for dr in ("fw", "bw"):
+            specs.append((ROW_ + dr + "/lstm_cell/kernel", (C + C // 2, 4 * (C // 2)), "glorot"))
+            specs.append((ROW_ + dr + "/lstm_cell/bias", (4 * (C // 2),), "zeros"))
     A = "Decoder/AttentionCell/"
     specs += [
         ("Decoder/embedding_table", (V, D), "embed"),
@@ -168,9 +173,35 @@ def encoder(P, img_u8, positional=True, return_all=False):
     x = x.permute(0, 2, 3, 1)
     if positional:
         x = x + timing_signal_2d(x.shape[1], x.shape[2], x.shape[3])[None]          # :66
+    if (ROW_ + "fw/lstm_cell/kernel") in P:
+        x = row_bilstm(P, x)
     if return_all:
         return x, [a.permute(0, 2, 3, 1) for a in acts]
     return x
+
+
+def row_bilstm(P, x):
+    """The product's optional row encoder (lxo_shape.encoder_rnn; north_star's "row-BiLSTM encoder").  NOT part of the reference
+    (encoder.py:4 imports GRUCell / LSTMCell and never uses them), so this is a SPECIFICATION of the extension, not a restatement:
+    every row of the [B, H', W', C] feature map is a sequence over W'; a forward and a backward +TF LSTMCell (C/2 units, gate order
+    i, j, f, o, forget_bias 1.0, zero initial state) run over it and their outputs are concatenated [forward | backward]."""
+    B, H, W, C = x.shape
+    U = C // 2
+    X = x.reshape(B * H, W, C)
+    outs = []
+    for dr, rev in (("fw", False), ("bw", True)):
+        K, b = P[ROW_ + dr + "/lstm_cell/kernel"], P[ROW_ + dr + "/lstm_cell/bias"]
+        c = torch.zeros(B * H, U, dtype=x.dtype)
+        h = torch.zeros(B * H, U, dtype=x.dtype)
+        hs = [None] * W
+        for w in (range(W - 1, -1, -1) if rev else range(W)):
+            z = torch.cat([X[:, w], h], dim=1) @ K + b
+            i, j, f, og = z[:, :U], z[:, U:2 * U], z[:, 2 * U:3 * U], z[:, 3 * U:]
+            c = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+            h = torch.sigmoid(og) * torch.tanh(c)
+            hs[w] = h
+        outs.append(torch.stack(hs, dim=1))
+    return torch.cat(outs, dim=-1).reshape(B, H, W, C)
 
 
 A_ = "Decoder/AttentionCell/"

@@ -27,6 +27,7 @@ class Sim(object):
         self.shape = _abi.LxoShape(B, H, W, T, V, d["C"], d["E"], d["U"], d["O"], d["D"], dtype, beam, max_steps)
         self.shape.encoder_cnn = 1 if d.get("cnn") else 0
         self.shape.no_positional = 0 if d.get("positional", True) else 1
+        self.shape.encoder_rnn = 1 if d.get("row_bilstm") else 0
         self.dims, self.V, self.dtype = d, V, dtype
         self.specs = PP.param_specs(V, d)
         self.P = params if params is not None else PP.init_params(V, seed, d)

@@ -86,6 +86,30 @@ def _check_fwd_bwd():
     assert checked >= 9
 
 
+def test_row_bilstm_encoder_vs_its_specification():
+    """The optional row-BiLSTM encoder (lxo_shape.encoder_rnn; not in the reference) against oracle/ref_model.py:row_bilstm:
+    loss and the gradients of the four new variables and of a conv kernel upstream of it, f32."""
+    import torch
+    from oracle import ref_model as R
+    img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
+    dims = dict(row_bilstm=True)
+    S = Sim(2, 32, 48, f.shape[1], 11, dtype=0, seed=2, dims=dims)
+    P = {k: torch.from_numpy(v.copy()) for k, v in S.P.items()}
+    S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+    S.ck(S.L.lxo_decoder_train_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), None), "dec")
+    S.ck(S.L.lxo_ce_loss_fwd_bwd(S.sref(), ptr(S.ws), ptr(f), ptr(l), ctypes.c_float(1.0 / int(l.sum())), None), "loss")
+    S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), None), "decbwd")
+    S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, None), "encbwd")
+    loss, G, _, _ = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l))
+    st = S.region("loss", np.float32)[:2]
+    assert abs(st[0] / st[1] - float(loss)) < 2e-5 * float(loss)
+    row = "Encoder/row_encoder/bidirectional_rnn/"
+    for k in (row + "fw/lstm_cell/kernel", row + "fw/lstm_cell/bias", row + "bw/lstm_cell/kernel", row + "bw/lstm_cell/bias",
+              "Encoder/convolutional_encoder/conv2d_5/kernel", "Encoder/convolutional_encoder/conv2d_2/bias", "Decoder/AttentionCell/att_img/kernel"):
+        g, r = S.grad(k), G[k].numpy()
+        assert np.abs(g - r).max() <= 5e-5 * max(np.abs(r).max(), 1e-6) + 1e-9, (k, np.abs(g - r).max(), np.abs(r).max())
+
+
 def test_forward_bf16_within_loss_bar():
     S, img, f, l = _run(1)
     st = S.region("loss", np.float32)[:2]
