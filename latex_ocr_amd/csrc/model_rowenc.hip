@@ -18,7 +18,7 @@ namespace {
 
 // rows of 16-byte pieces: TO_TM: dst row (w*M + m) <- src row (m*T + w); else the reverse
 template <bool TO_TM>
-__global__ __launch_bounds__(256) void rows_permute_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int M, int T, int pieces) {
+__global__ __launch_bounds__(256) void rows_permute_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int M, int T, int pieces) {
     const long long total = (long long)M * T * pieces;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long row = i / pieces;                       // destination row
@@ -51,8 +51,8 @@ int permute(bool to_tm, const void* src, void* dst, int M, int T, size_t row_byt
     const int pieces = (int)(row_bytes / 16);
     long long blocks = ((long long)M * T * pieces + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (to_tm) hipLaunchKernelGGL((rows_permute_kernel<true>), dim3((int)blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, M, T, pieces);
-    else hipLaunchKernelGGL((rows_permute_kernel<false>), dim3((int)blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, M, T, pieces);
+    if (to_tm) hipLaunchKernelGGL((rows_permute_kernel<true>), dim3((int)blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, M, T, pieces);
+    else hipLaunchKernelGGL((rows_permute_kernel<false>), dim3((int)blocks), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, M, T, pieces);
     return (int)hipGetLastError();
 }
 
