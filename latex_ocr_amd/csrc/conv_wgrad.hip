@@ -15,8 +15,6 @@
 
 namespace {
 
-__device__ unsigned lxo_wg_zero_line[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
 constexpr int WTH = 2, WTW = 64, WPW = WTW + 2, WPH = WTH + 2, WPROWS = WPH * WPW;   // 264 patch pixels
 constexpr int WTHREADS = 512;
 constexpr int WPATCH = 5 * WTHREADS * 16;           // 40960 B: 2560 slots >= 264 * 8
@@ -43,7 +41,7 @@ HIP_DYNAMIC_SHARED(char, lxo_wgrad_lds)
 namespace {
 
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co, int tiles_x, int tiles_y, int nblocks, int per_split) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wci = wave >> 2, wco = wave & 3;            // 2 x 4 waves: 32 ci x 32 co each (x 9 taps)
     // XCD-aware order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  The `ntiles` (ci, co) tiles of ONE pixel
     // range read the same input and d_out blocks, so they are made neighbours on ONE XCD (the n-th workgroup of XCD x is
@@ -56,34 +54,60 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     const int Cout = p.J;
     const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(p.B);
-    const char* zline = reinterpret_cast<const char*>(lxo_wg_zero_line);
     const int pb_beg = split * per_split, pb_end = min(nblocks, pb_beg + per_split);
     if (pb_beg >= pb_end) return;
 
-    const int sch = tid & 7;                               // patch: 16-byte chunk (8 channels) of the 64-channel row
-    const int dch = tid & 15;                              // d_out: 16-byte chunk of the 128-channel row
-    auto issue = [&](int pb, int stage) {
-        const int tx_i = pb % tiles_x, ty_i = (pb / tiles_x) % tiles_y, b = pb / (tiles_x * tiles_y);
+    // ---- the LDS-DMA of one pixel block: 5 (wave 0) / 4 requests for the patch, 4 for d_out, through buffer resources.
+    // The request addresses used to be rebuilt from the block index for every request (divisions, 64-bit multiplies, a select
+    // against a zero line: ~25 VALU instructions, a third of them quarter rate); in-kernel stamps of a build without the DMA put
+    // that at 2.1 k of a block's 7.6 k cycles (the matrix pipe waits while a wave issues VALU work).  Now: everything that depends
+    // on the lane is computed ONCE (byte offset of the lane's chunk from the block's patch origin; its patch row / column, packed),
+    // everything that depends on the block is SCALAR (soffset of the request; the valid row / column window of the block), and
+    // zero padding = an out-of-range offset (the buffer returns zeros): 4 VALU instructions per patch request, 2 per d_out request.
+    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+    const unsigned m0b = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lxo_wgrad_lds);
+    const int nB = p.M / (p.Ho * p.Wo);
+    const unsigned padoff = (unsigned)p.pad * (unsigned)(p.W + 1) * (unsigned)p.Cin * 2u;     // the patch origin of the first block lies `pad` rows and columns before the tensor
+    const lxo_rsrc_t rx = lxo_make_rsrc(reinterpret_cast<const char*>(X) - padoff, (unsigned)((long long)nB * p.H * p.W * p.Cin * 2) + padoff);
+    const lxo_rsrc_t rdy = lxo_make_rsrc(DY, (unsigned)((long long)nB * p.Ho * p.Wo * Cout * 2));
+    unsigned prel[5], ppk[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {                          // patch pixel prow = (tid >> 3) + 64 j, 16-byte chunk tid & 7 (swizzled by the pixel pair)
+        const int prow = (tid >> 3) + 64 * j;
+        const int py = prow / WPW, px = prow - py * WPW;
+        prel[j] = (unsigned)(((py * p.W + px) * p.Cin + (((tid & 7) ^ ((prow >> 1) & 7)) << 3)) * 2);
+        ppk[j] = ((unsigned)py << 16) | (unsigned)px;
+    }
+    // d_out: block pixel k = (tid >> 4) + 32 j = row j >> 1, column (tid >> 4) + 32 (j & 1); 16-byte chunk tid & 15 swizzled by k & 15 (the same for all j)
+    const int dgch = ((tid & 15) ^ ((tid >> 4) & 15)) << 3;
+    const unsigned drel = (unsigned)(((tid >> 4) * Cout + dgch) * 2);
+    const int dxq = (co0 + dgch) < Cout ? (tid >> 4) : 0x7FFF0000;                 // a channel chunk beyond Cout never passes the column test
+    int tx_i = pb_beg % tiles_x, ty_i = (pb_beg / tiles_x) % tiles_y, b_i = pb_beg / (tiles_x * tiles_y);   // walked, not divided, from here on
+    auto issue = [&](int stage) {                          // the block (b_i, ty_i, tx_i); then steps to the next one
         const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
+        const unsigned sx = (unsigned)((((b_i * p.H + oy0) * p.W + ox0) * p.Cin + ci0) * 2);
+        const int loy = max(0, p.pad - oy0), lox = max(0, p.pad - ox0);
+        const int ny = min(WPH, p.H + p.pad - oy0) - loy, nx = min(WPW, p.W + p.pad - ox0) - lox;   // >= 1: the block exists
+        const unsigned lo = __builtin_amdgcn_readfirstlane(((unsigned)loy << 16) | (unsigned)lox);
+        const unsigned lim = __builtin_amdgcn_readfirstlane(((unsigned)(ny - 1) << 16) | (unsigned)(nx - 1));
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {                      // 5 LDS-DMA: patch pixel prow = (tid >> 3) + 64 j
-            const int prow = (tid >> 3) + 64 * j;
-            const int py = prow / WPW, px = prow - py * WPW;
-            const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
-            const bool ok = prow < WPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const int gch = (sch ^ ((prow >> 1) & 7)) << 3;
-            const void* src = ok ? (const void*)(X + (((long long)b * p.H + iy) * p.W + ix) * p.Cin + ci0 + gch) : (const void*)zline;
-            LXO_GLDS16_HIDDEN(src, lxo_wgrad_lds, stage * WSTAGE + (wave * 64 + 512 * j) * 16);
+        for (int j = 0; j < 5; ++j) {
+            if (j == 4 && wave != 0) break;                 // pixels 256..263: wave 0 only (slots beyond 263 are never read)
+            const u16x2_t t = __builtin_bit_cast(u16x2_t, ppk[j]) - __builtin_bit_cast(u16x2_t, lo);
+            const u16x2_t m = __builtin_elementwise_min(t, __builtin_bit_cast(u16x2_t, lim));
+            const bool ok = __builtin_bit_cast(unsigned, m) == __builtin_bit_cast(unsigned, t) && (j < 4 || tid < 64);
+            const unsigned voff = ok ? prel[j] : LXO_BLDS_OOB;
+            LXO_BLDS16(voff, rx, sx, lxo_wgrad_lds, m0b, stage * WSTAGE + (wave * 64 + 512 * j) * 16);
         }
+        const unsigned sd = (unsigned)((((b_i * p.Ho + oy0) * p.Wo + ox0) * Cout + co0) * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                      // 4 LDS-DMA: block pixel k = (tid >> 4) + 32 j
-            const int k = (tid >> 4) + 32 * j;
-            const int oy = oy0 + (k >> 6), ox = ox0 + (k & 63);
-            const int gch = (dch ^ (k & 15)) << 3;            // the GLOBAL chunk this lane fetches (LDS slot dch holds it)
-            const bool ok = oy < p.Ho && ox < p.Wo && (co0 + gch) < Cout;
-            const void* src = ok ? (const void*)(DY + (((long long)b * p.Ho + oy) * p.Wo + ox) * Cout + co0 + gch) : (const void*)zline;
-            LXO_GLDS16_HIDDEN(src, lxo_wgrad_lds, stage * WSTAGE + WPATCH + (wave * 64 + 512 * j) * 16);
+        for (int j = 0; j < 4; ++j) {
+            const int hx = (oy0 + (j >> 1) < p.Ho) ? p.Wo - ox0 - 32 * (j & 1) : 0;            // scalar: columns of this request's row that exist
+            const unsigned voff = dxq < hx ? drel : LXO_BLDS_OOB;
+            const unsigned sdj = __builtin_amdgcn_readfirstlane(sd + (unsigned)((((j >> 1) * p.Wo + 32 * (j & 1)) * Cout) * 2));
+            LXO_BLDS16(voff, rdy, sdj, lxo_wgrad_lds, m0b, stage * WSTAGE + WPATCH + (wave * 64 + 512 * j) * 16);
         }
+        if (++tx_i == tiles_x) { tx_i = 0; if (++ty_i == tiles_y) { ty_i = 0; ++b_i; } }
     };
 
     f32x16 acc[9];
@@ -112,7 +136,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
 
 #define WSTAMP(i) do { if (p.dbg && tid == 0 && (i) < 64) p.dbg[(long long)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
     WSTAMP(0);
-    issue(pb_beg, 0);
+    issue(0);
     for (int pb = pb_beg; pb < pb_end; ++pb) {
         const int stage = (pb - pb_beg) & 1;
         WSTAMP(1 + 3 * (pb - pb_beg));
@@ -120,57 +144,80 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
         WSTAMP(2 + 3 * (pb - pb_beg));
         __builtin_amdgcn_s_barrier();
         WSTAMP(3 + 3 * (pb - pb_beg));
-        if (pb + 1 < pb_end) issue(pb + 1, stage ^ 1);
+#ifndef LXO_WG_DIAG
+#define LXO_WG_DIAG 0                                      // measurement builds only: 1 = no DMA after the first block, 2 = no LDS reads in the loop, 4 = no v_perm
+#endif
+        if (pb + 1 < pb_end && !((LXO_WG_DIAG & 1) && pb > pb_beg)) issue(stage ^ 1);
         const char* sb = lxo_wgrad_lds + stage * WSTAGE;
         const char* pk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pk[k] = sb + poff[k];
         const char* da = sb + doff_a;
         const char* db = sb + doff_b;
-        // One K-step of raw operands (2 d_out reads + 9 patch reads = 22 dwords) is read AHEAD: the reads of K-step ks + 1 are
-        // issued before the MFMAs of K-step ks, so the LDS latency hides under 288 cycles of matrix work instead of stalling
-        // every K-step (SQ_WAIT_ANY was 31 % with the reads and the MFMAs of a K-step back to back).
-        u32x2 rb[2][2], rd[2][9];
-        auto read_ks = [&](int ks, u32x2 (&b2)[2], u32x2 (&d9)[9]) {
-            const int ty = ks >> 2, xc = (ks & 3) * 16;
-            const int cd = (ty * 64 + xc) * 256;
-            b2[0] = tr_read(da + cd);
-            b2[1] = tr_read(db + cd);
+        // The K loop walks 16 sub-steps (16-pixel column group xg, patch row `row` of the four): patch row `row` is the kh = row
+        // operand of output row 0 and the kh = row - 1 operand of output row 1, so it is read ONCE and feeds 3 + 3 MFMAs (rows
+        // 0 and 3: 3).  Every non-matrix instruction costs ~5 cycles of the SIMD's matrix pipe here (stamps: 926 cycles per 18
+        // MFMAs with 70 other instructions in round 2's loop), so the kw-shifted operands are built with as few of them as the
+        // LDS allows: the kw = 0 and the kw = 2 windows (pixels 0..7 and 2..9 of the lane's run) are BOTH read from LDS (2
+        // transposing reads each: the second window used to be four v_mov out of an odd register pair), the kw = 1 window is
+        // four v_perm of the two (all three from LDS is LDS-bound).  Per 18 MFMAs: 20 LDS reads + 16 v_perm (round 2: 22 + 48).
+        // Raw patch operands are read one sub-step ahead, the d_out operands of both output rows one column group ahead.
+        u32x2 ra[2][4], rb[2][4];
+        auto read_b = [&](int xg, u32x2 (&b4)[4]) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int q3 = 0; q3 < 3; ++q3) {
-                    const int cc = (ty + kh) * WPW + xc + 4 * q3;        // even, compile-time
-                    d9[kh * 3 + q3] = tr_read(pk[(cc >> 1) & 7] + cc * 128);
-                }
+            for (int ty = 0; ty < 2; ++ty) {
+                const int cd = (ty * 64 + xg * 16) * 256;
+                b4[2 * ty] = tr_read(da + cd);
+                b4[2 * ty + 1] = tr_read(db + cd);
+            }
         };
-        read_ks(0, rb[0], rd[0]);
+        auto read_a = [&](int s, u32x2 (&r)[4]) {
+            const int cc = (s & 3) * WPW + (s >> 2) * 16;                       // even, compile-time
+            r[0] = tr_read(pk[(cc >> 1) & 7] + cc * 128);                       // pixels 0..3
+            r[1] = tr_read(pk[((cc + 4) >> 1) & 7] + (cc + 4) * 128);           //        4..7
+            r[2] = tr_read(pk[((cc + 2) >> 1) & 7] + (cc + 2) * 128);           //        2..5
+            r[3] = tr_read(pk[((cc + 6) >> 1) & 7] + (cc + 6) * 128);           //        6..9
+        };
+        read_b(0, rb[0]);
+        read_a(0, ra[0]);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {                   // 16 pixels per K-step: row ty = ks>>2, x = (ks&3)*16 + 8h ..
-            const int cur = ks & 1;                          // compile-time after unrolling
+        for (int s = 0; s < 16; ++s) {
+            const int xg = s >> 2, row = s & 3, cur = s & 1, bcur = xg & 1;     // compile-time after unrolling
             // Two waves share a SIMD's MFMA pipe; with the default (age-based) arbitration one runs ahead and then idles at
             // the block barrier while the other finishes alone (2 k of a block's 8.3 k cycles in the stamps).  Priority falls
             // as a wave advances through the block, so the wave that is behind wins the pipe and both arrive together.
-            if (ks == 0) __builtin_amdgcn_s_setprio(3);
-            else if (ks == 2) __builtin_amdgcn_s_setprio(2);
-            else if (ks == 4) __builtin_amdgcn_s_setprio(1);
-            else if (ks == 6) __builtin_amdgcn_s_setprio(0);
-            if (ks + 1 < 8) read_ks(ks + 1, rb[cur ^ 1], rd[cur ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);              // reads of ks + 1 stay ahead of the MFMAs of ks; nothing is hoisted further (144 accumulator registers)
-            const u32x4 bfr = {rb[cur][0][0], rb[cur][0][1], rb[cur][1][0], rb[cur][1][1]};
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                // patch row ty + kh, pixels xk .. xk+11: six dwords of pixel pairs
-                const unsigned d[6] = {rd[cur][kh * 3][0], rd[cur][kh * 3][1], rd[cur][kh * 3 + 1][0], rd[cur][kh * 3 + 1][1],
-                                       rd[cur][kh * 3 + 2][0], rd[cur][kh * 3 + 2][1]};
-                const u32x4 a0 = {d[0], d[1], d[2], d[3]};
-                const u32x4 a1 = {__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
-                                  __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16)};
-                const u32x4 a2 = {d[1], d[2], d[3], d[4]};
-                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 0], 0, 0, 0);
-                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 1], 0, 0, 0);
-                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, bfr), acc[kh * 3 + 2], 0, 0, 0);
+            if (s == 0) __builtin_amdgcn_s_setprio(3);
+            else if (s == 4) __builtin_amdgcn_s_setprio(2);
+            else if (s == 8) __builtin_amdgcn_s_setprio(1);
+            else if (s == 12) __builtin_amdgcn_s_setprio(0);
+            if (!(LXO_WG_DIAG & 2)) {
+                if (s + 1 < 16) read_a(s + 1, ra[cur ^ 1]);
+                if (row == 1 && xg + 1 < 4) read_b(xg + 1, rb[bcur ^ 1]);
+            } else if (s == 0) { read_a(1, ra[1]); read_b(1, rb[1]); }
+            __builtin_amdgcn_sched_barrier(0);              // the reads of sub-step s + 1 stay ahead of the MFMAs of s; nothing is hoisted further
+            const u32x2* r = ra[cur];
+            const u32x4 a0 = {r[0][0], r[0][1], r[1][0], r[1][1]};
+            const u32x4 a2 = {r[2][0], r[2][1], r[3][0], r[3][1]};
+            const u32x4 b0 = {rb[bcur][0][0], rb[bcur][0][1], rb[bcur][1][0], rb[bcur][1][1]};   // output row 0: kh = row
+            const u32x4 b1 = {rb[bcur][2][0], rb[bcur][2][1], rb[bcur][3][0], rb[bcur][3][1]};   // output row 1: kh = row - 1
+            // order: one kw = 0 MFMA first, the four v_perm of the kw = 1 window in its shadow, then the rest
+#define WG_MFMA(A, B, T) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), acc[T], 0, 0, 0)
+            if (row <= 2) WG_MFMA(a0, b0, row * 3 + 0); else WG_MFMA(a0, b1, (row - 1) * 3 + 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 a1 = (LXO_WG_DIAG & 4) ? u32x4{r[0][1], r[1][0], r[1][1], r[3][1]} :
+                             u32x4{__builtin_amdgcn_alignbit(r[0][1], r[0][0], 16), __builtin_amdgcn_alignbit(r[1][0], r[0][1], 16),
+                                   __builtin_amdgcn_alignbit(r[1][1], r[1][0], 16), __builtin_amdgcn_alignbit(r[3][1], r[1][1], 16)};
+            __builtin_amdgcn_sched_barrier(0);
+            if (row <= 2) {
+                WG_MFMA(a2, b0, row * 3 + 2);
+                WG_MFMA(a1, b0, row * 3 + 1);
+                if (row >= 1) WG_MFMA(a0, b1, (row - 1) * 3 + 0);
             }
+            if (row >= 1) {
+                WG_MFMA(a2, b1, (row - 1) * 3 + 2);
+                WG_MFMA(a1, b1, (row - 1) * 3 + 1);
+            }
+#undef WG_MFMA
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -207,6 +254,10 @@ static thread_local unsigned long long* g_wgrad_dbg = nullptr;
 extern "C" int lxo_wgrad_debug(unsigned long long* buf) { g_wgrad_dbg = buf; return 0; }
 int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     if (!p.conv || p.Cin % 64 || p.J % 8) return -2;
+    {   // both tensors are addressed through 32-bit buffer offsets (and 2^31 is the kernel's out-of-range offset)
+        const long long nb = p.M / (p.Ho * p.Wo);
+        if (nb * p.H * p.W * p.Cin * 2 + 2LL * (p.W + 1) * p.Cin >= (1LL << 31) || nb * p.Ho * p.Wo * p.J * 2 >= (1LL << 31)) return -2;
+    }
     {   // per device, not per process (see conv_igemm.hip attr_needed)
         static bool done[64] = {};
         int dev = 0;

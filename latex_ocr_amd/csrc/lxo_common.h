@@ -99,6 +99,27 @@ LXO_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
                  : "=&s"(keep_m0_) : "v"(voff), "s"(sbase), "s"((m0base) + (unsigned)(byte_off)) : "memory"); } while (0)
 #endif
 
+// LDS-DMA through a BUFFER RESOURCE (`buffer_load_dwordx4 voff, s[rsrc], soff offen lds`): the address is base + soff (scalar) + voff
+// (32 bits per lane), and a lane whose soff + voff lies at or beyond num_records writes ZEROS into its LDS slot (measured:
+// tools/blds_probe.hip) -- zero padding costs one v_cndmask of the offset instead of a 64-bit select against a zero line.  The
+// request is also cheaper to issue than the 64-bit-vaddr form (tools/issue_probe.hip: ~29 vs ~56 cycles of the matrix pipe).
+#define LXO_BLDS_OOB 0x80000000u          // an offset that is out of range of every buffer below 2 GB
+#ifndef LXO_BLDS16
+typedef __attribute__((ext_vector_type(4))) int lxo_rsrc_t;
+static __device__ __forceinline__ lxo_rsrc_t lxo_make_rsrc(const void* base, unsigned nbytes) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    lxo_rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));   // stride 0: raw buffer
+    r[2] = __builtin_amdgcn_readfirstlane((int)nbytes);
+    r[3] = 0x00020000;
+    return r;
+}
+#define LXO_BLDS16(voff, rsrc, soff, lds_base, m0base, byte_off) do { unsigned keep_m0_; \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_m0_) : "v"(voff), "s"(rsrc), "s"(soff), "s"((m0base) + (unsigned)(byte_off)) : "memory"); } while (0)
+#endif
+
 // dtype codes of the C ABI (include/lxo.h)
 #ifndef LXO_F32
 #define LXO_F32 0

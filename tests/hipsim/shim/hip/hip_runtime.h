@@ -290,6 +290,15 @@ template <class G, class Lp> inline void hipsim_global_load_lds(G g, Lp l, unsig
 // csrc/lxo_common.h: the inline-asm LDS-DMA
 #define LXO_GLDS16_HIDDEN(gsrc, lds_base, byte_off) hipsim_global_load_lds((const void*)(gsrc), (char*)(lds_base) + (byte_off), 16, 0, 0)
 #define LXO_GLDS16_SADDR(voff, sbase, lds_base, m0base, byte_off) hipsim_global_load_lds((const void*)((const char*)(sbase) + (voff)), (char*)(lds_base) + (byte_off), 16, 0, 0)
+// the buffer-resource form: base + soff + voff, zeros when soff + voff is out of range
+struct lxo_rsrc_t { const char* base; unsigned nbytes; };
+inline lxo_rsrc_t lxo_make_rsrc(const void* base, unsigned nbytes) { return lxo_rsrc_t{(const char*)base, nbytes}; }
+inline void hipsim_buffer_load_lds16(unsigned voff, lxo_rsrc_t r, unsigned soff, char* dst) {
+    const unsigned long long off = (unsigned long long)voff + soff;
+    char* d = dst + hipsim::lane() * 16;
+    if (off + 16 > r.nbytes) memset(d, 0, 16); else memcpy(d, r.base + off, 16);
+}
+#define LXO_BLDS16(voff, rsrc, soff, lds_base, m0base, byte_off) hipsim_buffer_load_lds16((voff), (rsrc), (soff), (char*)(lds_base) + (byte_off))
 
 // ---- host API subset used by the C-ABI layer ----
 inline hipError_t hipGetLastError() { return hipSuccess; }

@@ -12,6 +12,7 @@ case $what in
   ctimeline) timeout 300 python tools/conv_timeline.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_conv_timeline.log; echo "timeline rc=$?";;
   rstamps)  timeout 300 python tools/rstep_stamps.py > gpurun_out/${TAG}_rstep_stamps.log 2>&1; echo "rstamps rc=$?";;
   wstamps)  timeout 300 python tools/wgrad_stamps.py > gpurun_out/${TAG}_wgrad_stamps.log 2>&1; echo "wstamps rc=$?";;
+  wtime)    for v in "" _wgold _wg2 _wg5 _wg7; do f=latex_ocr_amd/liblxo$v.so; [ -f $f ] || continue; echo "== $f"; LXO_LIB_PATH=$R/$f timeout 300 python tools/wgrad_time.py 2>&1 | grep -v amdgpu; done > gpurun_out/${TAG}_wgrad_time.log 2>&1; echo "wtime rc=$?"; cat gpurun_out/${TAG}_wgrad_time.log;;
   *) bash tools/gpu_call.sh $TAG $what;;
 esac
 done
