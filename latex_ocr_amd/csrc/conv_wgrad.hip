@@ -40,7 +40,7 @@ HIP_DYNAMIC_SHARED(char, lxo_wgrad_lds)
 
 namespace {
 
-__global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co, int tiles_x, int tiles_y, int nblocks, int per_split) {
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co, int tiles_x, int tiles_y, int nblocks, int nsplit, float stagger) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wci = wave >> 2, wco = wave & 3;            // 2 x 4 waves: 32 ci x 32 co each (x 9 taps)
     // XCD-aware order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  The `ntiles` (ci, co) tiles of ONE pixel
@@ -54,7 +54,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     const int Cout = p.J;
     const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(p.B);
-    const int pb_beg = split * per_split, pb_end = min(nblocks, pb_beg + per_split);
+    // Pixel ranges of UNEQUAL length: every workgroup ends with 73 728 f32 atomics per lane-row into the same few MB, and with equal
+    // ranges all 256 of them arrive there together -- the atomic units then serve 18.9 M lane-atomics while every matrix pipe idles
+    // (stamps: 44-65 k cycles, 10-20 % of the launch).  Range length grows linearly with the split index (1 -/+ stagger at the ends),
+    // so the workgroups finish spread over about the time the atomics take and the epilogues of the early ones run under the K
+    // loops of the late ones.  boundary(s) = nblocks * (u + stagger * (u * u - u)), u = s / nsplit.
+    if (split >= nsplit) return;
+    auto boundary = [&](int sidx) {
+        const float u = (float)sidx / (float)nsplit;
+        const int v = (int)((float)nblocks * (u + stagger * (u * u - u)) + 0.5f);
+        return sidx >= nsplit ? nblocks : min(nblocks, max(0, v));
+    };
+    const int pb_beg = __builtin_amdgcn_readfirstlane(boundary(split)), pb_end = __builtin_amdgcn_readfirstlane(boundary(split + 1));
     if (pb_beg >= pb_end) return;
 
     // ---- the LDS-DMA of one pixel block: 5 (wave 0) / 4 requests for the patch, 4 for d_out, through buffer resources.
@@ -147,7 +158,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
 #ifndef LXO_WG_DIAG
 #define LXO_WG_DIAG 0                                      // measurement builds only: 1 = no DMA after the first block, 2 = no LDS reads in the loop, 4 = no v_perm
 #endif
-        if (pb + 1 < pb_end && !((LXO_WG_DIAG & 1) && pb > pb_beg)) issue(stage ^ 1);
         const char* sb = lxo_wgrad_lds + stage * WSTAGE;
         const char* pk[8];
 #pragma unroll
@@ -180,6 +190,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
         };
         read_b(0, rb[0]);
         read_a(0, ra[0]);
+        __builtin_amdgcn_sched_barrier(0);                  // the first LDS reads fly while the next block's DMA requests are issued
+        if (pb + 1 < pb_end && !((LXO_WG_DIAG & 1) && pb > pb_beg)) issue(stage ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int xg = s >> 2, row = s & 3, cur = s & 1, bcur = xg & 1;     // compile-time after unrolling
@@ -276,11 +289,17 @@ int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     if (nsplit > nblocks) nsplit = nblocks;
     const int per_split = cdiv(nblocks, nsplit);
     nsplit = cdiv(nblocks, per_split);
+    // the end-of-range spread that hides the atomic epilogue in units of blocks at each end of the ramp (swept in-step: 0 / 4.3 / 10 / 14 / 20 -> 0.48 / 0.50 / 0.526 / 0.50 / 0.48 of the MFMA peak; the
+    // spread also takes the 256 workgroups out of phase, which evens out the DMA bursts of conv2 -- one tile, no operand shared between workgroups, 4 TB/s)
+    static const float stag_scale = getenv("LXO_WG_STAGGER") ? (float)atof(getenv("LXO_WG_STAGGER")) : 10.f;
+    float stagger = stag_scale / (float)per_split;
+    if (stagger > 0.5f) stagger = 0.5f;
+    if (nsplit < 2) stagger = 0.f;
     GemmTN q = p;
     q.nbatch = tiles;
     q.dbg = g_wgrad_dbg;
     // splits are dealt to the 8 XCDs in turn: round the split count up to a multiple of 8 (empty ranges return at once)
     const int nsplit8 = (nsplit + 7) / 8 * 8;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * nsplit8), dim3(WTHREADS), 2 * WSTAGE, s, q, tiles_co, tiles_x, tiles_y, nblocks, per_split);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * nsplit8), dim3(WTHREADS), 2 * WSTAGE, s, q, tiles_co, tiles_x, tiles_y, nblocks, nsplit, stagger);
     return (int)hipGetLastError();
 }
