@@ -676,14 +676,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
     const int tx_i = mt % tiles_x, ty_i = (mt / tiles_x) % tiles_y, b = mt / (tiles_x * tiles_y);
     const int oy0 = ty_i * QTH, ox0 = tx_i * QTW, n0 = nt * WBN;
-    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + (long long)b * p.H * p.W * p.Cin;
     const bf16_t* __restrict__ Bp = reinterpret_cast<const bf16_t*>(p.Bp);
-    const char* zline = reinterpret_cast<const char*>(lxo_zero_line);
     const unsigned wst_off = 2 * WPATCHB + wave * WNST * WWSTAGE;  // this wave's private weight ring
     const unsigned m0base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lxo_conv_lds);
 
-    // patch slot s = tid + 256 j holds chunk s % 5 (4 = unused) of pixel s / 5; slots >= WPUNITS do not exist (last piece only)
-    int a_src[WPDMA];
+    // patch slot s = tid + 256 j holds chunk s % 5 (4 = unused) of pixel s / 5; slots >= WPUNITS do not exist (last piece only).
+    // The requests go through a buffer resource over the whole input tensor: the per-lane part of the address (pixel, chunk) is a
+    // 32-bit offset computed once per tile, the per-slice part (image, channel slice) is the request's scalar offset, and a pixel
+    // of the zero padding is an out-of-range offset (the buffer writes zeros: tools/blds_probe.hip) -- no VALU work per request,
+    // and the request itself costs about half the issue time of the 64-bit-address form (tools/issue_probe.hip).
+    const lxo_rsrc_t rsA = lxo_make_rsrc(p.A, (unsigned)((long long)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin * 2));
+    const unsigned soffA = __builtin_amdgcn_readfirstlane((unsigned)(b * p.H * p.W * p.Cin * 2));
+    unsigned a_src[WPDMA];
 #pragma unroll
     for (int j = 0; j < WPDMA; ++j) {
         const int s = tid + WTHR * j;
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         const int py = prow / QPW, px = prow - py * QPW;
         const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
         const bool ok = ch < 4 && prow < QPROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        a_src[j] = ok ? (iy * p.W + ix) * p.Cin + (ch << 3) : -1;
+        a_src[j] = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + (ch << 3)) * 2) : LXO_BLDS_OOB;
     }
     // weight rows n0 + wn*32 + r, r = 16 j + (lane >> 2) (1 KB = 16 rows per instruction), chunk swizzle ((r >> 2) & 3):
     // per-lane BYTE offsets from the wave-uniform tile base
@@ -703,10 +707,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     }
     auto issue_patch_piece = [&](int c, int buf, int j) {          // piece j (4 KB per workgroup) of slice c into patch buffer buf
         if (p.diag & 2) c = 0;
-        const void* src = a_src[j] >= 0 ? (const void*)(A + a_src[j] + c * WKC) : (const void*)zline;
-        if (j + 1 < WPDMA) LXO_GLDS16_HIDDEN(src, lxo_conv_lds, buf * WPATCHB + wave * 1024 + 4096 * j);
+        const unsigned so = soffA + (unsigned)(c * WKC * 2);
+        if (j + 1 < WPDMA) LXO_BLDS16(a_src[j], rsA, so, lxo_conv_lds, m0base, buf * WPATCHB + wave * 1024 + 4096 * j);
         else if (wave * 64 + WTHR * j < WPUNITS) {                 // the partial piece: wave 3 has no slot in it, wave 2 a part of its lanes
-            if (tid + WTHR * j < WPUNITS) LXO_GLDS16_HIDDEN(src, lxo_conv_lds, buf * WPATCHB + wave * 1024 + 4096 * j);
+            if (tid + WTHR * j < WPUNITS) LXO_BLDS16(a_src[j], rsA, so, lxo_conv_lds, m0base, buf * WPATCHB + wave * 1024 + 4096 * j);
         }
     };
     auto issue_patch = [&](int c, int buf) {
