@@ -10,7 +10,18 @@ remaining backward; Adam is replicated.
 The step never synchronises the host: the token count is a sum of host-known integers, so each rank
 uploads its own count at the START of the step and all-reduces it on a dedicated stream while the forward
 runs; the loss kernel reads the global count from device memory (lxo_ce_loss_fwd_bwd_dev).
+
+How a bucket's all-reduce is ordered behind the kernels that produce it: NOT with hipStreamWaitEvent.  On this runtime
+(ROCm 7.2, MI355X) a stream that waits for an event recorded on the compute stream slows the compute stream's own
+dependent-launch chains by ~0.25 ms per step (tools/queue_probe.py: one such wait per step is enough, every event flag
+behaves the same, the reverse direction -- the compute stream waiting for another stream -- is free).  So the compute
+stream only RECORDS an event per bucket; a helper thread waits for it on the host and then enqueues the collective on
+the side stream ("host-ordered", the default on a GPU; LXO_DP_HOST_ORDERED=0 restores the stream-side wait).
 """
+import os
+import queue
+import threading
+
 import torch
 import torch.distributed as td
 
@@ -30,6 +41,47 @@ class DataParallel(object):
         self._cnt_i = 0
         self.grad_dtype = None                 # None = reduce gradients as f32 (34.5 MB); torch.bfloat16 halves the bytes (opt-in, see reduce_range_fn)
         self.exposed_ms = []                   # (start, end) event pairs around finish(): the all-reduce time the compute stream waited for
+        self.host_ordered = self.cuda and os.environ.get("LXO_DP_HOST_ORDERED", "1") == "1"
+        self._q = None
+        self._err = None
+        if self.host_ordered:
+            self._q = queue.Queue()
+            self._thr = threading.Thread(target=self._bucket_worker, name="lxo-dp-buckets", daemon=True)
+            self._thr.start()
+
+    def _reduce(self, seg):
+        if self.grad_dtype is not None:
+            low = seg.to(self.grad_dtype)
+            td.all_reduce(low, op=td.ReduceOp.SUM)
+            seg.copy_(low)
+        else:
+            td.all_reduce(seg, op=td.ReduceOp.SUM)
+
+    def _bucket_worker(self):
+        """Host-ordered buckets: wait (on the host) for the event behind a bucket's gradients, then enqueue its all-reduce on the
+        side stream.  Collectives are issued by this thread only between the first comm() and finish() of a step, in bucket order,
+        so every rank issues them in the same order; the main thread issues its own (token count, barriers) outside that window."""
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self._q.get()
+            try:
+                if item is None:
+                    return
+                ev, seg = item
+                if self._err is None:
+                    ev.synchronize()
+                    with torch.cuda.stream(self.side):
+                        self._reduce(seg)
+            except BaseException as e:          # surfaced by finish()
+                self._err = e
+            finally:
+                self._q.task_done()
+
+    def close(self):
+        if self._q is not None:
+            self._q.put(None)
+            self._thr.join(timeout=10)
+            self._q = None
 
     def sum_count_async(self, n_local):
         """-> (device float32 tensor [1] holding the sum of n_local over ranks, event or None).  Asynchronous w.r.t. the
@@ -81,23 +133,16 @@ class DataParallel(object):
         def comm(lo, hi):
             seg = flat[lo:hi]
             if not self.cuda:
-                if self.grad_dtype is not None:
-                    low = seg.to(self.grad_dtype)
-                    td.all_reduce(low, op=td.ReduceOp.SUM)
-                    seg.copy_(low)
-                else:
-                    td.all_reduce(seg, op=td.ReduceOp.SUM)
+                self._reduce(seg)
                 return
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
-            self.side.wait_event(ev)
-            with torch.cuda.stream(self.side):
-                if self.grad_dtype is not None:
-                    low = seg.to(self.grad_dtype)
-                    td.all_reduce(low, op=td.ReduceOp.SUM)
-                    seg.copy_(low)
-                else:
-                    td.all_reduce(seg, op=td.ReduceOp.SUM)
+            if self.host_ordered:
+                self._q.put((ev, seg))
+            else:
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    self._reduce(seg)
             self._pending = True
         return comm
 
@@ -106,6 +151,11 @@ class DataParallel(object):
         with events on the compute stream (bench.py reports the exposed all-reduce time from them)."""
         timed = getattr(self, "time_finish", False) if timed is None else timed
         if self.cuda and self._pending:
+            if self.host_ordered:
+                self._q.join()                  # every bucket of this step has been enqueued on the side stream
+                if self._err is not None:
+                    e, self._err = self._err, None
+                    raise e
             cur = torch.cuda.current_stream(self.device)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

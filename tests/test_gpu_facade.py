@@ -64,11 +64,14 @@ def test_train_eval_predict(tmp_path, monkeypatch):
     assert all(os.path.exists(f) for f in files)
 
 
-def test_single_rank_rccl_path():
-    env = dict(os.environ, LXO_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+@pytest.mark.parametrize("host_ordered", ["1", "0"])
+def test_single_rank_rccl_path(host_ordered):
+    """bench.py through torch.distributed (nccl = RCCL) at world size 1: buckets ordered by the helper thread (default) and by stream waits"""
+    env = dict(os.environ, LXO_FORCE_DIST="1", LXO_DP_HOST_ORDERED=host_ordered, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                                    "--no-cpu-baseline", "--batch", "8", "--height", "32", "--width", "128", "--vocab", "50"],
                                   env=env, cwd=ROOT, timeout=600)
     line = [l for l in out.decode().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    assert d["data_parallel"]["exposed_allreduce_ms_per_step"][0] is not None
