@@ -7,13 +7,11 @@
 // out of them with the transposing read ds_read_b64_tr_b16 (4 consecutive m of one column per lane), the way
 // conv_wgrad_kernel reads its d_out block.  128 x 128 output tile, 4 waves as 2 x 2, each 64 x 64 = 2 x 2
 // v_mfma_f32_32x32x16_bf16 tiles; two LDS stages of 32 KB; the DMA of tile k+1 is in flight under the MFMAs of tile k.
-// Rows beyond M and 8-column chunks beyond I / J are fetched from a line of zeros.
+// Rows beyond the range and 8-column chunks beyond I / J read as zeros (out-of-range offsets of the buffer resources).
 #include "gemm.h"
 #include "api_util.h"
 
 namespace {
-
-__device__ unsigned lxo_tntr_zero_line[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 constexpr int TBR = 64;                              // reduction rows per LDS tile
 constexpr int TTILE = TBR * 256;                     // bytes of one operand tile: 64 rows x 128 columns x 2
@@ -49,21 +47,33 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmTN p) {
     if (mbeg >= mend) return;
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(p.B);
-    const char* zline = reinterpret_cast<const char*>(lxo_tntr_zero_line);
 
     // DMA geometry: thread -> (row r = (tid >> 4) + 16 j, LDS slot dch = tid & 15 of the 256-byte row); slot dch of row r holds the
-    // GLOBAL chunk dch ^ (r & 15) (a reader of global chunk c looks in slot c ^ (r & 15))
+    // GLOBAL chunk dch ^ (r & 15) (a reader of global chunk c looks in slot c ^ (r & 15)).
+    // Requests go through buffer resources that END at row `mend`: the per-lane byte offset (row r, chunk) is fixed for the whole
+    // kernel, the tile's first row is the request's scalar offset, rows beyond the range are out of the buffer and chunks beyond I / J
+    // carry an out-of-range offset -- both read as zeros (tools/blds_probe.hip).  The addresses used to be rebuilt per request
+    // (64-bit multiplies, a select against a zero line: ~25 VALU instructions for each of the 8 requests of a tile that has only
+    // 16 MFMAs per wave); the matrix pipe waits while a wave issues them.
     const int dch = tid & 15, drow = tid >> 4;
+    const unsigned m0b = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lxo_tntr_lds);
+    const lxo_rsrc_t ra = lxo_make_rsrc(A, (unsigned)((long long)mend * p.lda * 2));
+    const lxo_rsrc_t rb = lxo_make_rsrc(B, (unsigned)((long long)mend * p.ldb * 2));
+    unsigned voa[4], vob[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = drow + 16 * j;
+        const int gch = (dch ^ (r & 15)) << 3;                  // first column of the chunk inside the 128-column tile
+        voa[j] = i0 + gch < p.I ? (unsigned)((r * p.lda + i0 + gch) * 2) : LXO_BLDS_OOB;
+        vob[j] = j0 + gch < p.J ? (unsigned)((r * p.ldb + j0 + gch) * 2) : LXO_BLDS_OOB;
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int m0, int stage) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane((unsigned)(m0 * p.lda * 2)), sb = __builtin_amdgcn_readfirstlane((unsigned)(m0 * p.ldb * 2));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = drow + 16 * j, m = m0 + r;
-            const int gch = (dch ^ (r & 15)) << 3;              // first column of the chunk inside the 128-column tile
-            const bool oka = m < mend && i0 + gch < p.I, okb = m < mend && j0 + gch < p.J;
-            const void* sa = oka ? (const void*)(A + (long long)m * p.lda + i0 + gch) : (const void*)zline;
-            const void* sb = okb ? (const void*)(B + (long long)m * p.ldb + j0 + gch) : (const void*)zline;
-            LXO_GLDS16_HIDDEN(sa, lxo_tntr_lds, stage * TSTAGE + (wave * 64 + 256 * j) * 16);
-            LXO_GLDS16_HIDDEN(sb, lxo_tntr_lds, stage * TSTAGE + TTILE + (wave * 64 + 256 * j) * 16);
+            LXO_BLDS16(voa[j], ra, sa, lxo_tntr_lds, m0b, stage * TSTAGE + (wave_u * 64 + 256 * j) * 16);
+            LXO_BLDS16(vob[j], rb, sb, lxo_tntr_lds, m0b, stage * TSTAGE + TTILE + (wave_u * 64 + 256 * j) * 16);
         }
     };
 
@@ -138,6 +148,7 @@ int lxo_launch_gemm_tn_tr(const GemmTN& p, hipStream_t s) {
     // a ragged last 8-column chunk is read whole: it must lie inside the row (padded pitch), its surplus columns are never stored
     if (p.conv || !p.atomic || p.nbatch != 1 || p.lda % 8 || p.ldb % 8 || (p.I + 7) / 8 * 8 > p.lda || (p.J + 7) / 8 * 8 > p.ldb) return -2;
     if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return -2;
+    if ((long long)p.M * p.lda * 2 >= (1LL << 31) || (long long)p.M * p.ldb * 2 >= (1LL << 31)) return -2;   // 32-bit buffer offsets
     {   // per device, not per process (see conv_igemm.hip attr_needed)
         static bool done[64] = {};
         int dev = 0;
