@@ -12,7 +12,6 @@
 
 namespace {
 
-__device__ unsigned lxo_ntdma_zero_line[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 constexpr int NTILE = 128 * 128;                     // bytes of one operand tile: 128 rows x 64 k x 2
 constexpr int NSTAGE = 2 * NTILE;
 
@@ -29,24 +28,27 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT p) {
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(p.Bp);
-    const char* zline = reinterpret_cast<const char*>(lxo_ntdma_zero_line);
 
-    // DMA geometry: thread -> (row (tid >> 3) + 32 j, LDS slot tid & 7); slot s of row r holds the GLOBAL chunk s ^ ((r >> 1) & 7)
-    const bf16_t* asrc[4]; const bf16_t* bsrc[4]; bool aok[4], bok[4];
+    // DMA geometry: thread -> (row (tid >> 3) + 32 j, LDS slot tid & 7); slot s of row r holds the GLOBAL chunk s ^ ((r >> 1) & 7).
+    // Buffer resources: the per-lane byte offset (row, chunk) is fixed, the K-step is the request's scalar offset, rows beyond M / N
+    // carry an out-of-range offset and read as zeros -- no address arithmetic per request (see conv_wgrad.hip).
+    const unsigned m0b = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lxo_ntdma_lds);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const lxo_rsrc_t ra = lxo_make_rsrc(A, (unsigned)((long long)p.M * p.lda * 2));
+    const lxo_rsrc_t rb = lxo_make_rsrc(B, (unsigned)((long long)p.N * p.ldb * 2));
+    unsigned voa[4], vob[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (tid >> 3) + 32 * j, gch = ((tid & 7) ^ ((r >> 1) & 7)) << 3;
-        aok[j] = m0 + r < p.M; bok[j] = n0 + r < p.N;
-        asrc[j] = A + (long long)(aok[j] ? m0 + r : 0) * p.lda + gch;
-        bsrc[j] = B + (long long)(bok[j] ? n0 + r : 0) * p.ldb + gch;
+        voa[j] = m0 + r < p.M ? (unsigned)(((m0 + r) * p.lda + gch) * 2) : LXO_BLDS_OOB;
+        vob[j] = n0 + r < p.N ? (unsigned)(((n0 + r) * p.ldb + gch) * 2) : LXO_BLDS_OOB;
     }
     auto issue = [&](int k0, int stage) {
+        const unsigned so = (unsigned)(k0 * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const void* sa = aok[j] ? (const void*)(asrc[j] + k0) : (const void*)zline;
-            const void* sb = bok[j] ? (const void*)(bsrc[j] + k0) : (const void*)zline;
-            LXO_GLDS16_HIDDEN(sa, lxo_ntdma_lds, stage * NSTAGE + wave * 1024 + 4096 * j);
-            LXO_GLDS16_HIDDEN(sb, lxo_ntdma_lds, stage * NSTAGE + NTILE + wave * 1024 + 4096 * j);
+            LXO_BLDS16(voa[j], ra, so, lxo_ntdma_lds, m0b, stage * NSTAGE + wave_u * 1024 + 4096 * j);
+            LXO_BLDS16(vob[j], rb, so, lxo_ntdma_lds, m0b, stage * NSTAGE + NTILE + wave_u * 1024 + 4096 * j);
         }
     };
 
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(GemmNT p) {
 int lxo_launch_gemm_nt_dma(const GemmNT& p, int c_f32, hipStream_t s) {
     if (p.conv || p.addend || p.relu_ref || p.out_pre || p.colsum || p.accumulate || p.act || p.alpha != 1.f) return -2;
     if (p.K % 64 || p.lda % 8 || p.ldb % 8 || (((uintptr_t)p.A | (uintptr_t)p.Bp) & 15)) return -2;
+    if ((long long)p.M * p.lda * 2 >= (1LL << 31) || (long long)p.N * p.ldb * 2 >= (1LL << 31)) return -2;   // 32-bit buffer offsets
     {   // per device, not per process (see conv_igemm.hip attr_needed)
         static bool done[64] = {};
         int dev = 0;
