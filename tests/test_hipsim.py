@@ -51,6 +51,27 @@ def test_gemm_tn(dt, a_f32, b_f32):
     assert np.abs(C - ref).max() / np.abs(ref).max() < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,valid", [(2, 5, 70, 64, 72, 0), (1, 6, 66, 128, 128, 1), (3, 3, 20, 64, 136, 0)])
+def test_conv3x3_wgrad_bf16(B, H, W, Cin, Cout, valid):
+    """conv_wgrad_kernel under the SIMT interpreter: LDS-DMA through buffer resources (zero padding and ragged tiles = out-of-range
+    offsets), transposing LDS reads, pixel ranges of unequal length, f32 atomics -- against a float64 correlation of the same
+    bf16-rounded operands (partial pixel tiles in both directions, a partial 128-channel tile, SAME and VALID)."""
+    L = lib()
+    rng = np.random.default_rng(H * W + Cin + Cout)
+    x = bf16_to_f32(f32_to_bf16(rng.standard_normal((B, H, W, Cin)).astype(np.float32)))
+    Ho, Wo = (H - 2, W - 2) if valid else (H, W)
+    pad = 0 if valid else 1
+    dy = bf16_to_f32(f32_to_bf16(rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32)))
+    dw0 = rng.standard_normal((9 * Cin, Cout)).astype(np.float32); dw = dw0.copy()
+    assert L.lxo_conv3x3_wgrad(1, ptr(f32_to_bf16(x)), ptr(f32_to_bf16(dy)), ptr(dw), B, H, W, Cin, Ho, Wo, Cout, pad, None) == 0, L.lxo_last_error()
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+    ref = dw0.astype(np.float64)
+    for kh in range(3):
+        for kw in range(3):
+            ref[(kh * 3 + kw) * Cin:(kh * 3 + kw + 1) * Cin] += np.einsum("byxi,byxo->io", xp[:, kh:kh + Ho, kw:kw + Wo, :], dy.astype(np.float64))
+    assert np.abs(dw - ref).max() / np.abs(ref).max() < 2e-6
+
+
 def _run(dtype):
     img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
     S = Sim(2, 32, 48, f.shape[1], 11, dtype=dtype, seed=0)
