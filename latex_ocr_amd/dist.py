@@ -41,7 +41,8 @@ class DataParallel(object):
         self._cnt_i = 0
         self.grad_dtype = None                 # None = reduce gradients as f32 (34.5 MB); torch.bfloat16 halves the bytes (opt-in, see reduce_range_fn)
         self.exposed_ms = []                   # (start, end) event pairs around finish(): the all-reduce time the compute stream waited for
-        self.host_ordered = self.cuda and os.environ.get("LXO_DP_HOST_ORDERED", "1") == "1"
+        ho = os.environ.get("LXO_DP_HOST_ORDERED", "1")
+        self.host_ordered = (self.cuda and ho == "1") or ho == "force"       # "force": also on CPU tensors (gloo tests of the helper thread)
         self._q = None
         self._err = None
         if self.host_ordered:
@@ -61,7 +62,8 @@ class DataParallel(object):
         """Host-ordered buckets: wait (on the host) for the event behind a bucket's gradients, then enqueue its all-reduce on the
         side stream.  Collectives are issued by this thread only between the first comm() and finish() of a step, in bucket order,
         so every rank issues them in the same order; the main thread issues its own (token count, barriers) outside that window."""
-        torch.cuda.set_device(self.device)
+        if self.cuda:
+            torch.cuda.set_device(self.device)
         while True:
             item = self._q.get()
             try:
@@ -69,9 +71,12 @@ class DataParallel(object):
                     return
                 ev, seg = item
                 if self._err is None:
-                    ev.synchronize()
-                    with torch.cuda.stream(self.side):
+                    if ev is None:                  # CPU tensors: nothing to wait for
                         self._reduce(seg)
+                    else:
+                        ev.synchronize()
+                        with torch.cuda.stream(self.side):
+                            self._reduce(seg)
             except BaseException as e:          # surfaced by finish()
                 self._err = e
             finally:
@@ -133,7 +138,10 @@ class DataParallel(object):
         def comm(lo, hi):
             seg = flat[lo:hi]
             if not self.cuda:
-                self._reduce(seg)
+                if self.host_ordered:
+                    self._q.put((None, seg)); self._pending = True
+                else:
+                    self._reduce(seg)
                 return
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
@@ -150,12 +158,14 @@ class DataParallel(object):
         """Make the compute stream wait for every bucket before the optimizer reads the gradients.  timed: bracket the wait
         with events on the compute stream (bench.py reports the exposed all-reduce time from them)."""
         timed = getattr(self, "time_finish", False) if timed is None else timed
+        if self._pending and self.host_ordered:
+            self._q.join()                      # every bucket of this step has been enqueued on the side stream (CPU: reduced)
+            if self._err is not None:
+                e, self._err = self._err, None
+                raise e
+            if not self.cuda:
+                self._pending = False
         if self.cuda and self._pending:
-            if self.host_ordered:
-                self._q.join()                  # every bucket of this step has been enqueued on the side stream
-                if self._err is not None:
-                    e, self._err = self._err, None
-                    raise e
             cur = torch.cuda.current_stream(self.device)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

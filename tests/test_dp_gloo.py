@@ -104,7 +104,7 @@ def _mixed_dataset():
     return ListDataset(imgs, forms)
 
 
-def _worker4(rank, port, q, bf16_grads):
+def _worker4(rank, port, q, bf16_grads, host_ordered=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -116,7 +116,10 @@ def _worker4(rank, port, q, bf16_grads):
     from latex_ocr_amd.model.utils.image import pad_batch_images
     from latex_ocr_amd.model.utils.text import pad_batch_formulas
     from simlib import SIM_SO
+    if host_ordered:
+        os.environ["LXO_DP_HOST_ORDERED"] = "force"      # the helper thread that orders the buckets on a GPU, here over CPU tensors
     dp = DataParallel(device="cpu")
+    assert dp.host_ordered == bool(host_ordered)
     if bf16_grads:
         dp.grad_dtype = torch.bfloat16
     eng = Engine(11, dims=SMALL, dtype="f32", device="cpu", seed=0, lib=_abi.bind(ctypes.CDLL(SIM_SO)))
@@ -132,14 +135,14 @@ def _worker4(rank, port, q, bf16_grads):
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("bf16_grads", [False, True])
-def test_four_ranks_unequal_batches_same_steps_no_hang(bf16_grads):
+@pytest.mark.parametrize("bf16_grads,host_ordered", [(False, False), (True, False), (False, True)])
+def test_four_ranks_unequal_batches_same_steps_no_hang(bf16_grads, host_ordered):
     from simlib import build_sim
     build_sim()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000 + (7 if bf16_grads else 0)
-    procs = [ctx.Process(target=_worker4, args=(r, port, q, bf16_grads)) for r in range(4)]
+    port = 31500 + os.getpid() % 2000 + (7 if bf16_grads else 0) + (13 if host_ordered else 0)
+    procs = [ctx.Process(target=_worker4, args=(r, port, q, bf16_grads, host_ordered)) for r in range(4)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in range(4))
