@@ -7,8 +7,9 @@
 // d_out pixels for its 128 channels -- each once, serving all nine taps (262 FLOP per staged
 // byte).  The contraction runs over PIXELS, which are the strided index of NHWC, so MFMA
 // operands are fetched with the transposing LDS read ds_read_b64_tr_b16 (4 consecutive pixels
-// of one channel per lane); the kw = 0/1/2 shifted operands of a patch row come from the same
-// three reads through v_alignbit.  Partial tiles are reduced with f32 atomics.
+// of one channel per lane); the kw = 0 and kw = 2 windows of a patch row are read from LDS, the
+// kw = 1 window is four v_perm of the two.  Partial tiles are reduced with f32 atomics; the pixel
+// ranges of the workgroups have unequal lengths so that those epilogues do not collide.
 #include "gemm.h"
 #include "api_util.h"
 #include <stdlib.h>
@@ -166,11 +167,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
         const char* db = sb + doff_b;
         // The K loop walks 16 sub-steps (16-pixel column group xg, patch row `row` of the four): patch row `row` is the kh = row
         // operand of output row 0 and the kh = row - 1 operand of output row 1, so it is read ONCE and feeds 3 + 3 MFMAs (rows
-        // 0 and 3: 3).  Every non-matrix instruction costs ~5 cycles of the SIMD's matrix pipe here (stamps: 926 cycles per 18
-        // MFMAs with 70 other instructions in round 2's loop), so the kw-shifted operands are built with as few of them as the
-        // LDS allows: the kw = 0 and the kw = 2 windows (pixels 0..7 and 2..9 of the lane's run) are BOTH read from LDS (2
+        // 0 and 3: 3).  The kw = 0 and the kw = 2 windows (pixels 0..7 and 2..9 of the lane's run) are BOTH read from LDS (2
         // transposing reads each: the second window used to be four v_mov out of an odd register pair), the kw = 1 window is
-        // four v_perm of the two (all three from LDS is LDS-bound).  Per 18 MFMAs: 20 LDS reads + 16 v_perm (round 2: 22 + 48).
+        // four v_perm of the two (all three from LDS is LDS-bound).  Per 18 MFMAs: 20 LDS reads + 16 v_perm (round 2: 22 + 48);
+        // measured with LXO_WG_DIAG builds, these cost ~4 % of the loop -- what cost 30 % was the DMA issue (see `issue`).
         // Raw patch operands are read one sub-step ahead, the d_out operands of both output rows one column group ahead.
         u32x2 ra[2][4], rb[2][4];
         auto read_b = [&](int xg, u32x2 (&b4)[4]) {
