@@ -1104,7 +1104,9 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
     if (use_halo < 0) { const char* e = getenv("LXO_CONV_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
     static int use_2wg = -1;
     if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }
-    if (use_halo && use_2wg && (p.N % 64) == 0 && p.act != 2 && p.alpha == 1.f) {
+    // the halo kernel addresses its input through 32-bit buffer offsets (2^31 = its out-of-range marker): tensors below 2 GB only
+    const bool in_32bit = (long long)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin * 2 < (1LL << 31);
+    if (use_halo && use_2wg && in_32bit && (p.N % 64) == 0 && p.act != 2 && p.alpha == 1.f) {
         constexpr int LDS4 = WLDS, LDS2 = WLDS;                                                    // 77824: the patch + four waves' two private weight stages
         if (attr_needed(0)) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
