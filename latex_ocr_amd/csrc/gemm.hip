@@ -692,7 +692,7 @@ int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p,
         (((uintptr_t)p.A | (uintptr_t)p.Bp) & 15) == 0) {
         static int use_dma = -1;                           // LXO_GEMM_NT_DMA=0: the register-staged kernel for every dense NT GEMM (A/B)
         if (use_dma < 0) { const char* e = getenv("LXO_GEMM_NT_DMA"); use_dma = (e && e[0] == '0') ? 0 : 1; }
-        if (use_dma) return lxo_launch_gemm_nt_dma(p, c_f32, s);
+        if (use_dma) { const int rc = lxo_launch_gemm_nt_dma(p, c_f32, s); if (rc != -2) return rc; }   // -2: does not qualify (e.g. 2 GB operands): the register-staged kernel
     }
     if (!a_f32 && !c_f32) return k64 ? launch_nt<bf16_t, false, bf16_t, bf16_t, 128, 128, 64>(p, s) : launch_nt<bf16_t, false, bf16_t, bf16_t, 128, 128>(p, s);
     if (!a_f32 && c_f32) return k64 ? launch_nt<bf16_t, false, bf16_t, float, 128, 128, 64>(p, s) : launch_nt<bf16_t, false, bf16_t, float, 128, 128>(p, s);
@@ -711,14 +711,14 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
         if (a_f32 || b_f32) return -3;
         static int use_halo = -1;
         if (use_halo < 0) { const char* e = getenv("LXO_WGRAD_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
-        if (use_halo && p.Cin % 64 == 0 && p.J % 8 == 0 && p.atomic && p.nbatch == 1) return lxo_launch_conv_wgrad(p, s);
+        if (use_halo && p.Cin % 64 == 0 && p.J % 8 == 0 && p.atomic && p.nbatch == 1) { const int rc = lxo_launch_conv_wgrad(p, s); if (rc != -2) return rc; }
         return launch_tn<bf16_t, true, bf16_t, bf16_t>(p, s);
     }
     if (!a_f32 && !b_f32) {
         static int use_tr = -1;                            // LXO_GEMM_TN_TR=0: the packing kernel for every dense TN GEMM (A/B)
         if (use_tr < 0) { const char* e = getenv("LXO_GEMM_TN_TR"); use_tr = (e && e[0] == '0') ? 0 : 1; }
         if (use_tr && p.atomic && p.nbatch == 1 && p.lda % 8 == 0 && p.ldb % 8 == 0 && (p.I + 7) / 8 * 8 <= p.lda && (p.J + 7) / 8 * 8 <= p.ldb &&
-            (((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0) return lxo_launch_gemm_tn_tr(p, s);
+            (((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0) { const int rc = lxo_launch_gemm_tn_tr(p, s); if (rc != -2) return rc; }
         return launch_tn<bf16_t, false, bf16_t, bf16_t>(p, s);
     }
     if (a_f32 && !b_f32) return launch_tn<bf16_t, false, float, bf16_t>(p, s);
