@@ -499,7 +499,7 @@ def main():
                 dts = (time.perf_counter() - t1) / min(args.steps, 10)
                 eng.skip_padded = False
                 out["extension_skip_padded_steps"] = {"value": round(B / dts, 2), "unit": "img/s", "ms_per_step": round(dts * 1e3, 3),
-                                                      "note": "not the headline metric: padded (sample, step) pairs skipped, batch sorted by length; runs on round 1's split-K step kernels (lxo_*_active), so it no longer beats the fused default"}
+                                                      "note": "not the headline metric (the reference and `value` run every padded step): padded (sample, step) pairs skipped, batch sorted by length, same loss and gradients (tests/test_gpu_parity.py); the fused step kernels and the attention streams then cover active[t] rows per step"}
                 if not args.no_secondary:
                     try:
                         out["secondary"] = secondary(args, eng, torch, dev, B, H, W, V)

@@ -195,18 +195,21 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
     const int nh = dual ? 2 : 1;
-    const bool fused = fused_steps(P) && !dual && !active;
+    const bool fused = fused_steps(P) && !dual;
     if (fused) {
         bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         RC(mirror_oh(P, ws, 0, B, st));
-        for (int t = 0; t < T; ++t)
-            RC(cell_step_fused(P, prm, wp, ws, B, 1, zx + (size_t)t * B * 4 * U,
+        for (int t = 0; t < T; ++t) {
+            const int nr = active ? active[t] : B;          // rows [0, nr) are the samples whose formula is longer than t (non-increasing)
+            if (nr <= 0) break;
+            RC(cell_step_fused(P, prm, wp, ws, nr, 1, zx + (size_t)t * B * 4 * U,
                                rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
                                rec + (size_t)(t + 1) * B * P.REC, cs + (size_t)(t + 1) * B * U,
                                recb + (size_t)t * B * P.RECB, recb + (size_t)(t + 1) * B * P.RECB,
                                P.ws<float>(ws, W_GATES) + (size_t)t * B * 4 * U,
                                P.ws<float>(ws, W_ATTH) + (size_t)t * B * E,
                                P.ws<float>(ws, W_ALPHA) + (size_t)t * B * P.Rp, P.drop(t, 0), st));
+        }
     }
     if (dual) RC(fork_side(st));
     for (int t = 0; t < T && !fused; ++t)
@@ -252,7 +255,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
 
     // the same conditions as in lxo_impl_decoder_train_fwd: the fused step kernels ran (and left the bf16 mirrors of the record)
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
-    const bool fused = fused_steps(P) && !dual && !active;
+    const bool fused = fused_steps(P) && !dual;
     // d_o (from logits) for every step, and dy_W_o
     if (parts & 1) {
         RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
@@ -268,6 +271,10 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         HIPRC(hipMemsetAsync(dhc, 0, (size_t)TB * P.HC * 4, st));
         HIPRC(hipMemsetAsync(de, 0, (size_t)TB * P.Rp * 4, st));
         HIPRC(hipMemsetAsync(dz, 0, (size_t)TB * 4 * U * 4, st));
+        if (fused && P.bf) {     // the bf16 mirrors are the operands of those GEMMs and of the carry GEMM (rows a step did not run contribute nothing)
+            HIPRC(hipMemsetAsync(P.ws<bf16_t>(ws, W_GB), 0, (size_t)TB * P.GBP * 2, st));
+            HIPRC(hipMemsetAsync(P.ws<bf16_t>(ws, W_DZB), 0, (size_t)TB * P.DZBP * 2, st));
+        }
     }
     const int nh = dual ? 2 : 1;
     float* dxh = P.ws<float>(ws, W_DXH);
@@ -279,13 +286,21 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         float* carry_h = P.ws<float>(ws, W_CARRYH);
         const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG);
         const char* img = (const char*)P.ws<void>(ws, W_IMG);
-        const int nchb = P.attn_chunks(B);
-        // g_{T-1} = d_o(logits) * tanh'   (no carry yet)
-        RC(lxo_k_tanh_bwd(dolog + (size_t)(T - 1) * B * O, O, kNoSlabs, rec + (size_t)T * B * P.REC, P.REC,
-                          gall + (size_t)(T - 1) * B * O, O, bf ? gb + (size_t)(T - 1) * B * P.GBP : nullptr, P.GBP, P.drop(T - 1, 0), 0, B, O, st));
+        // With `active` (rows sorted by length, rows [0, active[t]) run step t): the last step that runs is t_last; step t's kernels
+        // cover active[t] rows; the carry kernel of step t covers the active[t - 1] rows of step t - 1 -- for the rows that end at
+        // t - 1 its GEMM operand (d_z_t, zeroed above, never written) is zero, so their g_{t-1} is the no-carry formula.
+        int t_last = T - 1;
+        while (active && t_last > 0 && active[t_last] <= 0) --t_last;
+        const int n_last = active ? active[t_last] : B;
+        // g_{t_last} = d_o(logits) * tanh'   (no carry yet)
+        RC(lxo_k_tanh_bwd(dolog + (size_t)t_last * B * O, O, kNoSlabs, rec + (size_t)(t_last + 1) * B * P.REC, P.REC,
+                          gall + (size_t)t_last * B * O, O, bf ? gb + (size_t)t_last * B * P.GBP : nullptr, P.GBP, P.drop(t_last, 0), 0, n_last, O, st));
         RStep a; memset(&a, 0, sizeof(a));
-        a.M = B; a.U = U; a.O = O; a.zx_row = -1;
-        for (int t = T - 1; t >= 0; --t) {
+        a.U = U; a.O = O; a.zx_row = -1;
+        for (int t = t_last; t >= 0; --t) {
+            const int nr = active ? active[t] : B;
+            const int nchb = P.attn_chunks(nr);
+            a.M = nr;
             const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
             float* g_t = gall + (size_t)t * B * O;
             float* dhc_t = dhc + (size_t)t * B * P.HC;
@@ -299,16 +314,16 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             RC(lxo_launch_rstep(P.s.dtype, bf, b1, st));
             const Slabs dc1 = {dhc_t, 1, 0, P.HC};
             {
-            LxoTimed tm("attn_bwd", "part", (double)B * P.R * (E + C) * P.esz, st);
+            LxoTimed tm("attn_bwd", "part", (double)nr * P.R * (E + C) * P.esz, st);
             RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + (size_t)t * B * E, prm + P.poff[P_BETA],
                               alpha + (size_t)t * B * P.Rp, dc1, U, nullptr, P.HC, rec_cur + P.OFF_CTX, P.REC,
-                              de + (size_t)t * B * P.Rp, datth_t, B, P.R, P.Rp, E, C, nchb, att_alternate() ? (t & 1) : 0, st));
+                              de + (size_t)t * B * P.Rp, datth_t, nr, P.R, P.Rp, E, C, nchb, att_alternate() ? (t & 1) : 0, st));
             }
             // d_h = (d_h~(o projection) + d_att_h W_att_h^T) * mask + carry -> d_z, d_c
             RStep b3 = a;
             b3.A = datth_t; b3.lda = E;                                  // f32 (atomically accumulated), converted on load
             b3.W = P.pk(wp, K_ATT_H); b3.ldw = P.ldAH; b3.N = U; b3.K = E; b3.epi = RS_LSTM_BWD;
-            b3.dhm = dhc_t; b3.lddhm = P.HC; b3.carry_h = carry_h; b3.carry_rows = (t == T - 1) ? 0 : B;
+            b3.dhm = dhc_t; b3.lddhm = P.HC; b3.carry_h = carry_h; b3.carry_rows = (t == t_last) ? 0 : (active ? active[t + 1] : B);
             b3.gates_in = gates + (size_t)t * B * 4 * U; b3.c_prev = cs + (size_t)t * B * U; b3.c_cur = cs + (size_t)(t + 1) * B * U;
             b3.dcc = dcc; b3.out = dz_t; b3.outb = bf ? dzb + (size_t)t * B * P.DZBP : nullptr; b3.ldob = P.DZBP; b3.dr = P.drop(t, 0);
             RC(lxo_launch_rstep(P.s.dtype, 0, b3, st));
@@ -318,6 +333,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             b4.W = (const char*)P.pk(wp, K_LSTM) + (size_t)D * P.ldK * P.esz; b4.ldw = P.ldK; b4.N = P.XH; b4.K = 4 * U; b4.epi = RS_CARRY;
             if (t == 0) { b4.first = 1; b4.out = dxh; b4.ldo = P.XH; }
             else {
+                b4.M = active ? active[t - 1] : B;                       // the rows of step t - 1 (>= nr)
                 b4.out = gall + (size_t)(t - 1) * B * O; b4.outb = bf ? gb + (size_t)(t - 1) * B * P.GBP : nullptr; b4.ldob = P.GBP; b4.out2 = carry_h;
                 b4.dolog = dolog + (size_t)(t - 1) * B * O; b4.o_prev = rec + (size_t)t * B * P.REC; b4.ldoprev = P.REC;
                 b4.dr = P.drop(t - 1, 0);
