@@ -1241,12 +1241,14 @@ int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, Drop dr, int rows, int cols
     LAUNCH(tanh_finalize_kernel, grid1((long long)rows * cols / 4), sl, o, ldo, dr, rows, cols);
     DONE;
 }
-static int att_u() {
-    static int u = -1;
-    // rows of both streams a wave keeps in flight per iteration.  8 since the row loads are unconditional (one request burst per
-    // iteration); 4 was faster only while hipcc serialised the conditional loads.  LXO_ATT_U=4 selects the old instantiation.
-    if (u < 0) { const char* e = getenv("LXO_ATT_U"); u = (e && atoi(e) == 4) ? 4 : 8; }
-    return u;
+static int att_u(int rows_per) {
+    static int forced = -1;
+    // rows of both streams a wave keeps in flight per iteration (8 waves per workgroup): 8, or 7 when 56 rows per iteration need no more
+    // iterations than 64 would -- the benchmark's chunk of 109 rows is 2 x 56 instead of 64 + 45 (forward pair 23.3 -> 22.3 us per step).
+    // LXO_ATT_U=7 / 8 forces one instantiation.
+    if (forced < 0) { const char* e = getenv("LXO_ATT_U"); forced = e ? atoi(e) : 0; }
+    if (forced == 7 || forced == 8) return forced;
+    return (rows_per + 55) / 56 <= (rows_per + 63) / 64 ? 7 : 8;
 }
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
                    float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, int rev, hipStream_t st) {
@@ -1269,11 +1271,11 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     }
 #define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per, rev
     if (dt == LXO_BF16) {
-        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
-        else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
+        if (E <= 256) { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 7>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
+        else { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 4, 7>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
     } else {
-        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
-        else { if (att_u() == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
+        if (E <= 256) { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 1, 7>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
+        else { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<float, 4, 7>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AF_ARGS); }
     }
 #undef AF_ARGS
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, nch, rows_per);
@@ -1288,11 +1290,11 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
     dim3 grid(nch, nv);
 #define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per, rev
     if (dt == LXO_BF16) {
-        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
-        else { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
+        if (E <= 256) { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 7>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
+        else { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 7>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
     } else {
-        if (E <= 256) { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); }
-        else { if (att_u() == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4, 4>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); }
+        if (E <= 256) { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 1, 7>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); }
+        else { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4, 8>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<float, 4, 7>), grid, dim3(512), 0, st, (const float*)att_img, (const float*)img, AB_ARGS); }
     }
 #undef AB_ARGS
     DONE;
