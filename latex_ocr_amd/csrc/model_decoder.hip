@@ -174,7 +174,22 @@ static int cell_step_fused(const Plan& P, const float* prm, const void* wp, void
     RC(lxo_launch_rstep(P.s.dtype, bf, k4, st));
     return 0;
 }
-static bool fused_steps(const Plan& P) { return P.s.step_kernels == 0; }
+// The fused step kernels split a contraction over the 4 waves in chunks of 32 / 64 k whose count must be a power of two up to 16
+// (rstep.hip: launch_nch): true for every contraction of the shipped sizes (and of any U, O, E, C in {128, 256, 512} that are
+// equal); a mixed shape such as U = 128, C = 256 (K = 384) runs on round 1's split-K step kernels instead.
+static bool rstep_k_ok(int K, bool bf) {
+    if (K % 128) return false;
+    const int kq = K / 4;
+    auto pow2_16 = [](int n) { return n >= 1 && n <= 16 && (n & (n - 1)) == 0; };
+    if (bf && kq % 64 == 0 && pow2_16(kq / 64)) return true;
+    return kq % 32 == 0 && pow2_16(kq / 32);
+}
+static bool fused_steps(const Plan& P) {
+    if (P.s.step_kernels != 0) return false;
+    const int ks[6] = {P.XH, P.s.U, P.HC, P.s.O, P.s.E, 4 * P.s.U};
+    for (int k : ks) if (!rstep_k_ok(k, P.bf) || !rstep_k_ok(k, false)) return false;     // the f32-operand launches (A converted on load) use 32-k chunks
+    return true;
+}
 // bf16 mirror of the [o | h] columns of `rows` records (initial state; beam re-ordering)
 static int mirror_oh(const Plan& P, void* ws, size_t slot_rows, int rows, hipStream_t st) {
     if (!P.bf) return 0;

@@ -113,7 +113,7 @@ def test_row_bilstm_encoder_vs_its_specification():
     import torch
     from oracle import ref_model as R
     img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
-    dims = dict(row_bilstm=True)
+    dims = dict(C=256, E=128, U=128, O=128, D=16, row_bilstm=True)     # the smallest widths the row encoder admits (C in {256, 512})
     S = Sim(2, 32, 48, f.shape[1], 11, dtype=0, seed=2, dims=dims)
     P = {k: torch.from_numpy(v.copy()) for k, v in S.P.items()}
     S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
