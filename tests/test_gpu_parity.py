@@ -63,6 +63,13 @@ def test_fwd_bwd_encoder_cnn_bf16():
     _grads_check("bf16", 1e-3, 0.97, dims=dict(cnn=True))
 
 
+@pytest.mark.parametrize("dtype,tol,cos", [("f32", 2e-5, 0.9999), ("bf16", 1e-3, 0.97)])
+def test_fwd_bwd_mixed_widths(dtype, tol, cos):
+    # model.json with unequal widths (attn_cell_config / att dims are free in the reference): U + C = 384 is a contraction the fused
+    # step kernels cannot chunk, so the decoder runs on the split-K step kernels -- same results either way
+    _grads_check(dtype, tol, cos, dims=dict(C=256, E=256, U=128, O=128, D=16))
+
+
 def test_fwd_bwd_dropout_f32():
     # config.dropout < 1: tf.nn.dropout on h and o (attention_cell.py:72,83), masks shared with the oracle
     _grads_check("f32", 2e-5, 0.99999, dropout=(0.8, 77))
