@@ -86,3 +86,26 @@ def test_greedy_decode_is_deterministic_and_bounded(full):
     b = eng.greedy_decode(img, V - 1, max_iter=40)
     assert a.shape == b.shape and np.array_equal(a, b)
     assert a.shape[0] == B and 1 <= a.shape[1] <= 41 and a.min() >= 0 and a.max() < V
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-5), ("bf16", 2e-3)])
+def test_largest_bucket_800x800_vs_oracle(dtype, tol):
+    """The largest image the reference's buckets produce (data.json [1600, 1600], halved by the build: 800 x 800 -> 98 x 98 = 9604
+    regions): the attention stream in 16 chunks per sample, conv tiles far from the benchmark's 128 x 512.
+    Loss against the oracle (forward only on the CPU side), attention rows as distributions, gradients finite."""
+    Vs = 60
+    img, f, l = batch(2, 800, 800, Vs, 4, 7, seed=99)
+    eng = Engine(Vs, dtype=dtype, seed=5)
+    eng.forward(img, f)
+    n = int(l.sum())
+    stats = eng.loss(l, 1.0 / n).cpu().numpy()
+    eng.backward()
+    torch.cuda.synchronize()
+    T = f.shape[1]
+    alpha = eng.region("alpha").float().cpu().numpy().reshape(T, 2, -1)[:, :, :9604]
+    assert np.abs(alpha.sum(-1) - 1).max() < 1e-4
+    assert bool(torch.isfinite(eng.grads).all())
+    P = oracle_params(eng)
+    with torch.no_grad():
+        loss_ref = float(R.forward_loss(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l))[0])
+    assert abs(stats[0] / stats[1] - loss_ref) / loss_ref < tol, (stats[0] / stats[1], loss_ref)
