@@ -70,6 +70,40 @@ def test_fwd_bwd_mixed_widths(dtype, tol, cos):
     _grads_check(dtype, tol, cos, dims=dict(C=256, E=256, U=128, O=128, D=16))
 
 
+def test_smallest_inputs_f32():
+    """The edges of the input domain: ONE sample, the smallest image the encoder admits (24 x 24 -> a single attention region, so the
+    softmax over regions is over one element), an EMPTY formula (only the END token: T = 1) -- and a batch that mixes an empty
+    formula with a longer one.  Loss, every gradient and the greedy ids against the oracle."""
+    from latex_ocr_amd.model.utils.image import pad_batch_images
+    from latex_ocr_amd.model.utils.text import pad_batch_formulas
+    V = 30
+    rng = np.random.default_rng(3)
+    for imgs, forms in (([rng.integers(0, 256, (24, 24, 1)).astype(np.uint8)], [[]]),
+                        ([rng.integers(0, 256, (24, 40, 1)).astype(np.uint8), rng.integers(0, 256, (30, 33, 1)).astype(np.uint8)], [[], [5, 6, 7, 8]])):
+        img = pad_batch_images(imgs)
+        f, l = pad_batch_formulas(forms, V - 2, V - 1)
+        assert f.shape[1] == max(len(x) for x in forms) + 1 and int(l.min()) == 1
+        eng = Engine(V, dtype="f32", seed=9)
+        P = oracle_params(eng)
+        eng.forward(img, f)
+        n = int(l.sum())
+        stats = eng.loss(l, 1.0 / n).cpu().numpy()
+        eng.backward()
+        torch.cuda.synchronize()
+        loss_ref, G, _, _ = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l))
+        assert abs(stats[0] / stats[1] - float(loss_ref)) / float(loss_ref) < 2e-5
+        got = eng.grad_dict()
+        gmax = max(float(G[k].abs().max()) for k in G)
+        for k in G:
+            r = G[k].numpy()
+            # with ONE region the attention weights do not depend on the scores: those gradients are exactly 0 in the oracle and
+            # rounding noise (1e-8 of the largest gradient) here, hence the floor relative to the whole gradient
+            assert np.abs(got[k] - r).max() <= 5e-5 * np.abs(r).max() + 1e-6 * gmax, (k, np.abs(got[k] - r).max(), np.abs(r).max(), gmax)
+        ids = np.asarray(eng.greedy_decode(img, V - 1, max_iter=6))
+        rid = R.greedy_decode(P, torch.from_numpy(img), V - 1, max_iter=6).numpy()
+        assert np.array_equal(ids[:, :rid.shape[1]], rid)
+
+
 def test_fwd_bwd_dropout_f32():
     # config.dropout < 1: tf.nn.dropout on h and o (attention_cell.py:72,83), masks shared with the oracle
     _grads_check("f32", 2e-5, 0.99999, dropout=(0.8, 77))
