@@ -296,7 +296,13 @@ int launch_ch(const RStep& p, hipStream_t st) {
     const int ncol = EPI == RS_LSTM_FWD ? p.U / 4 : cdiv(p.N, 16);
     // 32-row tiles when 64-row tiles would leave CUs idle (the A tile, re-read by every workgroup, is the bulk of the fetch)
     const bool half = (long long)ncol * cdiv(p.M, 64) <= 128 && p.M > 32;
+    // ... and 16-row tiles when even 32-row tiles leave half the CUs idle (o projection, att_h, the LSTM backward: 64 workgroups):
+    // a workgroup's fetch -- the length of these kernels -- shrinks with its A tile
+    static int q16 = -1;
+    if (q16 < 0) { const char* e = getenv("LXO_RSTEP_MT16"); q16 = (e && e[0] == '0') ? 0 : 1; }
+    const bool quarter = q16 && (long long)ncol * cdiv(p.M, 32) <= 128 && p.M > 16;
     if (kq % K0 == 0) {
+        if (quarter) return launch_nch<AT, WT, EPI, 16, K0>(p, dim3(ncol, cdiv(p.M, 16)), st);
         if (half) return launch_nch<AT, WT, EPI, 32, K0>(p, dim3(ncol, cdiv(p.M, 32)), st);
         return launch_nch<AT, WT, EPI, 64, K0>(p, dim3(ncol, cdiv(p.M, 64)), st);
     }

@@ -69,6 +69,6 @@ def test_two_ranks_on_one_gpu_equal_one_process(host_ordered):
     w1 = eng.get_params()["Decoder/AttentionCell/rnn/y_W_o"]
     for rank, losses, g, w in res:
         assert np.allclose(losses, ref, rtol=2e-5, atol=0), (losses, ref)          # the global token mean, on every rank
-        assert np.abs(g - g1).max() <= 2e-5 * np.abs(g1).max(), np.abs(g - g1).max()   # summed gradients of the last step
-        assert np.abs(w - w1).max() <= 2e-6                                        # replicated Adam
+        assert np.abs(g - g1).max() <= 1e-4 * np.abs(g1).max(), np.abs(g - g1).max()   # summed gradients of the third step (f32 sums in another order, two Adam steps earlier)
+        assert np.abs(w - w1).max() <= 1e-5                                        # replicated Adam
     assert np.array_equal(res[0][3], res[1][3])

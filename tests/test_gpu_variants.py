@@ -63,3 +63,12 @@ def test_kernel_generations_agree(tmp_path, h, w):
         other = _run(tmp_path, name, env, h, w, 4)
         worst = _compare(base, other, *bars)
         print("%dx%d default vs %s: worst cosine %.8f (%s, max rel %.2e)" % (h, w, name, worst[0], worst[1], worst[2]))
+
+
+def test_step_kernel_row_tiles_agree(tmp_path):
+    """The fused step kernels with 16-row tiles (default where 32-row tiles would leave CUs idle) vs 32 / 64-row tiles
+    (LXO_RSTEP_MT16=0) at a batch that takes the 16-row path (40 rows): every output element is the same contraction in the same order."""
+    base = _run(tmp_path, "default", {}, 32, 128, 40)
+    other = _run(tmp_path, "mt32", {"LXO_RSTEP_MT16": "0"}, 32, 128, 40)
+    worst = _compare(base, other, 1e-6, 0.999999, 1e-3)
+    print("16-row vs 32-row step tiles: worst cosine %.8f (%s, max rel %.2e)" % worst)
