@@ -51,6 +51,19 @@ static bool att_alternate() {
 }
 // att_img projection + initial states (attention_mechanism.py:19-43, 124-153; attention_cell.py:51-56)
 // nv = number of decoder rows (B for training/greedy, B*beam for beam search; rows v use image v / beam).
+static bool fused_steps(const Plan& P);
+// out[M][N] (+)= act(A[M][K] W[N][K]^T + bias) for the few-row GEMMs outside the loops (initial states, their gradients) on the
+// fused step kernels (16-row tiles, one workgroup per 16 columns: 128 workgroups where gemm_skinny_kernel has 16)
+static int rs_dense(const Plan& P, const float* A, int lda, const void* W, int ldw, float* out, int ldo, int M, int N, int K,
+                    const float* bias, bool tanh_act, bool accumulate, hipStream_t st) {
+    RStep a; memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K; a.U = P.s.U; a.O = P.s.O; a.zx_row = -1;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.out = out; a.ldo = ldo; a.bias = bias; a.accumulate = accumulate ? 1 : 0;
+    a.epi = tanh_act ? RS_TANH_O : RS_PLAIN;              // dropout descriptor zero: tanh only
+    a.dr.inv_keep = 1.f;
+    return lxo_launch_rstep(P.s.dtype, 0, a, st);
+}
+
 static int attention_prepare(const Plan& P, const float* prm, const void* wp, void* ws, int beam, hipStream_t st) {
     const int B = P.s.B, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
     RC(nt(P, false, false, false, P.ws<void>(ws, W_IMG), C, P.pk(wp, K_ATT_IMG_T), C, P.ws<void>(ws, W_ATT_IMG), E,
@@ -60,7 +73,11 @@ static int attention_prepare(const Plan& P, const float* prm, const void* wp, vo
     float* cs0 = P.ws<float>(ws, W_CS);
     const char* wt = (const char*)P.pk(wp, K_INIT_T);
     float* mean = P.ws<float>(ws, W_MEAN);
-    if (beam <= 1) {
+    if (beam <= 1 && fused_steps(P)) {
+        RC(rs_dense(P, mean, C, wt, C, cs0, U, B, U, C, prm + P.poff[P_BC0], true, false, st));
+        RC(rs_dense(P, mean, C, wt + (size_t)U * C * P.esz, C, rec0 + O, P.REC, B, U, C, prm + P.poff[P_BH0], true, false, st));
+        RC(rs_dense(P, mean, C, wt + (size_t)2 * U * C * P.esz, C, rec0, P.REC, B, O, C, prm + P.poff[P_BO0], true, false, st));
+    } else if (beam <= 1) {
         RC(nt(P, true, true, true, mean, C, wt, C, cs0, U, B, U, C, prm + P.poff[P_BC0], 2, false, st));
         RC(nt(P, true, true, true, mean, C, wt + (size_t)U * C * P.esz, C, rec0 + O, P.REC, B, U, C, prm + P.poff[P_BH0], 2, false, st));
         RC(nt(P, true, true, true, mean, C, wt + (size_t)2 * U * C * P.esz, C, rec0, P.REC, B, O, C, prm + P.poff[P_BO0], 2, false, st));
@@ -433,9 +450,15 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, st));
     RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, st));
     const char* wi = (const char*)P.pk(wp, K_INIT);
+    if (fused_steps(P)) {
+        RC(rs_dense(P, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, false, false, st));
+        RC(rs_dense(P, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, false, true, st));
+        RC(rs_dense(P, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, false, true, st));
+    } else {
     RC(nt(P, true, true, true, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, 0, false, st));
     RC(nt(P, true, true, true, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, 0, true, st));
     RC(nt(P, true, true, true, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, 0, true, st));
+    }
     // ---- d_img = sum_t alpha_t (x) d_ctx_t  (batched over samples)  + d_mean / R + d_att_img W_att_img^T ----
     float* dimg = P.ws<float>(ws, W_DIMG);
     if (P.dimg_masked()) {

@@ -26,6 +26,8 @@ struct RStep {
                                                // every m when zx_idx is null and zx_row >= 0 (start token); training: zx_idx null, zx_row < 0 -> zx[m]
     // LSTM_BWD (c_prev shared with LSTM_FWD)
     const float* dhm; int lddhm; const float* carry_h; const float* gates_in; const float* c_cur; float* dcc; int carry_rows;
+    // PLAIN / TANH_O, off the recurrent loops (initial states and their gradients): v = acc + bias[n] (+ the old out when accumulate)
+    const float* bias; int accumulate;
     // CARRY
     const float* dolog; const float* o_prev; int ldoprev; int first;
     Drop dr;

@@ -218,6 +218,11 @@ __global__ __launch_bounds__(256) void rstep_kernel(RStep p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = red[0][row][part * 4 + e] + red[1][row][part * 4 + e] + red[2][row][part * 4 + e] + red[3][row][part * 4 + e];
+        if constexpr (EPI == RS_PLAIN || EPI == RS_TANH_O) {
+            // bias / accumulate: only the launches outside the loops set them (uniform branches, their loads wait here)
+            if (p.bias) { float b4[4]; ld4(p.bias + n, b4); for (int e = 0; e < 4; ++e) v[e] += b4[e]; }
+            if (p.accumulate) { float o4[4]; ld4(p.out + (long long)m * p.ldo + n, o4); for (int e = 0; e < 4; ++e) v[e] += o4[e]; }
+        }
         if constexpr (EPI == RS_PLAIN) {
             st4(p.out + (long long)m * p.ldo + n, v);
             if (p.outb) st4b(p.outb + (long long)m * p.ldob + n, v);
