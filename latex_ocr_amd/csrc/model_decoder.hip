@@ -437,6 +437,13 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, st));
     // embeddings
     float* demb = P.ws<float>(ws, W_DEMB);
+    if (fused) {   // d_emb = d_z K[0:D]^T over all T*B rows: a tall GEMM on the step kernel (505 workgroups; the bf16 mirror of d_z halves its bytes)
+        RStep e; memset(&e, 0, sizeof(e));
+        e.M = TB; e.N = D; e.K = 4 * U; e.U = U; e.O = O; e.zx_row = -1; e.epi = RS_PLAIN; e.dr.inv_keep = 1.f;
+        e.A = P.bf ? (const void*)P.ws<bf16_t>(ws, W_DZB) : (const void*)dz; e.lda = P.bf ? P.DZBP : 4 * U;
+        e.W = P.pk(wp, K_LSTM); e.ldw = P.ldK; e.out = demb; e.ldo = D;
+        RC(lxo_launch_rstep(P.s.dtype, P.bf, e, st));
+    } else
     RC(nt(P, true, true, true, dz, 4 * U, P.pk(wp, K_LSTM), P.ldK, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
     RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, st));
     // ---- initial states ----
