@@ -986,6 +986,61 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
     }
 }
 
+// The same without global atomics and robust to skewed token frequencies: workgroup `id` (V of them, + one for the start token) scans
+// the T*B token slots in chunks of 4096, compacts the slots that hold ITS token into an LDS list, then 256 / D rows of d_emb at a time
+// are summed column-wise (coalesced row reads) and the total is added to the table row once.  The atomic kernel above spent 46 us on
+// 0.5 M global atomics (uniform tokens; a frequent token serialises on its row); this one reads the token ids V times out of L2.
+__global__ __launch_bounds__(256) void embed_scatter_rows_kernel(const float* __restrict__ demb, const int* __restrict__ formula,
+                                                                float* __restrict__ dtable, float* __restrict__ dstart,
+                                                                int B, int T, int D, int V) {
+    constexpr int CH = 2048;
+    __shared__ int list[CH];
+    __shared__ float part[256];
+    __shared__ int cnt;
+    const int id = blockIdx.x;                                  // V = the start token (step 0 of every sample)
+    const int tid = threadIdx.x;
+    const int rpw = 256 / D, r = tid / D, c = tid - r * D;      // rows summed in parallel, this thread's (row lane, column)
+    float sum = 0.f;
+    const int total = T * B;
+    // blockIdx.y: a quarter of the slots each (a frequent token -- the PAD id of a padded batch holds a third of all slots -- would
+    // otherwise make one workgroup the whole kernel); the quarters meet in D atomics per workgroup
+    const int per = (total + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(total, s0 + per);
+    for (int base = s0; base < s1; base += CH) {
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        for (int j = base + tid; j < min(s1, base + CH); j += 256) {
+            // slot j of `formula` ([B][T], read in its own order: coalesced) = sample b, position tt: the input of step tt + 1 (the
+            // last position feeds no step); the start token feeds step 0 of every sample: rows 0 .. B-1 of d_emb
+            const int b = j / T, tt = j - b * T;
+            if (id == V) { if (j < B) list[atomicAdd(&cnt, 1)] = j; continue; }
+            if (tt + 1 >= T) continue;
+            int tok = formula[j]; tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+            if (tok == id) list[atomicAdd(&cnt, 1)] = (tt + 1) * B + b;
+        }
+        __syncthreads();
+        const int n = cnt;
+        if (r < rpw) {
+            for (int k = r; k < n; k += 4 * rpw) {              // four rows per thread in flight
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int kk = min(k + u * rpw, n - 1); v[u] = demb[(long long)list[kk] * D + c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (k + u * rpw < n) sum += v[u];
+            }
+        }
+        __syncthreads();
+    }
+    part[tid] = (r < rpw) ? sum : 0.f;
+    __syncthreads();
+    if (tid < D) {
+        float t = 0.f;
+        for (int q = 0; q < rpw; ++q) t += part[q * D + tid];
+        float* dst = id == V ? dstart : dtable + (long long)id * D;
+        if (t != 0.f) atomicAdd(&dst[tid], t);
+    }
+}
+
 // dpre = d_s0 * (1 - s0^2) for s in (c, h, o) -> [B][U+U+O]   (attention_mechanism.py:151 backward)
 __global__ __launch_bounds__(256) void init_bwd_kernel(const float* __restrict__ dcc, Slabs dxh,
                                                       const float* __restrict__ c0, const float* __restrict__ rec0, int ldr,
@@ -1359,6 +1414,7 @@ int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t 
     DONE;
 }
 int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st) {
+    if (D <= 256) { hipLaunchKernelGGL(embed_scatter_rows_kernel, dim3(V + 1, 4), dim3(256), 0, st, demb, formula, dtable, dstart, B, T, D, V); DONE; }
     LAUNCH(embed_scatter_kernel, grid1((long long)T * B * D), demb, formula, dtable, dstart, B, T, D, V);
     DONE;
 }
