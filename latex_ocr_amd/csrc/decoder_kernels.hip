@@ -787,8 +787,11 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
             for (int j = 0; j < 4; ++j) { x[rr][kc][j] = 0.f; acc[rr][kc][j] = 0.f; }
             if (rbase + rr < R && kc < KC && k0 < E) load4(att_img + ((long long)b * R + rbase + rr) * E + k0, x[rr][kc]);
             if constexpr (is_bf16<CT>::value) {
+                // e^{2(x + a)} = e^{2x} e^{2a}: the factor of the region element is formed ONCE here, the factor of the step's att_h
+                // once per step for all four regions -- per element and step that leaves one transcendental (the reciprocal) instead
+                // of two.  Exponents clamped to +-120 (2^+-120: products never meet inf * 0; |x| > 41 is 1 - tanh^2 < 1e-35 anyway)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[rr][kc][j] *= 2.8853900817779268f;
+                for (int j = 0; j < 4; ++j) x[rr][kc][j] = __builtin_amdgcn_exp2f(fminf(fmaxf(x[rr][kc][j] * 2.8853900817779268f, -120.f), 120.f));
             }
         }
     float sumd = 0.f;                                     // bf16 path: sum of d over the steps and the wave's regions
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
                     for (int rr = 0; rr < 4; ++rr) d[tt][rr] = (t < T && rbase + rr < R) ? dq[rr] : 0.f;
                     if constexpr (is_bf16<CT>::value) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) a[tt][j] *= 2.8853900817779268f;
+                        for (int j = 0; j < 4; ++j) a[tt][j] = __builtin_amdgcn_exp2f(fminf(fmaxf(a[tt][j] * 2.8853900817779268f, -120.f), 120.f));
                     }
                 }
 #pragma unroll
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
                         if constexpr (is_bf16<CT>::value) {
                             // with r = 1 / (1 + e^{2s}):  tau = 1 - 2r,  1 - tau^2 = 4 r (1 - r).  The kernel is VALU-bound
                             // (1.4 G tanh per launch), so everything around the two transcendentals is pared down: x and
-                            // att_h arrive pre-scaled by 2 log2 e (x once, att_h once per step for all four regions), the
+                            // att_h arrive as e^{2x} / e^{2a} (x once, att_h once per step for all four regions), the
                             // element pairs run on the packed-f32 ALU (v_pk_add / v_pk_fma), and
                             // d_beta = sum d - 2 sum d r keeps only the r-part per element
                             const f32x2 d4 = {4.f * dd, 4.f * dd}, d2 = {dd, dd}, one = {1.f, 1.f};
@@ -830,9 +833,7 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 const f32x2 xs = {x[rr][kc][2 * h], x[rr][kc][2 * h + 1]}, as = {a[tt][2 * h], a[tt][2 * h + 1]};
-                                const f32x2 y = xs + as;
-                                const f32x2 u = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
-                                const f32x2 w = u + one;
+                                const f32x2 w = __builtin_elementwise_fma(xs, as, one);          // 1 + e^{2x} e^{2a}
                                 const f32x2 r = {__builtin_amdgcn_rcpf(w[0]), __builtin_amdgcn_rcpf(w[1])};
                                 const f32x2 q = __builtin_elementwise_fma(-r, r, r);
                                 f32x2 ac = {acc[rr][kc][2 * h], acc[rr][kc][2 * h + 1]}, dv = {db[kc][2 * h], db[kc][2 * h + 1]};
