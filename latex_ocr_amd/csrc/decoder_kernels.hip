@@ -1003,8 +1003,8 @@ __global__ __launch_bounds__(256) void embed_scatter_rows_kernel(const float* __
     const int rpw = 256 / D, r = tid / D, c = tid - r * D;      // rows summed in parallel, this thread's (row lane, column)
     float sum = 0.f;
     const int total = T * B;
-    // blockIdx.y: a quarter of the slots each (a frequent token -- the PAD id of a padded batch holds a third of all slots -- would
-    // otherwise make one workgroup the whole kernel); the quarters meet in D atomics per workgroup
+    // blockIdx.y: a sixteenth of the slots each (a frequent token -- the PAD id of a padded batch holds a third of all slots -- would
+    // otherwise make one workgroup the whole kernel); the parts meet in D atomics per workgroup
     const int per = (total + (int)gridDim.y - 1) / (int)gridDim.y;
     const int s0 = blockIdx.y * per, s1 = min(total, s0 + per);
     for (int base = s0; base < s1; base += CH) {
@@ -1415,7 +1415,7 @@ int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t 
     DONE;
 }
 int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st) {
-    if (D <= 256) { hipLaunchKernelGGL(embed_scatter_rows_kernel, dim3(V + 1, 4), dim3(256), 0, st, demb, formula, dtable, dstart, B, T, D, V); DONE; }
+    if (D <= 256) { hipLaunchKernelGGL(embed_scatter_rows_kernel, dim3(V + 1, 16), dim3(256), 0, st, demb, formula, dtable, dstart, B, T, D, V); DONE; }
     LAUNCH(embed_scatter_kernel, grid1((long long)T * B * D), demb, formula, dtable, dstart, B, T, D, V);
     DONE;
 }
