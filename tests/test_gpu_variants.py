@@ -13,7 +13,8 @@ mathematics with different kernels, so they must agree far more tightly than eit
   (LXO_GEMM_NT_DMA=0): the same products in the same order per output element;
 * forward attention as part + combine (default)  vs  scores kernel + softmax-context kernel without a merge launch
   (LXO_ATT_SPLIT=1): summation order;
-* fused recurrent-step kernels (default)  vs  round 1's split-K kernels (step_kernels = 1).
+* fused recurrent-step kernels (default)  vs  round 1's split-K kernels (step_kernels = 1);
+* the off-by-default stream switches LXO_DUAL_STREAM=1 and LXO_ENC_OVERLAP=1 (both measured slower, kept as A/B paths).
 Odd image sizes exercise the clipped pool windows of both generations."""
 import os, subprocess, sys
 import numpy as np
@@ -59,7 +60,11 @@ def test_kernel_generations_agree(tmp_path, h, w):
             ("tn_packing_kernel", {"LXO_GEMM_TN_TR": "0"}, (1e-5, 0.99999, 1e-2)),
             ("nt_register_staged", {"LXO_GEMM_NT_DMA": "0"}, (1e-5, 0.99999, 1e-2)),
             ("att_scores_then_context", {"LXO_ATT_SPLIT": "1"}, (1e-5, 0.99999, 1e-2)),
-            ("split_k_steps", {"LXO_STEP_KERNELS": "1"}, (1e-4, 0.9995, 5e-2))):
+            ("split_k_steps", {"LXO_STEP_KERNELS": "1"}, (1e-4, 0.9995, 5e-2)),
+            # the two off-by-default stream switches: half-batch chains on two streams (on the split-K step kernels) and the
+            # encoder's weight gradients on a second stream (the same kernels, other order of the f32 atomics)
+            ("two_half_batch_chains", {"LXO_DUAL_STREAM": "1"}, (1e-4, 0.9995, 5e-2)),
+            ("wgrad_side_stream", {"LXO_ENC_OVERLAP": "1"}, (1e-5, 0.99999, 1e-2))):
         other = _run(tmp_path, name, env, h, w, 4)
         worst = _compare(base, other, *bars)
         print("%dx%d default vs %s: worst cosine %.8f (%s, max rel %.2e)" % (h, w, name, worst[0], worst[1], worst[2]))
