@@ -3,11 +3,11 @@
 // One AttentionCell.step (attention_cell.py:58-89) is a chain of DEPENDENT launches; measured on MI355X
 // (tools/launch_probe.hip, tools/loop_probe.py) the chain is device-bound: 1.53 us per kernel boundary plus
 // ~3 us per body, and every split-K GEMM leaves 1-4 MB of f32 partial products for its consumer to re-read.
-// The kernels here take the other decomposition: a workgroup owns 16 OUTPUT COLUMNS for all 64 rows over the
+// The kernels here take the other decomposition: a workgroup owns 16 OUTPUT COLUMNS for a tile of 64 / 32 / 16 rows over the
 // FULL contraction, so the product is final inside the workgroup and the consumer stage (LSTM gates, tanh, LSTM
 // backward, the carried tanh') runs in the epilogue: one launch instead of two, no slabs.
 //
-//   C[64 x 16] = A[64 x K] * W[16 x K]^T          4 waves, each contracts a quarter of K for all 64 rows
+//   C[MT x 16] = A[MT x K] * W[16 x K]^T          4 waves, each contracts a quarter of K for all MT rows
 //   v_mfma_f32_16x16x32_bf16 (v_mfma_f32_16x16x4_f32 in the f32 parity mode), operands loaded straight into
 //   MFMA fragment layout (16 B per lane; the k permutation inside a 32-wide step is free because A and W
 //   use the same one), ALL loads of a chunk in flight at once (one memory round trip), partial tiles of the
@@ -39,7 +39,7 @@ LXO_DEV void st4b(bf16_t* p, const float (&v)[4]) { u32x2 a = {pack_bf2(v[0], v[
 LXO_DEV void ld4(const float* p, float (&v)[4]) { const f32x4 a = *reinterpret_cast<const f32x4*>(p); v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
 
 // AT: element type of A in memory (bf16 mirror, or float converted while staging); WT: compute dtype (bf16 / float = parity mode)
-// MT: rows per workgroup (64 or 32); KC: k elements of this wave's share staged per chunk; NCH: chunks (compile time, so that
+// MT: rows per workgroup (64, 32 or 16: the launcher takes the smallest that still gives every CU at most one workgroup); KC: k elements of this wave's share staged per chunk; NCH: chunks (compile time, so that
 // every s_waitcnt is counted: staging chunk c waits for ITS loads only while the later chunks are still landing);
 // NBUF: chunks whose loads are in flight in registers (chunks beyond that are re-issued into freed registers).
 // Every wave stages ITS OWN quarter of the contraction for all MT rows through its own LDS region: global loads are
@@ -48,7 +48,7 @@ LXO_DEV void ld4(const float* p, float (&v)[4]) { const f32x4 a = *reinterpret_c
 // bank groups).  No workgroup barrier in the main loop: a wave only reads LDS it wrote itself, and the LDS pipe
 // is in order per wave.  The epilogue's own operands are requested before the main loop so that their memory round
 // trip overlaps the GEMM.  In-kernel stamps (tools/rstep_stamps.py): a CU accepts one 1-KB wave load per ~24 cycles, so
-// the fetch of A (re-read by every workgroup) sets the kernel's length -- hence MT = 32 when that fills more CUs.
+// the fetch of A (re-read by every workgroup) sets the kernel's length -- hence MT = 32 / 16 when that fills more CUs.
 template <typename AT, typename WT, int EPI, int MT, int KC, int NCH, int NBUF>
 __global__ __launch_bounds__(256) void rstep_kernel(RStep p) {
     constexpr bool BF = is_bf16<WT>::value;
