@@ -50,7 +50,11 @@ LXO_DEV void ld4(const float* p, float (&v)[4]) { const f32x4 a = *reinterpret_c
 // trip overlaps the GEMM.  In-kernel stamps (tools/rstep_stamps.py): a CU accepts one 1-KB wave load per ~24 cycles, so
 // the fetch of A (re-read by every workgroup) sets the kernel's length -- hence MT = 32 / 16 when that fills more CUs.
 template <typename AT, typename WT, int EPI, int MT, int KC, int NCH, int NBUF>
-__global__ __launch_bounds__(256) void rstep_kernel(RStep p) {
+__global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* kW, int k_lda, int k_ldw, int k_M, int k_N, int k_K, int k_U, RStep p) {
+    // The leading scalars repeat p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U: scalar kernel arguments are PRELOADED into SGPRs at wave
+    // launch (-mllvm -amdgpu-kernarg-preload-count, Makefile), a by-value struct is not -- so the operand addresses and the first
+    // loads do not wait for the scalar loads of the 280-byte argument block (a memory round trip at the head of every launch of
+    // the recurrence); the rest of `p` (epilogue operands, outputs) arrives while those loads are in flight.
     constexpr bool BF = is_bf16<WT>::value;
     constexpr int RB = MT / 16;                                              // 16-row MFMA blocks per wave
     constexpr int PITCH = KC + (BF ? 8 : 4);
@@ -64,37 +68,37 @@ __global__ __launch_bounds__(256) void rstep_kernel(RStep p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * MT;
-    const int kq = p.K >> 2;                                  // this wave's share of the contraction (= KC * NCH)
+    const int kq = k_K >> 2;                                  // this wave's share of the contraction (= KC * NCH)
     WT* As = lds[wave];
     WT* Ws = lds[wave] + MT * PITCH;
-    const AT* __restrict__ Ag = reinterpret_cast<const AT*>(p.A) + wave * kq;
-    const WT* __restrict__ Wg = reinterpret_cast<const WT*>(p.W) + wave * kq;
+    const AT* __restrict__ Ag = reinterpret_cast<const AT*>(kA) + wave * kq;
+    const WT* __restrict__ Wg = reinterpret_cast<const WT*>(kW) + wave * kq;
     // per-lane source rows of the staging loads
     int aoff[NA], woff[NW];                                   // element offsets inside one step's operands: well below 2^31
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int i = j * 64 + lane, row = i / PRA, pc = i - row * PRA;
         int m = m0 + row;
-        if (m >= p.M) m = p.M - 1;
-        aoff[j] = m * p.lda + pc * APL;
+        if (m >= k_M) m = k_M - 1;
+        aoff[j] = m * k_lda + pc * APL;
     }
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int i = j * 64 + lane, row = i / PRW, pc = i - row * PRW;
         int nb;                                               // output column of tile row `row`
-        if constexpr (EPI == RS_LSTM_FWD) nb = (row >> 2) * p.U + blockIdx.x * 4 + (row & 3);   // 4 units x gates i,j,f,o
+        if constexpr (EPI == RS_LSTM_FWD) nb = (row >> 2) * k_U + blockIdx.x * 4 + (row & 3);   // 4 units x gates i,j,f,o
         else nb = blockIdx.x * 16 + row;
-        if (nb >= p.N) nb = p.N - 1;
-        woff[j] = nb * p.ldw + pc * WPL;
+        if (nb >= k_N) nb = k_N - 1;
+        woff[j] = nb * k_ldw + pc * WPL;
     }
     u32x4 ra[NBUF][NA], rw[NBUF][NW];
 #define ISSUE(buf, c) do { const int kb_ = (c) * KC; \
         _Pragma("unroll") for (int j = 0; j < NW; ++j) rw[buf][j] = *reinterpret_cast<const u32x4*>(Wg + woff[j] + kb_); \
         _Pragma("unroll") for (int j = 0; j < NA; ++j) ra[buf][j] = *reinterpret_cast<const u32x4*>(Ag + aoff[j] + kb_); } while (0)
 #define STAMP(i) do { if (p.dbg && tid == 0) p.dbg[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-    STAMP(0);
 #pragma unroll
     for (int b = 0; b < NBUF; ++b) if (b < NCH) ISSUE(b, b);
+    STAMP(0);                                                 // p.dbg is part of the argument block: nothing of it is touched before the loads are out
 
     // ---- epilogue operands, requested now ----
     constexpr int ETH = MT * 4;                               // threads that run the epilogue: (row, 4 columns) each
@@ -281,11 +285,11 @@ template <typename AT, typename WT, int EPI, int MT, int KC>
 int launch_nch(const RStep& p, dim3 grid, hipStream_t st) {
     const int nch = (p.K / 4) / KC;
     switch (nch) {
-    case 1: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 1, 1>), grid, dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 2, 2>), grid, dim3(256), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 4, 4>), grid, dim3(256), 0, st, p); break;
-    case 8: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 8, 4>), grid, dim3(256), 0, st, p); break;
-    case 16: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 16, 4>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 1, 1>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
+    case 2: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 2, 2>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
+    case 4: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 4, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
+    case 8: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 8, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
+    case 16: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 16, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
     default: return -2;                                     // K / (4 * KC) must be a power of two up to 16 (every shape validate() admits with U, O, E, C in {128, 256, 512})
     }
     return (int)hipGetLastError();
