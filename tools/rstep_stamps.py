@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 lib = ctypes.CDLL(os.path.join(ROOT, "latex_ocr_amd", "liblxo.so"))
 lib.lxo_rstep_debug.argtypes = [ctypes.c_void_p, ctypes.c_int]
 names = ["start", "requests issued", "chunk0 staged", "chunk0 computed", "all computed", "reduced", "epilogue done"]
-for epi, label in ((2, "LSTM_FWD"), (1, "TANH_O"), (0, "PLAIN (last launch: B1 in bwd)"), (3, "LSTM_BWD"), (4, "CARRY (t=0: raw)")):
+for epi, label in ((2, "LSTM_FWD"), (1, "TANH_O"), (0, "PLAIN (last launch of a step: the tall d_emb GEMM over all T*B rows)"), (3, "LSTM_BWD"), (4, "CARRY (t=0: raw)")):
     dbg = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
     lib.lxo_rstep_debug(ctypes.c_void_p(dbg.data_ptr()), epi)
     eng.forward(img, f_d)
