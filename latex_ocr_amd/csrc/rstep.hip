@@ -26,6 +26,18 @@ LXO_DEV v4f mfma16_bf16(u32x4 a, u32x4 b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// The cell's transcendentals.  f32 (parity) mode: the library functions.  bf16 mode: v_exp_f32 / v_rcp_f32 forms (abs error ~1e-7, far
+// below what the bf16 mirrors of h / o keep): in-kernel stamps put 1.8-2.2 k cycles of a 5-6 k cycle step kernel into the epilogue,
+// most of it the five library calls per LSTM element.  Saturation is exact (e^{2x} -> inf gives 1, -> 0 gives -1 / 0).
+template <bool FAST> LXO_DEV float tanh_e(float x) {
+    if constexpr (FAST) return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.f);
+    else return tanhf(x);
+}
+template <bool FAST> LXO_DEV float sigm_e(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+    else return sigmoidf_(x);
+}
+
 // 8 consecutive k of one row as a bf16 MFMA fragment
 LXO_DEV u32x4 frag8(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
 LXO_DEV u32x4 frag8(const float* p) {
@@ -202,10 +214,10 @@ __global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float z = pz[q] + red[0][row][q * 4 + part] + red[1][row][q * 4 + part] + red[2][row][q * 4 + part] + red[3][row][q * 4 + part];
-            a[q] = (q == 1) ? tanhf(z) : sigmoidf_(q == 2 ? z + 1.0f : z);
+            a[q] = (q == 1) ? tanh_e<BF>(z) : sigm_e<BF>(q == 2 ? z + 1.0f : z);
         }
         const float c = a[2] * pcp + a[0] * a[1];
-        const float h = a[3] * tanhf(c);
+        const float h = a[3] * tanh_e<BF>(c);
         const float ht = h * drop_scale(p.dr, 1u, m, u, U);      // h~ = dropout(h): what attention and the o projection read (attention_cell.py:72)
         if (p.gates) {
 #pragma unroll
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* 
         } else if constexpr (EPI == RS_TANH_O) {
             // o = dropout(tanh(.))      (attention_cell.py:82-83)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]) * drop_scale(p.dr, 2u, m, n + e, p.N);
+            for (int e = 0; e < 4; ++e) v[e] = tanh_e<BF>(v[e]) * drop_scale(p.dr, 2u, m, n + e, p.N);
             st4(p.out + (long long)m * p.ldo + n, v);
             if (p.outb) st4b(p.outb + (long long)m * p.ldob + n, v);
         } else if constexpr (EPI == RS_LSTM_BWD) {
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float dh = (e0[e] + v[e]) * drop_scale(p.dr, 1u, m, n + e, U) + e1[e];
-                const float tc = tanhf(e6[e]);
+                const float tc = tanh_e<BF>(e6[e]);
                 const float dc = e8[e] + dh * e5[e] * (1.f - tc * tc);
                 dzi[e] = dc * e3[e] * e2[e] * (1.f - e2[e]);
                 dzj[e] = dc * e2[e] * (1.f - e3[e] * e3[e]);
