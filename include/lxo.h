@@ -19,10 +19,11 @@ extern "C" {
 #define LXO_BF16 1
 
 const char* lxo_last_error(void);
-/* ABI version of this header.  Bumped whenever lxo_shape grows or an entry point changes (round 3: 3).  A binding must check
+/* ABI version of this header.  Bumped whenever lxo_shape grows or an entry point changes (round 4: 4 -- lxo_comm_*,
+ * lxo_allreduce_bucket, LXO_GNORM_FLOATS behind lxo_global_norm_scale's scale_out).  A binding must check
  * lxo_version() == LXO_ABI_VERSION and lxo_shape_size() == sizeof(its own lxo_shape) before the first call: a caller built
  * against an older header passes a shorter struct and the library would read past its end. */
-#define LXO_ABI_VERSION 3
+#define LXO_ABI_VERSION 4
 int lxo_version(void);
 int lxo_shape_size(void);
 
@@ -208,7 +209,10 @@ int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const vo
                                const int32_t* formula, float* grads, const int32_t* active_rows, int parts, void* stream);
 
 /* tf.clip_by_global_norm scale (img2seq.py:119-121): scale_out[0] = clip / max(||g||, clip),
- * scale_out[1] = ||g|| ; device memory, no host sync.  clip <= 0 -> scale 1. */
+ * scale_out[1] = ||g|| ; device memory, no host sync.  clip <= 0 -> scale 1.  scale_out must hold LXO_GNORM_FLOATS floats:
+ * the rest is scratch for one partial sum of squares per workgroup, which are added in workgroup order (no float atomics:
+ * the norm is the same in every run). */
+#define LXO_GNORM_FLOATS (2 + 1024)
 int lxo_global_norm_scale(long long n, const float* grads, float clip, float* scale_out, void* stream);
 /* tf.train.AdamOptimizer update (img2seq.py:101), TF epsilon placement:
  * m,v updated; theta -= lr_t * m / (sqrt(v) + eps), grads pre-multiplied by *scale_dev if given. */
@@ -249,6 +253,30 @@ int lxo_decode_step(const lxo_shape* s, const float* params, const void* wpack, 
 int lxo_beam_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                     int id_end, int max_iter, int32_t* ids_out, int32_t* parents_out,
                     int* steps_out, void* stream);
+
+/* ---- data parallel: one process per GPU, RCCL over xGMI -------------------------------------
+ * The reference trains on one device (one sess.run per step, model/img2seq.py:169).  Samples are independent through encoder,
+ * decoder and loss, so a data-parallel binding needs exactly two exchanges per step, both sums over ranks:
+ *   (1) the number of unmasked tokens -- the loss is the mean over ALL tokens of the GLOBAL batch (img2seq.py:69-71); the summed
+ *       count is what lxo_ce_loss_fwd_bwd_dev reads from device memory;
+ *   (2) the gradients, in buckets as lxo_decoder_train_bwd_part / lxo_encoder_bwd(l, l) finalise them (y_W_o, the rest of the
+ *       decoder, conv6 .. conv3, conv2 + conv1), on a side stream so that they overlap the rest of the backward.
+ * RCCL (librccl.so) is bound with dlopen at the first lxo_comm_* call; nothing else in the library needs it.
+ * Bootstrap: rank 0 calls lxo_comm_unique_id and ships the LXO_COMM_ID_BYTES bytes to the other ranks by any host channel
+ * (a file, a TCP store, MPI); every rank then calls lxo_comm_init with ITS device current (hipSetDevice). */
+#define LXO_COMM_ID_BYTES 128
+int lxo_comm_unique_id(void* id_out /* host, LXO_COMM_ID_BYTES */);
+int lxo_comm_init(const void* unique_id, int rank, int world, void** comm_out);
+/* rank / world as the communicator reports them (ncclCommUserRank / ncclCommCount): what bench.py prints as rccl_ranks_seen */
+int lxo_comm_info(void* comm, int* rank, int* world);
+/* In-place sum over ranks of `count` elements (LXO_F32, LXO_BF16 or LXO_I32) at device pointer ptr, enqueued on side_stream
+ * (a hipStream_t).  ready_event (a hipEvent_t, may be NULL): recorded by the caller on its compute stream behind the kernels
+ * that finalised the bucket; the side stream waits for it before the collective.  A caller that orders buckets on the host
+ * (hipEventSynchronize, then this call) passes NULL.  The caller makes its compute stream wait for side_stream before the
+ * optimizer step.  Every rank must issue the same sequence of calls on a communicator. */
+int lxo_allreduce_bucket(void* comm, void* ptr, long long count, int dtype, void* side_stream, void* ready_event);
+int lxo_comm_destroy(void* comm);
+const char* lxo_comm_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,9 @@ extern "C" int lxo_ws_region_dtype(const lxo_shape* s, const char* name) {
     for (const char* n : kU8) if (strcmp(name, n) == 0) return LXO_U8;
     // "d_img": the hand-over from the decoder backward to the encoder backward.  f32 mode: the f32 gradient w.r.t. the encoder
     // output; bf16 mode: d_y6 (that gradient with conv6's ReLU mask applied, bf16; conv6's bias gradient is already in grads)
-    if (strcmp(name, "d_img") == 0) return bf ? LXO_BF16 : LXO_F32;
+    // -- and only where the decoder's last GEMM applies the mask (Plan::dimg_masked: bf16, E % 32 == 0, no row encoder); with the row
+    // encoder, or an E the fused GEMM does not take, the region is the plain f32 gradient in bf16 mode too
+    if (strcmp(name, "d_img") == 0) { Plan P(*s); return P.dimg_masked() ? LXO_BF16 : LXO_F32; }
     for (int i = 0; i < W_COUNT; ++i) if (strcmp(name, lxo_ws_name(i)) == 0) return LXO_F32;
     return fail(-1, "unknown workspace region");
 }
@@ -157,7 +159,7 @@ extern "C" int lxo_decoder_train_bwd_active(const lxo_shape* s, const float* par
     return 0;
 }
 extern "C" int lxo_global_norm_scale(long long n, const float* grads, float clip, float* scale_out, void* stream) {
-    // scale_out needs 3 floats: {scale, norm, scratch}
+    // scale_out: LXO_GNORM_FLOATS floats = {scale, norm, up to 1024 per-workgroup partial sums (added in order: no atomics)}
     CHECK_LAUNCH(lxo_k_global_norm_scale(n, grads, clip, scale_out + 2, scale_out, (hipStream_t)stream), "lxo_global_norm_scale");
     return 0;
 }

@@ -7,6 +7,11 @@ struct Slabs { const float* p; int n; long long stride; int ld; };
 // row0 + r, column c) of stream `which` is kept iff hash24(seed, which, (t*rows_total + row0 + r)*width + c) < thr;
 // kept values are scaled by inv_keep.  thr == 0 disables (keep_prob 1, decode).
 struct Drop { unsigned thr; float inv_keep; unsigned seed; int t, row0, rows_total; };
+// f32 parity mode ("det"): reductions whose partial sums would meet in one address by float atomics store the partials to slots of
+// this scratch (ws region "det_part") instead and lxo_k_det_reduce adds the slots in ascending order, so that two runs of the
+// same step agree bit for bit.  p == nullptr (bf16 mode): atomics.
+struct DetScratch { float* p; size_t floats; };
+int lxo_k_det_reduce(const float* part, int nslot, long long stride, int N, float* out, hipStream_t st);    // out[n] += sum_q part[q * stride + n]
 int lxo_k_rowmean(int dt, const void* img, float* mean, int B, int R, int C, hipStream_t st);
 int lxo_k_embed_gather(int dt, const float* table, const float* start, const int* formula, void* out, int B, int T, int D, int Dp, int V, hipStream_t st);
 int lxo_k_embed_rows(int dt, const float* table, const float* start, const int* ids, void* out, int n, int D, int Dp, int V, hipStream_t st);
@@ -24,13 +29,13 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
                    Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
                    int nv, int R, int Rp, int E, int C, int nch, int rev, hipStream_t st);
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
-                   int T, int B, int R, int Rp, int E, hipStream_t st);
+                   int T, int B, int R, int Rp, int E, DetScratch det, hipStream_t st);
 int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st);
 // ntok_dev (nullable): device scalar holding the global token count; when set the kernel uses 1 / *ntok_dev instead of inv_ntok
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
-                  const float* ntok_dev, int B, int T, int V, int Vp, hipStream_t st);
-int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t st);
-int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st);
+                  const float* ntok_dev, int B, int T, int V, int Vp, DetScratch det, hipStream_t st);
+int lxo_k_colsum(const float* a, long long lda, float* out, long long M, int N, DetScratch det, hipStream_t st);
+int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, int det, hipStream_t st);
 int lxo_k_init_bwd(const float* dcc, Slabs dxh, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st);
 int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids_step, int* ids_out, int max_steps, int step,
                  int* finished, int* n_unfinished, hipStream_t st);

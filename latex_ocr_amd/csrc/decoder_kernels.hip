@@ -761,7 +761,7 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
 template <typename CT, int KCT>
 __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ att_img, const float* __restrict__ att_h,
                                                       const float* __restrict__ beta, const float* __restrict__ de,
-                                                      CT* __restrict__ dout, float* __restrict__ dbeta,
+                                                      CT* __restrict__ dout, float* __restrict__ dbeta, float* __restrict__ dbeta_part,
                                                       int T, int B, int R, int Rp, int E) {
     __shared__ float redb[4][1024];
     const int b = blockIdx.y;
@@ -876,6 +876,11 @@ __global__ __launch_bounds__(256) void datt_img_kernel(const CT* __restrict__ at
         }
     }
     __syncthreads();
+    if (dbeta_part) {       // f32 parity mode: this workgroup's slot of the scratch; lxo_k_det_reduce adds the slots in order
+        float* slot = dbeta_part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * E;
+        for (int k = tid; k < E; k += 256) slot[k] = redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k];
+        return;
+    }
     for (int k = tid; k < E; k += 256) atomicAdd(&dbeta[k], redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k]);
 }
 
@@ -896,7 +901,7 @@ __global__ __launch_bounds__(256) void add_mean_grad_kernel(float* __restrict__ 
 template <typename CT>
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int* __restrict__ formula,
                                                      const int* __restrict__ lengths, CT* __restrict__ dlogits,
-                                                     float* __restrict__ loss_acc, float inv_ntok, const float* __restrict__ ntok_dev,
+                                                     float* __restrict__ loss_acc, float* __restrict__ loss_part, float inv_ntok, const float* __restrict__ ntok_dev,
                                                      int B, int T, int V, int Vp) {
     __shared__ float red[8];
     if (ntok_dev) inv_ntok = 1.0f / ntok_dev[0];      // data parallel: the global token count arrives by all-reduce, never through the host
@@ -928,7 +933,8 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         const float c = red[0] + red[1] + red[2] + red[3], n = red[4] + red[5] + red[6] + red[7];
-        if (n > 0.f) { atomicAdd(&loss_acc[0], c); atomicAdd(&loss_acc[1], n); }
+        if (loss_part) { loss_part[2 * blockIdx.x] = c; loss_part[2 * blockIdx.x + 1] = n; }     // f32 parity mode: summed in workgroup order by lxo_k_det_reduce
+        else if (n > 0.f) { atomicAdd(&loss_acc[0], c); atomicAdd(&loss_acc[1], n); }
     }
 }
 
@@ -968,6 +974,31 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
 }
 
 
+// ---- f32 parity mode: reductions without float atomics (the order of every sum is fixed, so two runs agree bit for bit) ----
+// part[rb][n] = sum of rows [rb * rows_per, ...) of column n, rows in ascending order
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ a, long long lda, float* __restrict__ part, long long M, int N, int rows_per) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const long long m0 = (long long)blockIdx.y * rows_per, m1 = m0 + rows_per < M ? m0 + rows_per : M;
+    if (n >= N) return;
+    float s = 0.f;
+    for (long long mb = m0; mb < m1; mb += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const long long m = mb + u < m1 ? mb + u : m1 - 1; v[u] = a[m * lda + n]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (mb + u < m1) s += v[u];
+    }
+    part[(long long)blockIdx.y * N + n] = s;
+}
+// out[n] += part[0][n] + part[1][n] + ... (slot order)
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int nslot, long long stride, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int q = 0; q < nslot; ++q) s += part[(long long)q * stride + n];
+    out[n] += s;
+}
+
 // d_emb rows -> embedding_table / start_token gradients (decoder.py:90-93 backward)
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ demb, const int* __restrict__ formula,
                                                            float* __restrict__ dtable, float* __restrict__ dstart,
@@ -993,11 +1024,12 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
 // 0.5 M global atomics (uniform tokens; a frequent token serialises on its row); this one reads the token ids V times out of L2.
 __global__ __launch_bounds__(256) void embed_scatter_rows_kernel(const float* __restrict__ demb, const int* __restrict__ formula,
                                                                 float* __restrict__ dtable, float* __restrict__ dstart,
-                                                                int B, int T, int D, int V) {
+                                                                int B, int T, int D, int V, int det) {
     constexpr int CH = 2048;
     __shared__ int list[CH];
     __shared__ float part[256];
     __shared__ int cnt;
+    __shared__ int wcnt[4];
     const int id = blockIdx.x;                                  // V = the start token (step 0 of every sample)
     const int tid = threadIdx.x;
     const int rpw = 256 / D, r = tid / D, c = tid - r * D;      // rows summed in parallel, this thread's (row lane, column)
@@ -1010,6 +1042,28 @@ __global__ __launch_bounds__(256) void embed_scatter_rows_kernel(const float* __
     for (int base = s0; base < s1; base += CH) {
         if (tid == 0) cnt = 0;
         __syncthreads();
+        if (det) {
+            // f32 parity mode: the list is compacted in slot order (ballot + prefix counts), so the rows are summed in the same order every run
+            for (int jb = base; jb < min(s1, base + CH); jb += 256) {      // block-uniform trip count
+                const int j = jb + tid;
+                int row = -1;
+                if (j < min(s1, base + CH)) {
+                    const int b = j / T, tt = j - b * T;
+                    if (id == V) { if (j < B) row = j; }
+                    else if (tt + 1 < T) { int tok = formula[j]; tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok); if (tok == id) row = (tt + 1) * B + b; }
+                }
+                const unsigned long long m = __ballot(row >= 0);
+                const int lane = tid & 63, wv = tid >> 6;
+                if (lane == 0) wcnt[wv] = __builtin_popcountll(m);
+                __syncthreads();
+                int off = cnt;
+                for (int w = 0; w < wv; ++w) off += wcnt[w];
+                if (row >= 0) list[off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = row;
+                __syncthreads();
+                if (tid == 0) cnt += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                __syncthreads();
+            }
+        } else
         for (int j = base + tid; j < min(s1, base + CH); j += 256) {
             // slot j of `formula` ([B][T], read in its own order: coalesced) = sample b, position tt: the input of step tt + 1 (the
             // last position feeds no step); the start token feeds step 0 of every sample: rows 0 .. B-1 of d_emb
@@ -1226,10 +1280,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];      // one partial per workgroup: summed in order below (no atomics: every run gives the same norm)
 }
-__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float clip, float* __restrict__ out) {
-    const float gn = sqrtf(sumsq[0]);
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, int nparts, float clip, float* __restrict__ out) {
+    float ss = 0.f;
+    for (int i = 0; i < nparts; ++i) ss += sumsq[i];
+    const float gn = sqrtf(ss);
     out[1] = gn;
     out[0] = clip > 0.f ? clip / fmaxf(gn, clip) : 1.0f;
 }
@@ -1363,7 +1419,7 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, nch, rows_per);
     DONE;
 }
-// datth must be zero on entry (chunks accumulate with atomics)
+// datth must be zero on entry (chunks accumulate with atomics; nch == 1 -- the f32 parity mode -- has one writer per element)
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
                    Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
                    int nv, int R, int Rp, int E, int C, int nch, int rev, hipStream_t st) {
@@ -1381,17 +1437,25 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* at
 #undef AB_ARGS
     DONE;
 }
+int lxo_k_det_reduce(const float* part, int nslot, long long stride, int N, float* out, hipStream_t st) {
+    if (nslot <= 0 || N <= 0) return 0;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, nslot, stride, N, out);
+    DONE;
+}
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
-                   int T, int B, int R, int Rp, int E, hipStream_t st) {
+                   int T, int B, int R, int Rp, int E, DetScratch det, hipStream_t st) {
     dim3 grid(cdiv(R, 16), B);
     if (E > 1024) return -2;
+    float* part = nullptr;
+    if (det.p) { if ((size_t)grid.x * grid.y * E > det.floats) return -6; part = det.p; }
     if (dt == LXO_BF16) {
-        if (E <= 256) hipLaunchKernelGGL((datt_img_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, T, B, R, Rp, E);
-        else hipLaunchKernelGGL((datt_img_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, T, B, R, Rp, E);
+        if (E <= 256) hipLaunchKernelGGL((datt_img_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, part, T, B, R, Rp, E);
+        else hipLaunchKernelGGL((datt_img_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)att_img, att_h, beta, de, (bf16_t*)dout, dbeta, part, T, B, R, Rp, E);
     } else {
-        if (E <= 256) hipLaunchKernelGGL((datt_img_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, T, B, R, Rp, E);
-        else hipLaunchKernelGGL((datt_img_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, T, B, R, Rp, E);
+        if (E <= 256) hipLaunchKernelGGL((datt_img_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, part, T, B, R, Rp, E);
+        else hipLaunchKernelGGL((datt_img_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)att_img, att_h, beta, de, (float*)dout, dbeta, part, T, B, R, Rp, E);
     }
+    if (part) return lxo_k_det_reduce(part, (int)(grid.x * grid.y), E, E, dbeta, st);
     DONE;
 }
 int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hipStream_t st) {
@@ -1399,23 +1463,39 @@ int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hi
     DONE;
 }
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
-                  const float* ntok_dev, int B, int T, int V, int Vp, hipStream_t st) {
+                  const float* ntok_dev, int B, int T, int V, int Vp, DetScratch det, hipStream_t st) {
     int g = cdiv(T * B, 4);
     if (g > 512) g = 512;
-    if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, inv_ntok, ntok_dev, B, T, V, Vp);
-    else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, inv_ntok, ntok_dev, B, T, V, Vp);
+    float* part = (det.p && det.floats >= 1024) ? det.p : nullptr;      // loss_acc is zero on entry (lxo_impl_ce_loss)
+    if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, part, inv_ntok, ntok_dev, B, T, V, Vp);
+    else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, part, inv_ntok, ntok_dev, B, T, V, Vp);
+    if (part) return lxo_k_det_reduce(part, g, 2, 2, loss_acc, st);
     DONE;
 }
-int lxo_k_colsum(const float* a, int lda, float* out, int M, int N, hipStream_t st) {
+int lxo_k_colsum(const float* a, long long lda, float* out, long long M, int N, DetScratch det, hipStream_t st) {
+    if (det.p) {
+        // f32 parity mode: per-row-block partial sums, then the blocks in order (two launches, no atomics)
+        if (M <= 0 || N <= 0) return 0;
+        long long maxslots = (long long)(det.floats / (size_t)N);
+        if (maxslots < 1) return -6;
+        if (maxslots > 1024) maxslots = 1024;
+        long long rows_per = (M + maxslots - 1) / maxslots;
+        if (rows_per < 64) rows_per = 64;
+        const int nrb = (int)((M + rows_per - 1) / rows_per);
+        hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 256), nrb), dim3(256), 0, st, a, lda, det.p, M, N, (int)rows_per);
+        return lxo_k_det_reduce(det.p, nrb, N, N, out, st);
+    }
     const int rpb = 64;
     if (N % 4 == 0 && lda % 4 == 0 && ((uintptr_t)a & 15) == 0 && M > 0)
-        hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, st, a, lda, out, M, N, rpb);
+        hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(N, 256), cdiv((int)M, rpb)), dim3(256), 0, st, a, (int)lda, out, (int)M, N, rpb);
     else
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, st, a, lda, out, M, N, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), cdiv((int)M, rpb)), dim3(256), 0, st, a, (int)lda, out, (int)M, N, rpb);
     DONE;
 }
-int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, hipStream_t st) {
-    if (D <= 256) { hipLaunchKernelGGL(embed_scatter_rows_kernel, dim3(V + 1, 16), dim3(256), 0, st, demb, formula, dtable, dstart, B, T, D, V); DONE; }
+// det != 0 (f32 parity mode): one workgroup per token id, its rows listed and summed in slot order (no atomics meet in a table row)
+int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, int det, hipStream_t st) {
+    if (D <= 256) { hipLaunchKernelGGL(embed_scatter_rows_kernel, dim3(V + 1, det ? 1 : 16), dim3(256), 0, st, demb, formula, dtable, dstart, B, T, D, V, det); DONE; }
+    if (det) return -2;
     LAUNCH(embed_scatter_kernel, grid1((long long)T * B * D), demb, formula, dtable, dstart, B, T, D, V);
     DONE;
 }
@@ -1449,10 +1529,11 @@ int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k
     LAUNCH(tile_rows_kernel, grid1((long long)n * cols), src, lds, dst, ldd, n, k, cols);
     DONE;
 }
+// sumsq_tmp: 1024 floats (one partial per workgroup, summed in order: the norm is the same in every run)
 int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sumsq_tmp, float* out, hipStream_t st) {
-    HIPRC(hipMemsetAsync(sumsq_tmp, 0, sizeof(float), st));
-    LAUNCH(sumsq_kernel, grid1(n, 256 * 8, 1024), g, n, sumsq_tmp);
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq_tmp, clip, out);
+    const int nparts = grid1(n, 256 * 8, 1024);
+    LAUNCH(sumsq_kernel, nparts, g, n, sumsq_tmp);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq_tmp, nparts, clip, out);
     DONE;
 }
 int lxo_k_simple_opt(float* p, const float* g, float* slot, long long n, float lr, int mode, const float* scale, hipStream_t st) {

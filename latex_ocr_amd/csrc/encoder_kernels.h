@@ -1,12 +1,14 @@
 // Launchers of the non-GEMM encoder kernels and of the weight-packing kernels.
 #pragma once
 #include "lxo_common.h"
+#include "decoder_kernels.h"
 // one weight-pack job: kind 0 transpose (dst[n][coff+k] = src[k][n], k < Kpad zero padded), kind 1 padded row copy
 // (K rows, N real / Kpad padded columns), kind 2 conv dgrad layout (K = Cin, N = Cout)
 struct PackJob { int kind, K, N, lds, ldd, coff, Kpad, first_block, nblocks; long long src; long long dst; };
 struct PackTable { int n; PackJob job[64]; };
 int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float* b, void* out, int B, int H, int W, hipStream_t s);
-int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s);
+// det (f32 parity mode): the workgroups' partial dW / db go to slots of the scratch and are added in order (no float atomics)
+int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, DetScratch det, hipStream_t s);
 int lxo_k_maxpool_fwd(int dt, const void* in, void* out, int B, int H, int W, int C, int ph, int pw, hipStream_t s);
 // bf16 mode, layers whose forward ran the fused conv + pool epilogue: routes by the one-byte-per-element mask instead of the activation
 int lxo_k_maxpool_mask_bwd(const unsigned char* mask, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s);

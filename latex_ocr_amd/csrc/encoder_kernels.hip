@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(const uint8_t* __re
 template <typename CT>
 __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const CT* __restrict__ dout,
-                                                            float* __restrict__ dw, float* __restrict__ db,
+                                                            float* __restrict__ dw, float* __restrict__ db, float* __restrict__ part,
                                                             int B, int H, int W, int Hp, int Wp) {
     __shared__ float red[4][8][80];
     const int cg = threadIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -187,7 +187,11 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(const uint8_t* __re
     for (int i = threadIdx.x; i < 640; i += 256) {
         const int g8 = i / 80, k = i % 80;
         const float v = red[0][g8][k] + red[1][g8][k] + red[2][g8][k] + red[3][g8][k];
-        if (k < 72) atomicAdd(&dw[(k >> 3) * 64 + g8 * 8 + (k & 7)], v);
+        if (part) {          // f32 parity mode: this workgroup's slot [dw 576 | db 64]; lxo_k_det_reduce adds the slots in order
+            if (k < 72) part[(long long)blockIdx.x * 640 + (k >> 3) * 64 + g8 * 8 + (k & 7)] = v;
+            else part[(long long)blockIdx.x * 640 + 576 + g8 * 8 + (k - 72)] = v;
+        }
+        else if (k < 72) atomicAdd(&dw[(k >> 3) * 64 + g8 * 8 + (k & 7)], v);
         else atomicAdd(&db[g8 * 8 + (k - 72)], v);
     }
 }
@@ -768,6 +772,7 @@ __global__ __launch_bounds__(256) void col2im_s2_relu_kernel(const CT* __restric
         for (int e = 0; e < 8; ++e) { acc[e] = r[e] > 0.f ? acc[e] : 0.f; cs[e] += acc[e]; }
         store8(dy + p * C + c8 * 8, acc);
     }
+    if (!db) return;             // f32 parity mode: the caller sums the columns of dy in a fixed order instead
 #pragma unroll
     for (int e = 0; e < 8; ++e) atomicAdd(&db[c8 * 8 + e], cs[e]);
 }
@@ -818,12 +823,20 @@ int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float
     DISPATCH_CT(dt, conv1_fwd_t, img, w, b, out, B, H, W, s);
     return (int)hipGetLastError();
 }
-template <typename CT> static void conv1_bwd_t(const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s) {
+template <typename CT> static int conv1_bwd_t(const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, DetScratch det, hipStream_t s) {
     const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
-    hipLaunchKernelGGL((conv1_pool_bwd_kernel<CT>), dim3(grid_for((long long)B * Hp * ((Wp + 31) / 32), 16, 512)), dim3(256), 0, s,
-                       img, w, b, (const CT*)dout, dw, db, B, H, W, Hp, Wp);
+    const int g = grid_for((long long)B * Hp * ((Wp + 31) / 32), 16, 512);
+    float* part = nullptr;
+    if (det.p) { if ((size_t)g * 640 > det.floats) return -6; part = det.p; }
+    hipLaunchKernelGGL((conv1_pool_bwd_kernel<CT>), dim3(g), dim3(256), 0, s,
+                       img, w, b, (const CT*)dout, dw, db, part, B, H, W, Hp, Wp);
+    if (part) {          // the workgroups' partial sums, added in workgroup order
+        if (int rc = lxo_k_det_reduce(part, g, 640, 576, dw, s)) return rc;
+        return lxo_k_det_reduce(part + 576, g, 640, 64, db, s);
+    }
+    return 0;
 }
-int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, hipStream_t s) {
+int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, DetScratch det, hipStream_t s) {
     if (dt == LXO_BF16 && conv1_mfma()) {
         const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
         static int cap = -1; if (cap < 0) { const char* e = getenv("LXO_C1_CAP"); cap = e ? atoi(e) : 512; }
@@ -831,7 +844,8 @@ int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float
                            img, w, b, (const bf16_t*)dout, dw, db, B, H, W, Hp, Wp);
         return (int)hipGetLastError();
     }
-    DISPATCH_CT(dt, conv1_bwd_t, img, w, b, dout, dw, db, B, H, W, s);
+    const int rc = dt == LXO_BF16 ? conv1_bwd_t<bf16_t>(img, w, b, dout, dw, db, B, H, W, det, s) : conv1_bwd_t<float>(img, w, b, dout, dw, db, B, H, W, det, s);
+    if (rc) return rc;
     return (int)hipGetLastError();
 }
 template <typename CT> static void pool_fwd_t(const void* in, void* out, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {

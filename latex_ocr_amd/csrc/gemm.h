@@ -26,7 +26,7 @@ struct GemmNT {
     // the activated tile, pool_mask (one byte per pooled element) = first-max position (qy * pw + qx) | 4 if the maximum is > 0;
     // C may be null (the full-resolution activation is then never written: nothing else reads it)
     void* pool_out; unsigned char* pool_mask; int pool_h, pool_w;
-    int diag;                  // measurement aid (LXO_CONV_DIAG, wrong results): 1 weights always from slice 0 / tap 0, 2 patch always slice 0, 4 no output stores
+    int diag;                  // -DLXO_DIAG builds only (LXO_CONV_DIAG, wrong results by design): 1 weights always from slice 0 / tap 0, 2 patch always slice 0, 4 no output stores; ignored by the shipped library
 };
 
 // C[I,J] (+)= sum_m A[m,I] * B[m,J]      ("TN": reduction over rows)
@@ -52,7 +52,7 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
 // split-K partial products: slab[ks][M][ldc] = A[:, ks*128:(ks+1)*128] * Bp[:, same]^T, ks < K/128 (A float)
 int lxo_launch_gemm_slab(int dt, const GemmNT& p, float* slab, long long slab_stride, hipStream_t s);
 
-// bf16 3x3 implicit-GEMM convolution, 256x128x64 tiles, LDS-DMA double buffering (conv_igemm.hip)
+// bf16 3x3 implicit-GEMM convolution on halo tiles (conv_igemm.hip)
 int lxo_launch_conv_igemm(const GemmNT& p, hipStream_t s);
 
 // bf16 dense NT GEMM (plain product) with LDS-DMA staging (gemm_nt_dma.hip); -2 if the call does not qualify

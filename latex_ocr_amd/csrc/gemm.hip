@@ -704,8 +704,11 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
     if (p.I <= 0 || p.J <= 0 || p.M <= 0) return 0;
     if (!p.atomic && p.nsplit != 1) return -2;
     if (dt == LXO_F32) {
-        if (p.conv) return launch_tn<float, true, float, float>(p, s);
-        return launch_tn<float, false, float, float>(p, s);
+        // f32 is the parity mode: ONE row range per output tile, so no two workgroups add into the same element and the sum over the rows
+        // runs in the same order in every run (bit-reproducible gradients); the bf16 kernels keep their split ranges + f32 atomics
+        GemmTN q = p; q.nsplit = 1;
+        if (q.conv) return launch_tn<float, true, float, float>(q, s);
+        return launch_tn<float, false, float, float>(q, s);
     }
     if (p.conv) {
         if (a_f32 || b_f32) return -3;

@@ -269,7 +269,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
 int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, const float* ntok_dev, hipStream_t st) {
     HIPRC(hipMemsetAsync(P.ws<float>(ws, W_LOSS), 0, 64, st));
     RC(lxo_k_ce_loss(P.s.dtype, P.ws<float>(ws, W_LOGITS), formula, lengths, P.ws<void>(ws, W_DLOGITS), P.ws<float>(ws, W_LOSS),
-                     inv_ntok, ntok_dev, P.s.B, P.s.T, P.s.V, P.Vp, st));
+                     inv_ntok, ntok_dev, P.s.B, P.s.T, P.s.V, P.Vp, P.det_scratch(ws), st));
     return 0;
 }
 
@@ -284,6 +284,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     float* dcc = P.ws<float>(ws, W_DCC);
     float* gates = P.ws<float>(ws, W_GATES); float* atth = P.ws<float>(ws, W_ATTH); float* alpha = P.ws<float>(ws, W_ALPHA);
     const void* dlog = P.ws<void>(ws, W_DLOGITS);
+    const DetScratch det = P.det_scratch(ws);      // f32 parity mode: ordered reductions (no float atomics); null in bf16 mode
 
     // the same conditions as in lxo_impl_decoder_train_fwd: the fused step kernels ran (and left the bf16 mirrors of the record)
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
@@ -331,7 +332,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         a.U = U; a.O = O; a.zx_row = -1;
         for (int t = t_last; t >= 0; --t) {
             const int nr = active ? active[t] : B;
-            const int nchb = P.attn_chunks(nr);
+            const int nchb = P.det() ? 1 : P.attn_chunks(nr);      // parity mode: one chunk per sample = one writer per d_att_h element
             a.M = nr;
             const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
             float* g_t = gall + (size_t)t * B * O;
@@ -380,7 +381,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             if (hb <= 0) continue;
             // rows that also ran step t+1 receive its carries; the others end here (their later steps were skipped)
             const int crows = (t == T - 1) ? 0 : (active ? active[t + 1] : hb);
-            const int nchb = P.attn_chunks(hb);
+            const int nchb = P.det() ? 1 : P.attn_chunks(hb);
             hipStream_t sh = h ? g_side : st;
             const size_t r0 = (size_t)h * hb;
             float* sb1 = P.ws<float>(ws, W_S_B1) + r0 * (O / 128) * P.HC;
@@ -434,7 +435,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(tn(P, false, true, P.ws<void>(ws, W_EMB_IN), P.Dp, dz, 4 * U, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st)); // dK rows 0..D
     RC(tn(P, true, true, rec, P.REC, dz, 4 * U, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st)); // dK rows D..
     }
-    RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, st));
+    RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, det, st));
     // embeddings
     float* demb = P.ws<float>(ws, W_DEMB);
     if (fused) {   // d_emb = d_z K[0:D]^T over all T*B rows: a tall GEMM on the step kernel (505 workgroups; the bf16 mirror of d_z halves its bytes)
@@ -445,7 +446,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_launch_rstep(P.s.dtype, P.bf, e, st));
     } else
     RC(nt(P, true, true, true, dz, 4 * U, P.pk(wp, K_LSTM), P.ldK, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
-    RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, st));
+    RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, P.det() ? 1 : 0, st));
     // ---- initial states ----
     float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
     const int W3 = 2 * U + O;
@@ -453,9 +454,9 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, st));
     RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, st));
     RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, st));
-    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, st));
-    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, st));
-    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, st));
+    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, det, st));
+    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, det, st));
+    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, det, st));
     const char* wi = (const char*)P.pk(wp, K_INIT);
     if (fused_steps(P)) {
         RC(rs_dense(P, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, false, false, st));
@@ -472,7 +473,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         // one batched GEMM contracts both products, adds the mean gradient and applies conv6's ReLU mask + bias-gradient sum
         // in its epilogue (dimg.hip): region "d_img" receives d_y6 in the compute dtype, lxo_encoder_bwd skips its mask pass
         RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
-                          T, B, P.R, P.Rp, E, st));
+                          T, B, P.R, P.Rp, E, det, st));
         DimgArgs a; memset(&a, 0, sizeof(a));
         a.alpha = alpha; a.ld_alpha = (long long)B * P.Rp; a.Rp = P.Rp;
         a.dctx = dhc + U; a.ld_dctx = (long long)B * P.HC; a.HC = P.HC;
@@ -490,7 +491,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         }
         RC(lxo_k_add_mean_grad(dimg, dmean, B, P.R, C, st));
         RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
-                          T, B, P.R, P.Rp, E, st));
+                          T, B, P.R, P.Rp, E, det, st));
         RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     }
     RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, st));

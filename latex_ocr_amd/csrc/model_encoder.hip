@@ -3,6 +3,7 @@
 #include "impl.h"
 #include "gemm.h"
 #include "encoder_kernels.h"
+#include "decoder_kernels.h"
 #include "api_util.h"
 #include "timing.h"
 
@@ -106,7 +107,7 @@ static int conv_fwd_pool(const Plan& P, const void* in, const void* wpk, const f
 // dgrad: d_in[b,y,x,ci] = sum d_out[b,y+a-padd,x+b-padd,co] * Wd[ci][(a,b,co)], optional ReLU mask of the
 // producing layer's activation (relu_ref, same shape as d_in) and its bias gradient (colsum)
 static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din, int Hout, int Wout, int Cout,
-                      int Hin, int Win, int Cin, bool valid, const void* relu_ref, float* colsum, hipStream_t st) {
+                      int Hin, int Win, int Cin, bool valid, const void* relu_ref, float* colsum, DetScratch det, hipStream_t st) {
     GemmNT g; memset(&g, 0, sizeof(g));
     g.A = dout; g.Bp = wd; g.C = din;
     g.conv = 1; g.H = Hout; g.W = Wout; g.Cin = Cout;
@@ -114,10 +115,13 @@ static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din
     g.M = P.s.B * Hin * Win; g.N = Cin; g.K = 9 * Cout;
     g.lda = Cout; g.ldb = 9 * Cout; g.ldc = Cin;
     g.act = 0; g.alpha = 1.f; g.addend_rows = 1;
-    g.relu_ref = relu_ref; g.ldr = Cin; g.colsum = colsum;
+    g.relu_ref = relu_ref; g.ldr = Cin; g.colsum = P.det() ? nullptr : colsum;
     // algorithmic FLOPs of a data gradient = those of the layer's forward, whatever grid the kernel pads to
     LxoTimed tm("conv_dgrad", conv_name(Cin, Cout, valid), 2.0 * P.s.B * Hout * Wout * 9.0 * Cin * Cout, st);
-    return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
+    RC(lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st));
+    // f32 parity mode: the bias gradient is an ordered column sum of the masked result (the fused sum uses float atomics)
+    if (P.det() && colsum) RC(lxo_k_colsum((const float*)din, Cin, colsum, g.M, Cin, det, st));
+    return 0;
 }
 // wgrad: dW[(kh,kw,ci)][co] += sum_m in[m shifted][ci] * d_out[m][co]
 static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw, int H, int W, int Cin, int Cout,
@@ -205,6 +209,14 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
     void* const G[3] = {P.ws<void>(ws, W_G0), P.ws<void>(ws, W_G1), P.ws<void>(ws, W_G2)};
     const int* XB = P.cnn ? XC : XV; const int* YB = P.cnn ? YC : YV;
     auto gw = [&](int pid) { return grads + P.poff[pid]; };
+    const DetScratch det = P.det_scratch(ws);
+    // f32 parity mode: the kernels that route / mask a gradient tensor do not sum the bias gradient on the way (float atomics);
+    // an ordered column sum over the tensor they wrote follows (rows x C floats, contiguous)
+    auto dbp = [&](int pid) -> float* { return P.det() ? nullptr : gw(pid); };
+    auto dbsum = [&](const void* x, long long rows, int Cc, int pid) -> int {
+        if (!P.det()) return 0;
+        return lxo_k_colsum((const float*)x, Cc, gw(pid), rows, Cc, det, st);
+    };
     hipStream_t side = g_enc_side;
     bool pending[3] = {false, false, false};
     // main is about to WRITE buffer i: wait for the weight gradient that still reads it
@@ -234,21 +246,23 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
                 const void* dy6 = P.ws<void>(ws, W_DIMG);
                 RC(wgrad(P.ws<void>(ws, W_P5), XB[6], gw(P_CONV6_W), P.H6, P.W5, C, C, true, dy6));
                 RC(acquire(YB[6]));
-                RC(conv_dgrad(P, dy6, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, st));
+                RC(conv_dgrad(P, dy6, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, det, st));
                 break;
             }
             RC(acquire(XB[6]));
-            RC(lxo_k_mask_convert(dt, P.ws<float>(ws, W_DIMG), P.ws<void>(ws, W_Y6), X, gw(P_CONV6_B), (long long)B * P.R, C, st));
+            RC(lxo_k_mask_convert(dt, P.ws<float>(ws, W_DIMG), P.ws<void>(ws, W_Y6), X, dbp(P_CONV6_B), (long long)B * P.R, C, st));
+            RC(dbsum(X, (long long)B * P.R, C, P_CONV6_B));
             RC(wgrad(P.ws<void>(ws, W_P5), XB[6], gw(P_CONV6_W), P.H6, P.W5, C, C, true));
             RC(acquire(YB[6]));
-            RC(conv_dgrad(P, X, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, st));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, det, st));
             break;
         case 5:   // d_y5 = route(d_p5) -> X ; wgrad5 ; d_p4 = dgrad5 -> Y
             RC(acquire(XB[5]));
             if (P.cnn) {
                 // strided conv backward: db = colsum(d_p5), dW = cols^T d_p5, d_cols = d_p5 W^T, d_y5 = col2im(d_cols) * (y5 > 0) -> X
                 const int M = B * P.H6 * P.W5;
-                RC(lxo_k_colsum_ct(dt, Yup, gw(P_CONVS_B), M, C, st));
+                if (P.det()) RC(dbsum(Yup, M, C, P_CONVS_B));
+                else RC(lxo_k_colsum_ct(dt, Yup, gw(P_CONVS_B), M, C, st));
                 GemmTN t; memset(&t, 0, sizeof(t));
                 t.A = P.ws<void>(ws, W_COLS); t.B = Yup; t.C = gw(P_CONVS_W); t.M = M; t.I = 8 * C; t.J = C;
                 t.lda = 8 * C; t.ldb = C; t.ldc = C;
@@ -259,44 +273,48 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
                 g.A = Yup; g.Bp = P.pk(wp, K_CONVS_D); g.C = P.ws<void>(ws, W_COLS);
                 g.M = M; g.N = 8 * C; g.K = C; g.lda = C; g.ldb = C; g.ldc = 8 * C; g.alpha = 1.f; g.addend_rows = 1;
                 RC(lxo_launch_gemm_nt(dt, 0, 0, 0, g, st));
-                RC(lxo_k_col2im_s2_relu(dt, P.ws<void>(ws, W_COLS), P.ws<void>(ws, W_Y5), X, gw(P_CONV5_B), B, P.H4, P.W2, P.H6, P.W5, C, st));
+                RC(lxo_k_col2im_s2_relu(dt, P.ws<void>(ws, W_COLS), P.ws<void>(ws, W_Y5), X, dbp(P_CONV5_B), B, P.H4, P.W2, P.H6, P.W5, C, st));
+                RC(dbsum(X, (long long)B * P.H4 * P.W2, C, P_CONV5_B));
                 // conv5 at H2 x W2 on the un-pooled y4: d_y4 = dgrad5 * (y4 > 0) -> Y (+ db4)
                 RC(wgrad(P.ws<void>(ws, W_Y4), XB[5], gw(P_CONV5_W), P.H4, P.W2, 256, C, false));
                 RC(acquire(YB[5]));
-                RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), st));
+                RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), det, st));
                 break;
             }
             if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
-            else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), Yup, X, dbp(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            RC(dbsum(X, (long long)B * P.H4 * P.W2, C, P_CONV5_B));
             RC(wgrad(P.ws<void>(ws, W_P4), XB[5], gw(P_CONV5_W), P.H4, P.W2, 256, C, false));
             RC(acquire(YB[5]));
-            RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, st));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, det, st));
             break;
         case 4:   // d_y4 = route(d_p4) -> X (cnn: already there, masked) ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> Y (+ db3)
             if (!P.cnn) {
                 RC(acquire(XB[4]));
                 if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
-                else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
+                else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), Yup, X, dbp(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
+                RC(dbsum(X, (long long)B * P.H2 * P.W2, 256, P_CONV4_B));
             }
             RC(wgrad(P.ws<void>(ws, W_Y3), XB[4], gw(P_CONV4_W), P.H2, P.W2, 256, 256, false));
             RC(acquire(YB[4]));
-            RC(conv_dgrad(P, X, P.pk(wp, K_CONV4_D), Y, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), st));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV4_D), Y, P.H2, P.W2, 256, P.H2, P.W2, 256, false, P.ws<void>(ws, W_Y3), gw(P_CONV3_B), det, st));
             break;
         case 3:   // d_y3 = Y[4] (no pool) ; wgrad3 ; d_p2 = dgrad3 -> Y
             RC(wgrad(P.ws<void>(ws, W_P2), XB[3], gw(P_CONV3_W), P.H2, P.W2, 128, 256, false));
             RC(acquire(YB[3]));
-            RC(conv_dgrad(P, X, P.pk(wp, K_CONV3_D), Y, P.H2, P.W2, 256, P.H2, P.W2, 128, false, nullptr, nullptr, st));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV3_D), Y, P.H2, P.W2, 256, P.H2, P.W2, 128, false, nullptr, nullptr, det, st));
             break;
         case 2:   // d_y2 = route(d_p2) -> X ; wgrad2 ; d_p1 = dgrad2 -> Y
             RC(acquire(XB[2]));
             if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
-            else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), Yup, X, dbp(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            RC(dbsum(X, (long long)B * P.H1 * P.W1, 128, P_CONV2_B));
             RC(wgrad(P.ws<void>(ws, W_P1), XB[2], gw(P_CONV2_W), P.H1, P.W1, 64, 128, false));
             RC(acquire(YB[2]));
-            RC(conv_dgrad(P, X, P.pk(wp, K_CONV2_D), Y, P.H1, P.W1, 128, P.H1, P.W1, 64, false, nullptr, nullptr, st));
+            RC(conv_dgrad(P, X, P.pk(wp, K_CONV2_D), Y, P.H1, P.W1, 128, P.H1, P.W1, 64, false, nullptr, nullptr, det, st));
             break;
         case 1:   // d_p1 = Y[2] ; recompute conv1, route through pool+ReLU, dW1, db1
-            RC(lxo_k_conv1_pool_bwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], G[YB[2]], gw(P_CONV1_W), gw(P_CONV1_B), B, P.s.H, P.s.W, st));
+            RC(lxo_k_conv1_pool_bwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], G[YB[2]], gw(P_CONV1_W), gw(P_CONV1_B), B, P.s.H, P.s.W, det, st));
             break;
         default: return -4;
         }

@@ -166,7 +166,7 @@ int lxo_impl_rowenc_bwd(const Plan& P, const float* prm, const void* wp, void* w
     for (int d = 0; d < 2; ++d) {
         const size_t dz4 = (size_t)d * G.TM * 4 * U, du = (size_t)d * G.TM * U;
         float* gK = grads + P.poff[P_ROWF_K + 2 * d];
-        RC(lxo_k_colsum(dz + dz4, 4 * U, grads + P.poff[P_ROWF_B + 2 * d], (int)G.TM, 4 * U, st));
+        RC(lxo_k_colsum(dz + dz4, 4 * U, grads + P.poff[P_ROWF_B + 2 * d], (long long)G.TM, 4 * U, P.det_scratch(ws), st));
         const void* dzop = bf ? (const void*)(dzb + dz4) : (const void*)(dz + dz4);
         const size_t opsz = bf ? 2 : 4;
         // d_Kx = X^T d_Z over all positions

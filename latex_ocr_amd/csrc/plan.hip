@@ -50,6 +50,7 @@ static const char* kWsNames[W_COUNT] = {
     "cols",
     "rxt", "rzx", "rg", "rc", "rh", "rhb", "rdz", "rdzb", "rdh", "rdcc", "rzero",
     "m2", "m4", "m5",
+    "det_part",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
 
@@ -138,6 +139,11 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_M2] = bf ? BL * H2 * W2 * 128 : 0;
     wb[W_M4] = (bf && !cnn) ? BL * H4 * W2 * 256 : 0;
     wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
+    if (!bf) {        // the largest user: d_beta, one E-vector per (sample, 16 regions) workgroup; column sums use at most 1024 row blocks x 4U columns
+        size_t need = BL * (size_t)((R + 15) / 16) * E * f4;
+        const size_t floor_ = (size_t)1024 * (4 * U > 2048 ? 4 * U : 2048) * f4;
+        wb[W_DET] = need > floor_ ? need : floor_;
+    }
     const int nb = s.beam > 1 ? s.beam : 1;
     const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)
     const size_t TB = (size_t)T * B;
@@ -243,7 +249,7 @@ bool Plan::pool_fused() const {
     static int v = -1;
     if (v < 0) { const char* e = getenv("LXO_POOL_FUSED"); v = (e && atoi(e) == 0) ? 0 : 1; }
     static int halo = -1;                                 // the A/B switches that select the older conv kernels (no fused pool there)
-    if (halo < 0) { const char* a = getenv("LXO_CONV_HALO"); const char* b2 = getenv("LXO_CONV_2WG"); halo = ((a && a[0] == '0') || (b2 && b2[0] == '0')) ? 0 : 1; }
+    if (halo < 0) { const char* b2 = getenv("LXO_CONV_2WG"); halo = (b2 && b2[0] == '0') ? 0 : 1; }
     return bf && v == 1 && halo == 1 && s.C % 128 == 0;
 }
 Drop Plan::drop(int t, int row0) const {

@@ -58,7 +58,7 @@ def test_train_grads_f32_b8_full_size():
 
 def test_train_grads_bf16_b64_full_size():
     """The headline configuration itself: B=64, T up to 101, bf16 storage / f32 accumulate."""
-    _grads_vs_oracle("bf16", 64, 1e-3, 0.98, seed=1234)
+    _grads_vs_oracle("bf16", 64, 1e-3, 0.9999, seed=1234)      # measured on MI355X: loss rel 2e-7, worst gradient cosine 0.99995
 
 
 def test_encoder_only_b32_f32():
@@ -151,7 +151,7 @@ def test_greedy_bf16_early_exit_agreement(end_checkpoint):
     for b, t in bad[:8]:
         top2 = torch.topk(logits[b, t], 2).values
         print("mismatch row %d step %d: hip %d oracle %d, oracle top1-top2 margin %.3e" % (b, t, ids[b, t], ref[b, t], float(top2[0] - top2[1])))
-    assert (ids == ref).mean() >= 0.99
+    assert (ids == ref).mean() >= 0.999        # measured 1.0
 
 
 def test_beam5_f32_ids_and_parents(end_checkpoint):
@@ -194,7 +194,7 @@ def test_trained_checkpoint_loss_f32_and_bf16(end_checkpoint):
 
 def test_beam5_batch64_f32_identical_and_bf16_agreement(end_checkpoint):
     """configs[4] at the shape the bench times: beam 5 on B = 64 images (320 decoder rows): f32 ids + parents identical to the
-    oracle, bf16 agreement on the best hypothesis reported and held to 0.98; greedy bf16 on the same 64 crops with the oracle's
+    oracle, bf16 agreement on the best hypothesis reported and held to 0.999 (measured 1.000); greedy bf16 on the same 64 crops with the oracle's
     top1 - top2 margin printed for every token that differs."""
     _oracle_threads()
     imgs, forms = count_set(64, 77)
@@ -211,7 +211,7 @@ def test_beam5_batch64_f32_identical_and_bf16_agreement(end_checkpoint):
     agree_best = float((b16[:, :n, 0] == rid.numpy()[:, :n, 0]).mean())
     agree_all = float((b16[:, :n] == rid.numpy()[:, :n]).mean())
     print("beam 5, B = 64: %d steps (bf16 %d); bf16 vs oracle agreement: best hypothesis %.4f, all five %.4f" % (rid.shape[1], b16.shape[1], agree_best, agree_all))
-    assert agree_best >= 0.98
+    assert agree_best >= 0.999          # measured 1.000 (all five hypotheses 0.999)
     g16 = e16.greedy_decode(img, V - 1, max_iter=151)
     gref, logits = R.greedy_decode(P, torch.from_numpy(img), V - 1, max_iter=151, return_logits=True)
     gref = gref.numpy()
@@ -221,7 +221,7 @@ def test_beam5_batch64_f32_identical_and_bf16_agreement(end_checkpoint):
         top2 = torch.topk(logits[b, t], 2).values
         print("greedy bf16 mismatch row %d step %d: hip %d oracle %d, oracle top1-top2 margin %.3e" % (b, t, g16[b, t], gref[b, t], float(top2[0] - top2[1])))
     print("greedy bf16, 64 crops at 128x512: agreement %.4f (%d of %d tokens differ)" % (float((g16 == gref).mean()), len(bad), gref.size))
-    assert (g16 == gref).mean() >= 0.99
+    assert (g16 == gref).mean() >= 0.999       # measured 640 of 640 tokens
 
 
 def test_beam5_f32_random_weights_bounded():

@@ -1,0 +1,63 @@
+"""-m gpu: the f32 PARITY mode is reproducible bit for bit ("keep deterministic order in parity mode").
+
+Every reduction of the f32 mode runs in a fixed order: the weight-gradient GEMMs take one row range per output tile, bias
+gradients / d_beta / the loss statistics / conv1's gradients go through per-workgroup slots that are added in slot order
+(ws region "det_part", csrc: DetScratch), the attention backward runs one chunk per sample, the embedding scatter lists its rows
+in slot order -- no float atomics anywhere on the path.  So two runs of the same step on the same inputs agree in every bit:
+loss statistics, all 28 gradients, and a 30-step Adam trajectory (where any rounding difference would be amplified).
+bf16 mode keeps its atomic epilogues (speed) and is NOT held to this."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_common import *  # noqa
+
+
+def _one_pass(V, img, f, l, dims=None):
+    eng = Engine(V, dtype="f32", seed=3, dims=dims)
+    eng.forward(img, f)
+    stats = eng.loss(l, 1.0 / int(l.sum())).cpu().numpy().copy()
+    eng.backward()
+    torch.cuda.synchronize()
+    return stats, eng.grad_dict()
+
+
+@pytest.mark.parametrize("shape", [(12, 64, 256, 120, 5, 24), (5, 50, 150, 50, 3, 9)])
+def test_f32_gradients_bit_identical_run_to_run(shape):
+    n, H, W, V, lo, hi = shape
+    img, f, l = batch(n, H, W, V, lo, hi, seed=11)
+    runs = [_one_pass(V, img, f, l) for _ in range(3)]
+    s0, g0 = runs[0]
+    assert len(g0) == 28
+    for s, g in runs[1:]:
+        assert s.tobytes() == s0.tobytes(), (s, s0)
+        bad = [k for k in g0 if g[k].tobytes() != g0[k].tobytes()]
+        assert not bad, "f32 gradients differ between two runs of the same step: %s" % bad
+
+
+def test_f32_encoder_variants_bit_identical_run_to_run():
+    """the "cnn" encoder (strided conv, col2im) and the optional row-BiLSTM encoder take their own backward kernels"""
+    img, f, l = batch(4, 64, 128, 50, 3, 9, seed=12)
+    for dims in ({"cnn": True}, {"row_bilstm": True}):
+        a = _one_pass(50, img, f, l, dims=dims)
+        b = _one_pass(50, img, f, l, dims=dims)
+        assert a[0].tobytes() == b[0].tobytes()
+        bad = [k for k in a[1] if a[1][k].tobytes() != b[1][k].tobytes()]
+        assert not bad, (dims, bad)
+
+
+def test_f32_adam_trajectory_bit_identical_run_to_run():
+    """30 Adam steps with global-norm clipping (its norm is an ordered sum too): identical loss curves and identical final weights"""
+    V = 50
+    img, f, l = batch(20, 32, 128, V, 5, 12, seed=13)
+    out = []
+    for _ in range(2):
+        eng = Engine(V, dtype="f32", seed=0)
+        eng.set_optimizer("adam")
+        curve = np.array([eng.train_step(img, f, l, 1e-3, clip=5.0) for _ in range(30)], np.float64)
+        out.append((curve, eng.params.detach().cpu().numpy().copy()))
+    assert out[0][0].tobytes() == out[1][0].tobytes(), np.abs(out[0][0] - out[1][0]).max()
+    assert out[0][1].tobytes() == out[1][1].tobytes()
+    assert out[0][0][-1] < out[0][0][0]

@@ -110,7 +110,15 @@ def test_decode_vs_reference_code_bf16_agreement():
     n5 = min(b5.shape[1], w5.shape[1])
     agree5 = float((b5[:, :n5, 0] == w5[:, :n5, 0]).mean())
     print("bf16 vs reference code: greedy agreement %.4f (steps %d vs %d), beam-5 best-hypothesis agreement %.4f" % (agree, ids.shape[1], want.shape[1], agree5))
-    assert agree >= 0.95 and agree5 >= 0.9
+    # every position where bf16 parts from the reference code, with the margin the REFERENCE's own logits leave there: a bf16 flip is only
+    # legitimate where top1 - top2 is within bf16 rounding of the logit
+    wl = REFDEC[tag + "greedy_logits"]
+    for b, t in np.argwhere(ids[:, :n] != want[:, :n])[:12]:
+        top = np.sort(wl[b, t])[::-1]
+        print("greedy mismatch row %d step %d: hip %d reference %d, reference top1-top2 margin %.3e" % (b, t, ids[b, t], want[b, t], float(top[0] - top[1])))
+    for b, t in np.argwhere(b5[:, :n5, 0] != w5[:, :n5, 0])[:12]:
+        print("beam-5 best-hypothesis mismatch row %d step %d: hip %d reference %d" % (b, t, b5[b, t, 0], w5[b, t, 0]))
+    assert agree >= 0.999 and agree5 >= 0.98         # measured on MI355X: 1.0000 and 0.988 (toy weights: near-ties by construction)
 
 
 @pytest.mark.parametrize("V", [11, 50])

@@ -183,7 +183,7 @@ def test_adam_and_clip():
     rng = np.random.default_rng(0)
     n = 1000
     p = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
-    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); sc = np.zeros(4, np.float32)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); sc = np.zeros(2 + 1024, np.float32)      # LXO_GNORM_FLOATS
     p0 = p.copy()
     assert L.lxo_global_norm_scale(n, ptr(g), ctypes.c_float(5.0), ptr(sc), None) == 0
     gn = np.sqrt((g.astype(np.float64) ** 2).sum())

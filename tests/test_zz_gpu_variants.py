@@ -14,6 +14,8 @@ mathematics with different kernels, so they must agree far more tightly than eit
 * forward attention as part + combine (default)  vs  scores kernel + softmax-context kernel without a merge launch
   (LXO_ATT_SPLIT=1): summation order;
 * fused recurrent-step kernels (default)  vs  round 1's split-K kernels (step_kernels = 1);
+* the two-workgroup conv kernel with fused pools (default)  vs  the general halo conv kernel + separate pools (LXO_CONV_2WG=0: the
+  kernel that shapes outside the model's -- Cout % 64 != 0, tensors of 2 GB and more -- run on);
 * the off-by-default stream switches LXO_DUAL_STREAM=1 and LXO_ENC_OVERLAP=1 (both measured slower, kept as A/B paths).
 Odd image sizes exercise the clipped pool windows of both generations."""
 import os, subprocess, sys
@@ -24,10 +26,10 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp, name, env, h, w, b):
+def _run(tmp, name, env, h, w, b, dtype="bf16"):
     out = os.path.join(str(tmp), name + ".npz")
     e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(HERE, "variant_dump.py"), out, str(h), str(w), str(b)], env=e,
+    r = subprocess.run([sys.executable, os.path.join(HERE, "variant_dump.py"), out, str(h), str(w), str(b), dtype], env=e,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     return dict(np.load(out))
@@ -61,6 +63,8 @@ def test_kernel_generations_agree(tmp_path, h, w):
             ("nt_register_staged", {"LXO_GEMM_NT_DMA": "0"}, (1e-5, 0.99999, 1e-2)),
             ("att_scores_then_context", {"LXO_ATT_SPLIT": "1"}, (1e-5, 0.99999, 1e-2)),
             ("split_k_steps", {"LXO_STEP_KERNELS": "1"}, (1e-4, 0.9995, 5e-2)),
+            # the general halo conv kernel (what Cout % 64 != 0 or a tensor of 2 GB and more runs on) for every layer; no fused pools there
+            ("general_halo_conv", {"LXO_CONV_2WG": "0"}, (1e-4, 0.9995, 5e-2)),
             # the two off-by-default stream switches: half-batch chains on two streams (on the split-K step kernels) and the
             # encoder's weight gradients on a second stream (the same kernels, other order of the f32 atomics)
             ("two_half_batch_chains", {"LXO_DUAL_STREAM": "1"}, (1e-4, 0.9995, 5e-2)),
@@ -72,8 +76,19 @@ def test_kernel_generations_agree(tmp_path, h, w):
 
 def test_step_kernel_row_tiles_agree(tmp_path):
     """The fused step kernels with 16-row tiles (default where 32-row tiles would leave CUs idle) vs 32 / 64-row tiles
-    (LXO_RSTEP_MT16=0) at a batch that takes the 16-row path (40 rows): every output element is the same contraction in the same order."""
+    (LXO_RSTEP_MT16=0) at a batch that takes the 16-row path (40 rows).  Every output element of a step kernel is the same
+    contraction in the same order whatever the row tile, so:
+    * in the f32 parity mode -- whose reductions are all ordered (no float atomics) -- the loss statistics
+      and all 28 gradients are BIT-IDENTICAL between the two tilings;
+    * in bf16 mode the step kernels still agree exactly, but the loss sum and several gradients are accumulated with f32 atomics whose
+      order differs from run to run of ONE binary (the round-3 driver run measured 1.06e-6 on the loss of this very pair), so the bars
+      are those of the other pairs (1e-5 ~ 20 ulp of the loss)."""
+    base = _run(tmp_path, "f32_default", {}, 32, 128, 40, "f32")
+    other = _run(tmp_path, "f32_mt32", {"LXO_RSTEP_MT16": "0"}, 32, 128, 40, "f32")
+    assert sorted(base) == sorted(other)
+    diff = [k for k in base if not np.array_equal(base[k], other[k])]
+    assert not diff, "f32 parity mode: 16-row vs 32-row tiles differ in %s" % diff
     base = _run(tmp_path, "default", {}, 32, 128, 40)
     other = _run(tmp_path, "mt32", {"LXO_RSTEP_MT16": "0"}, 32, 128, 40)
-    worst = _compare(base, other, 1e-6, 0.999999, 1e-3)
-    print("16-row vs 32-row step tiles: worst cosine %.8f (%s, max rel %.2e)" % worst)
+    worst = _compare(base, other, 1e-5, 0.99999, 1e-2)
+    print("16-row vs 32-row step tiles: f32 bit-identical; bf16 worst cosine %.8f (%s, max rel %.2e)" % worst)
