@@ -401,7 +401,12 @@ def main():
         if world > 1 or os.environ.get("LXO_FORCE_DIST") == "1":
             import torch.distributed as td
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+            # control plane = a gloo group (the 128-byte RCCL id, host barriers, the final gathers); data plane = RCCL over xGMI through
+            # liblxo's C ABI (lxo_comm_init / lxo_allreduce_bucket); LXO_DP_COMM=torch puts both on a torch.distributed nccl group instead
+            if os.environ.get("LXO_DP_COMM", "abi") == "torch":
+                td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+            else:
+                td.init_process_group(backend="gloo", rank=rank, world_size=world)
             from latex_ocr_amd.dist import DataParallel
             dist = DataParallel(device=dev)
             dist.time_finish = True                              # event pair around the wait for the gradient buckets
@@ -443,7 +448,10 @@ def main():
         dist.all_reduce(mine)
         dp_info = {"per_rank_ms_per_step": [round(float(x), 3) for x in mine[:, 0].tolist()],
                    "exposed_allreduce_ms_per_step": [round(float(x), 3) for x in mine[:, 1].tolist()],
-                   "gradient_dtype": "bf16" if getattr(dist, "grad_dtype", None) is not None else "f32"}
+                   "gradient_dtype": "bf16" if getattr(dist, "grad_dtype", None) is not None else "f32",
+                   # how many ranks the RCCL communicator itself reports (ncclCommCount through lxo_comm_info): proves N ranks met on RCCL
+                   "rccl_ranks_seen": dist.lxo.ranks_seen if getattr(dist, "lxo", None) is not None else None,
+                   "data_plane": "RCCL via the C ABI (lxo_allreduce_bucket)" if getattr(dist, "lxo", None) is not None else "torch.distributed (%s)" % td.get_backend()}
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce_max(tt)
         dt = float(tt.item())
@@ -516,6 +524,7 @@ def main():
     if dist is not None:
         import torch.distributed as td
         dist.barrier()                   # ranks > 0 wait for rank 0's extra measurements before tearing down
+        dist.close()
         td.destroy_process_group()
 
 

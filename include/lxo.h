@@ -114,9 +114,11 @@ typedef struct lxo_shape {
      * no_positional != 0 = positional_embeddings false (encoder.py:60-65 skipped) */
     int encoder_cnn;
     int no_positional;
-    /* decoder step decomposition: 0 (default) = full-K workgroups with the cell's point-wise stages fused into the GEMM
-     * epilogues (csrc/rstep.hip: 9 dependent launches per training step pair); 1 = the split-K slab GEMMs + separate
-     * point-wise kernels of round 1 (13 launches; also what the *_active entry points and the side-stream interleave use) */
+    /* decoder step decomposition: 0 (default) = automatic: the teacher-forced recurrence of lxo_decoder_train_fwd as ONE persistent launch
+     * of 8 XCD-local chains (csrc/xdec.hip) where the shape qualifies (bf16, the shipped widths U = O = C = 512, E = 256, B in
+     * {8, 16, 32, 64}, an MI355X), else the fused step kernels; 2 = always the fused step kernels (full-K workgroups with the cell's
+     * point-wise stages in the GEMM epilogues, csrc/rstep.hip: 9 dependent launches per training step pair); 1 = the split-K slab
+     * GEMMs + separate point-wise kernels of round 1 (13 launches; also what the side-stream interleave uses) */
     int step_kernels;
     /* optional row encoder between the CNN and the decoder (north_star's "row-BiLSTM encoder"; ABSENT from the reference, whose
      * encoder.py:4 imports GRUCell / LSTMCell and never uses them -- off by default, outside the parity contract): 1 = every

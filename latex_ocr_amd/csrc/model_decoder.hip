@@ -6,6 +6,7 @@
 #include "gemm.h"
 #include "decoder_kernels.h"
 #include "rstep.h"
+#include "xdec.h"
 #include "dimg.h"
 #include "api_util.h"
 #include "timing.h"
@@ -202,7 +203,7 @@ static bool rstep_k_ok(int K, bool bf) {
     return kq % 32 == 0 && pow2_16(kq / 32);
 }
 static bool fused_steps(const Plan& P) {
-    if (P.s.step_kernels != 0) return false;
+    if (P.s.step_kernels == 1) return false;
     const int ks[6] = {P.XH, P.s.U, P.HC, P.s.O, P.s.E, 4 * P.s.U};
     for (int k : ks) if (!rstep_k_ok(k, P.bf) || !rstep_k_ok(k, false)) return false;     // the f32-operand launches (A converted on load) use 32-k chunks
     return true;
@@ -218,7 +219,7 @@ static int mirror_oh(const Plan& P, void* ws, size_t slot_rows, int rows, hipStr
 // img2seq.py:68-71) and for every gradient, so they are not run.  null = the reference's behaviour: all B rows, all T steps.
 int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, const int* active,
                                hipStream_t st) {
-    const int B = P.s.B, T = P.s.T, U = P.s.U, O = P.s.O, E = P.s.E, D = P.s.D, V = P.s.V;
+    const int B = P.s.B, T = P.s.T, U = P.s.U, O = P.s.O, E = P.s.E, D = P.s.D, V = P.s.V, C = P.s.C;
     RC(attention_prepare(P, prm, wp, ws, 1, st));
     RC(lxo_k_embed_gather(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], formula, P.ws<void>(ws, W_EMB_IN), B, T, D, P.Dp, V, st));
     float* zx = P.ws<float>(ws, W_ZX);
@@ -228,7 +229,27 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
     const int nh = dual ? 2 : 1;
     const bool fused = fused_steps(P) && !dual;
-    if (fused) {
+    bool chain_done = false;
+    if (fused && P.bf && !active && P.s.step_kernels == 0) {
+        // the whole recurrence in one launch: 8 XCD-local chains of B / 8 samples (xdec.hip); -2 = the shape does not qualify
+        RC(mirror_oh(P, ws, 0, B, st));
+        XDecFwd x; memset(&x, 0, sizeof(x));
+        x.Wrt = (const bf16_t*)P.pk(wp, K_LSTM_RT); x.ldrt = P.ldRT;
+        x.Wah = (const bf16_t*)P.pk(wp, K_ATT_H_T); x.ldah = P.ldAHT;
+        x.Wow = (const bf16_t*)P.pk(wp, K_OW_T); x.ldow = P.ldOWT;
+        x.beta = prm + P.poff[P_BETA];
+        x.att_img = P.ws<bf16_t>(ws, W_ATT_IMG); x.img = P.ws<bf16_t>(ws, W_IMG);
+        x.zx = zx; x.rec = rec; x.recb = P.ws<bf16_t>(ws, W_RECB); x.cs = cs;
+        x.gates = P.ws<float>(ws, W_GATES); x.atth = P.ws<float>(ws, W_ATTH); x.alpha = P.ws<float>(ws, W_ALPHA);
+        x.part = P.ws<float>(ws, W_APART); x.sync = P.ws<unsigned>(ws, W_XSYNC);
+        x.T = T; x.B = B; x.R = P.R; x.Rp = P.Rp; x.REC = P.REC; x.RECB = P.RECB;
+        x.dr = P.drop(0, 0);
+        LxoTimed tm("xdec_fwd", "chain", (double)T * B * P.R * (E + C) * P.esz, st);
+        const int rc = lxo_launch_xdec_fwd(x, U, O, C, E, st);
+        if (rc == 0) chain_done = true;
+        else if (rc != -2) return rc < 0 ? rc : -rc;
+    }
+    if (fused && !chain_done) {
         bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         RC(mirror_oh(P, ws, 0, B, st));
         for (int t = 0; t < T; ++t) {

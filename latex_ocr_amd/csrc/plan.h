@@ -56,6 +56,7 @@ enum WsId {
     // d_z (+ mirror), upstream gradient, carried d_c, a zero block
     W_RXT, W_RZX, W_RG, W_RC, W_RH, W_RHB, W_RDZ, W_RDZB, W_RDH, W_RDCC, W_RZERO,
     W_M2, W_M4, W_M5,   // bf16 mode: pool masks of conv2 / conv4 / conv5 (one byte per pooled element; fused conv + pool epilogue)
+    W_XSYNC,            // persistent decoder chain (xdec.hip): per-XCD flag lines, tickets, error word
     W_DET,              // f32 parity mode: slots of per-workgroup partial sums for the ordered (atomic-free) reductions (DetScratch)
     W_COUNT
 };

@@ -50,7 +50,7 @@ static const char* kWsNames[W_COUNT] = {
     "cols",
     "rxt", "rzx", "rg", "rc", "rh", "rhb", "rdz", "rdzb", "rdh", "rdcc", "rzero",
     "m2", "m4", "m5",
-    "det_part",
+    "xdec_sync", "det_part",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
 
@@ -139,6 +139,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_M2] = bf ? BL * H2 * W2 * 128 : 0;
     wb[W_M4] = (bf && !cnn) ? BL * H4 * W2 * 256 : 0;
     wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
+    wb[W_XSYNC] = 4096;
     if (!bf) {        // the largest user: d_beta, one E-vector per (sample, 16 regions) workgroup; column sums use at most 1024 row blocks x 4U columns
         size_t need = BL * (size_t)((R + 15) / 16) * E * f4;
         const size_t floor_ = (size_t)1024 * (4 * U > 2048 ? 4 * U : 2048) * f4;
@@ -148,7 +149,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)
     const size_t TB = (size_t)T * B;
     wb[W_ATT_IMG] = BL * R * E * esz;
-    wb[W_APART] = BK_ * 32 * (C + 2) * f4;
+    wb[W_APART] = BK_ * 32 * (C + 4) * f4;         // chunk partials of the attention forward: at most 32 chunks per row, [max, sum, context] (the persistent chain pads a partial to C + 4)
     wb[W_MEAN] = BL * C * f4;
     wb[W_EMB_IN] = TB * Dp * esz;
     wb[W_ZX] = TB * 4 * U * f4;

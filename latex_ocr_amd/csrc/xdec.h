@@ -1,0 +1,35 @@
+// Persistent, XCD-local decoder chain (xdec.hip): the T teacher-forced steps of AttentionCell.step (attention_cell.py:58-89) in ONE
+// launch -- 8 independent chains (one per XCD, B/8 samples each), workgroups of a chain hand over through their XCD's L2 and
+// meet at a flag-line barrier that costs 0.44 us (tools/xcd_barrier_probe.hip) where a dependent kernel boundary costs 1.5 us.
+#pragma once
+#include "lxo_common.h"
+#include "decoder_kernels.h"
+
+struct XDecFwd {
+    // recurrent weights, bf16, K-contiguous ([out][in]) with the row pitches of the plan; each workgroup keeps its column slice of all
+    // three in REGISTERS for the whole launch
+    const bf16_t* Wrt; int ldrt;      // K_LSTM_RT [4U][XH]: z = [o_prev | h_prev] Wrt^T
+    const bf16_t* Wah; int ldah;      // K_ATT_H_T [E][U]
+    const bf16_t* Wow; int ldow;      // K_OW_T    [O][U + C]
+    const float* beta;                // [E]
+    const bf16_t* att_img;            // [B][R][E]
+    const bf16_t* img;                // [B][R][C]
+    const float* zx;                  // [T][B][4U]: emb_t K[0:D] + b
+    float* rec; bf16_t* recb;         // [(T + 1)][B][REC] f32 record [o | h | h~ | ctx] and its bf16 mirror (pitch RECB); slot 0 = initial state
+    float* cs;                        // [(T + 1)][B][U]
+    float* gates;                     // [T][B][4U] activated gates i, j, f, o
+    float* atth;                      // [T][B][E]
+    float* alpha;                     // [T][B][Rp]
+    float* part;                      // [B][nq][C + 2] chunk partials (max, sum, unnormalised context)
+    unsigned* sync;                   // [8][64] per-XCD {flag line (32 words), ticket line} + [512] error word; zero on entry
+    int T, B, R, Rp, REC, RECB;
+    Drop dr;                          // dropout of h and o (thr == 0: off); dr.t is set per step
+    unsigned long long* dbg;          // measurement aid (null = off): [256 workgroups][T][16] 100 MHz timestamps at the phase boundaries (tools/xdec_stamps.py)
+};
+
+// 0 = launched; -2 = the shape does not qualify (the caller runs the launch-per-step chain instead)
+int lxo_launch_xdec_fwd(const XDecFwd& p, int U, int O, int C, int E, hipStream_t st);
+// measurement aid: the next launches of this host thread stamp their phases into buf (null = off)
+extern "C" int lxo_xdec_debug(unsigned long long* buf);
+// bytes of the `sync` block
+constexpr size_t kXDecSyncBytes = (8 * 64 + 64) * 4;

@@ -1,0 +1,528 @@
+// Persistent, XCD-local decoder chain: the T teacher-forced steps of AttentionCell.step (model/components/attention_cell.py:58-89:
+// LSTM cell -> dropout -> attention context (attention_mechanism.py:46-94) -> o projection) in ONE launch.
+//
+// Why: the launch-per-step chain (rstep.hip + the attention pair) is five dependent launches per step, each paying the 1.5 us kernel
+// boundary plus a fetch of its operands into an empty CU: 39.6 us per step for ~14 us of streaming.  The samples of a
+// batch are independent through the recurrence, workgroup b runs on XCD b % 8, and an XCD's L2 is the point of coherence for its own
+// 32 CUs.  So the batch is cut into 8 chains of NB = B / 8 samples, chain x lives on XCD x, and the workgroups of a chain hand their
+// results over THROUGH THAT L2: plain stores (the L1 is write-through), `s_waitcnt vmcnt(0)`, one flag word per workgroup in a
+// 128-byte line, consumers poll the line and then read with sc1 loads (L1 bypassed).  No agent-scope fence, no atomic, nothing crosses
+// the die.  tools/xcd_barrier_probe.hip (profiles/r04_xcd_barrier_probe.txt): 0.44 us per barrier idle, lost in the noise under a
+// 10 MB-per-XCD stream, zero stale reads -- against 1.5 us for a kernel boundary and 4.1 us for a whole-chip barrier.
+//
+// One workgroup per CU (256 x 512 threads), identity = (XCD id read from the hardware, rank = ticket on the XCD's counter).
+// The recurrent weights never move: workgroup `rank` keeps ITS column slice of K_LSTM_RT (16 units x 4 gates x 1024 k = 128 KB), of
+// the att_h projection (8 columns x 512 k) and of the o projection (16 columns x 1024 k) in REGISTERS for the whole launch -- each of
+// the 8 waves holds the MFMA B-fragments of its eighth of every contraction (88 VGPRs per lane).  Per step, four phases:
+//   P1  z = zx_t + [o | h]_{t-1} K^T  -> gates, c, h, h~         every workgroup: its 16 units, all NB rows      (attention_cell.py:70-72)
+//   P2  att_h = h~ W                                              every workgroup: its 8 columns                  (attention_mechanism.py:79)
+//   P3  scores / online softmax / context of one (sample, chunk)  workgroup = (rank / nq, rank % nq), nq = 32 / NB (attention_mechanism.py:80-94)
+//   P4  merge the chunks, alpha, ctx; o = dropout(tanh([h~ | ctx] o_W))   every workgroup: its 16 columns          (attention_cell.py:82-83)
+// with an XCD barrier after each.  A workgroup whose barrier does not complete within 50 ms (a chain that lost a member: fewer than
+// 32 workgroups of the grid landed on its XCD) flags an error word and stops waiting; the host checks the word after the first use
+// of this path and falls back to the launch-per-step chain (engine.py).
+#include "xdec.h"
+#include "drop.h"
+#include "api_util.h"
+#include <stdlib.h>
+
+#ifdef LXO_HIPSIM
+// tests/hipsim interprets one workgroup after the other: a kernel whose workgroups wait for each other cannot run there
+int lxo_launch_xdec_fwd(const XDecFwd&, int, int, int, int, hipStream_t) { return -2; }
+extern "C" int lxo_xdec_debug(unsigned long long*) { return 0; }
+#else
+
+HIP_DYNAMIC_SHARED(char, xdec_dyn_lds)
+
+namespace {
+constexpr int XU = 512, XO = 512, XC = 512, XE = 256;           // the shipped attn_cell_config (configs/model.json); other sizes take the launch chain
+constexpr int XXH = XO + XU, XHC = XU + XC;
+constexpr int OFF_H = XO, OFF_HT = XO + XU, OFF_CTX = XO + 2 * XU;
+constexpr int XW = 8;                                            // waves per workgroup
+constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
+constexpr int SCMAX = 2048;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB)
+
+typedef __attribute__((ext_vector_type(4))) float v4f;
+LXO_DEV v4f mfma16(u32x4 a, u32x4 b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// the same v_exp_f32 / v_rcp_f32 forms as the bf16 step kernels (rstep.hip)
+LXO_DEV float tanh_x(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.f); }
+LXO_DEV float sigm_x(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+
+// Loads of data ANOTHER workgroup of the chain wrote in the previous phase: buffer loads with sc1 = served by the XCD's L2, never by
+// this CU's L1 (which no other CU's store refreshes).  The compiler counts them like any other load.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+LXO_DEV rsrc_t make_rsrc(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
+LXO_DEV u32x4 l2_load16(rsrc_t r, unsigned byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16); }
+LXO_DEV float l2_load4(rsrc_t r, unsigned byte_off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 16)); }
+
+// Barrier of the 32 workgroups of one XCD.  flags = the XCD's 128-byte flag line; ph = phase number (strictly increasing).
+// Every thread first waits for ITS stores to be acknowledged by the L2; lane-wise poll of the whole line by wave 0.
+LXO_DEV void xbar(unsigned* flags, int rank, unsigned ph, unsigned* err, int* s_dead) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        if (tid == 0) *reinterpret_cast<volatile unsigned*>(flags + rank) = ph;
+        if (!*s_dead) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                const unsigned v = __hip_atomic_load(flags + (tid & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__ballot(v < ph) == 0ull) break;
+                if (wall_clock64() - t0 > 5000000ull) {          // 50 ms of a 100 MHz clock: the chain is broken
+                    if (tid == 0) { *s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 1u; }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// One block of ATT_U rows per wave of the attention chunk: scores from the att_img rows (raw bf16 words in xa), online-softmax update of
+// (m, l, acc) with the img rows (xi).  Rows at or beyond `an` were loaded clamped and contribute nothing.
+template <int ATT_U>
+LXO_DEV void att_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], int base, int an, const float (&ah)[4], const float (&bt)[4],
+                       float& m, float& l, float (&acc)[8], float* sc, int lane) {
+    float pt[ATT_U];
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        const float x0 = __uint_as_float(xa[u][0] << 16), x1 = __uint_as_float(xa[u][0] & 0xffff0000u);
+        const float x2 = __uint_as_float(xa[u][1] << 16), x3 = __uint_as_float(xa[u][1] & 0xffff0000u);
+        float a = tanh_x(x0 + ah[0]) * bt[0];
+        a = fmaf(tanh_x(x1 + ah[1]), bt[1], a);
+        a = fmaf(tanh_x(x2 + ah[2]), bt[2], a);
+        a = fmaf(tanh_x(x3 + ah[3]), bt[3], a);
+        pt[u] = a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+    }
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) if (base + XW * u < an) mn = fmaxf(mn, pt[u]);
+    const float scl = __expf(m - mn);
+    l *= scl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= scl;
+    m = mn;
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        const int r = base + XW * u;
+        const bool ok = r < an;
+        const float pw = ok ? __expf(pt[u] - m) : 0.f;
+        l += pw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[2 * e] = fmaf(pw, __uint_as_float(xi[u][e] << 16), acc[2 * e]);
+            acc[2 * e + 1] = fmaf(pw, __uint_as_float(xi[u][e] & 0xffff0000u), acc[2 * e + 1]);
+        }
+        if (ok && lane == 0) sc[r] = pt[u];
+    }
+}
+// the loads of one block: UNCONDITIONAL (a row index beyond the chunk is clamped to its last row), so that the compiler counts them
+// and a block can stay in flight under the computation of the previous one.  Buffer loads: the row is wave-uniform, so it travels in the
+// SCALAR offset and the per-lane offset is one loop-invariant register -- no address arithmetic on the vector ALU, no 64-bit address pairs.
+template <int ATT_U>
+LXO_DEV void att_load(u32x4 (&xi)[ATT_U], u32x2 (&xa)[ATT_U], rsrc_t rim, rsrc_t rai, int base, int an, int lane) {
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        const int r = max(min(base + XW * u, an - 1), 0);
+        xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rim, lane * 16, r * (XC * 2), 0);
+        xa[u] = __builtin_amdgcn_raw_buffer_load_b64(rai, lane * 8, r * (XE * 2), 0);
+    }
+}
+
+template <int NB, int ATT_U>
+__global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
+    constexpr int NQ = 32 / NB;                                  // attention chunks per sample = workgroups per sample
+    __shared__ float red[XW][8][64];                             // cross-wave partial tiles: [wave][row][column]          16 KB
+    __shared__ float redc[XW][XC];                               // P3: the waves' partial contexts                        16 KB
+    __shared__ __attribute__((aligned(16))) bf16_t actx[16][XC + 8];   // P4: merged contexts as the A tile of the o projection   16.6 KB
+    __shared__ float sc[SCMAX];                                  // raw scores of this workgroup's chunk                   16 KB
+    __shared__ float cst[8][16];                                 // c state of this workgroup's 16 units (lives here for all T steps)
+    __shared__ float stm[NB][NQ], stl[NB][NQ], wgt[NB][NQ], smax[NB], sinv[NB];
+    __shared__ float wred[2 * XW];
+    __shared__ int s_rank, s_dead;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave: known uniform (row arithmetic on the scalar ALU)
+    const int r16 = lane & 15, g4 = lane >> 4;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    unsigned* xsync = p.sync + xcc * 64;
+    unsigned* err = p.sync + 8 * 64;
+    if (tid == 0) { s_dead = 0; s_rank = (int)atomicAdd(xsync + 32, 1u); }
+    for (int i = tid; i < 16 * (XC + 8); i += 512) (&actx[0][0])[i] = 0;     // rows >= NB of the A tile stay zero
+    __syncthreads();
+    const int rank = s_rank;
+    if (rank >= 32) { if (tid == 0) *reinterpret_cast<volatile unsigned*>(err) = 2u; return; }   // more than 32 workgroups on this XCD: not a chain
+    const int B = p.B, T = p.T;
+    const int b0 = (int)xcc * NB;                                // first sample of this chain
+    const int u0 = rank * 16, e0 = rank * 8, o0 = rank * 16;
+
+    // ---- resident weights: this wave's eighth of every contraction, as MFMA B fragments (lane = (column r16, k group g4)) ----
+    // K_LSTM_RT: gate i in registers, gates j, f, o in LDS (96 KB, fragment-shaped: [wave][gate][k-step][lane] x 16 B, read back by the
+    // lane that wrote it) -- 88 resident VGPRs left no room for the attention stream's two row blocks in flight
+    u32x4 wrt0[4], wah[2], wow[4];
+    u32x4* wl = reinterpret_cast<u32x4*>(xdec_dyn_lds) + (wave * 12) * 64 + lane;       // + (gate - 1) * 4 * 64 + ks * 64
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wrt + (long long)(q * XU + u0 + r16) * p.ldrt + wave * 128 + ks * 32 + g4 * 8);
+            if (q == 0) wrt0[ks] = w; else wl[((q - 1) * 4 + ks) * 64] = w;
+        }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wah + (long long)(e0 + (r16 & 7)) * p.ldah + wave * 64 + ks * 32 + g4 * 8);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        wah[ks] = r16 < 8 ? w : z;                               // an 8-column slice in a 16-column tile
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        wow[ks] = *reinterpret_cast<const u32x4*>(p.Wow + (long long)(o0 + r16) * p.ldow + wave * 128 + ks * 32 + g4 * 8);
+    float bt[4];
+    { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + lane * 4); bt[0] = b4[0]; bt[1] = b4[1]; bt[2] = b4[2]; bt[3] = b4[3]; }
+    if (tid < NB * 16) cst[tid >> 4][tid & 15] = p.cs[(long long)(b0 + (tid >> 4)) * XU + u0 + (tid & 15)];
+
+    // attention role of this workgroup
+    const int as = rank / NQ, aq = rank - as * NQ;               // (sample of the chain, chunk)
+    const int ab = b0 + as;
+    const int rows_per = (p.R + NQ - 1) / NQ;
+    const int ar0 = aq * rows_per;
+    const int an = min(p.R, ar0 + rows_per) - ar0;               // may be <= 0 for a trailing chunk
+    const bf16_t* ai = p.att_img + ((long long)ab * p.R + ar0) * XE;
+    const bf16_t* im = p.img + ((long long)ab * p.R + ar0) * XC;
+    float* pout = p.part + ((long long)ab * NQ + aq) * PST;
+    const int arow = min(r16, NB - 1);                           // A-fragment row of this lane (rows >= NB repeat the last one; their products are dropped)
+    Drop dr = p.dr;
+    unsigned ph = 0;
+    // The chunk is walked in blocks of XW * ATT_U rows, two blocks per loop trip (buffers A and B): block i+1 is in flight while block i is
+    // computed, and the FIRST block of the next step is requested before this step's last block is computed -- it lands during P4 / P1 / P2,
+    // so P3 starts on data that is already in registers.  An odd block count is rounded up (the extra block is all clamped rows).
+    const int nblk = an > 0 ? (an + XW * ATT_U - 1) / (XW * ATT_U) : 0;
+    const int nblk2 = (nblk + 1) & ~1;
+    const int anq = an > 0 ? an : 1;                             // an empty trailing chunk still issues (masked) loads: row 0 of the first sample
+    const rsrc_t imq = make_rsrc(an > 0 ? im : p.img, (unsigned)anq * XC * 2u);
+    const rsrc_t aiq = make_rsrc(an > 0 ? ai : p.att_img, (unsigned)anq * XE * 2u);
+    u32x4 xiA[ATT_U], xiB[ATT_U]; u32x2 xaA[ATT_U], xaB[ATT_U];
+    att_load<ATT_U>(xiA, xaA, imq, aiq, wave, anq, lane);        // step 0 walks forward: its first blocks are blocks 0 and 1
+    att_load<ATT_U>(xiB, xaB, imq, aiq, wave + XW * ATT_U, anq, lane);
+
+    // x-part of the LSTM pre-activation of this thread's epilogue element (threads < NB * 16: row tid >> 4, unit tid & 15), one step ahead
+    float pzn[4];
+    {
+        const int er = min(tid >> 4, NB - 1);
+        const float* zr = p.zx + (long long)(b0 + er) * 4 * XU + u0 + (tid & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pzn[q] = zr[q * XU];
+    }
+    unsigned long long* dbg = p.dbg ? p.dbg + ((long long)(xcc * 32 + rank) * T) * 16 : nullptr;
+#define XSTAMP(i) do { if (dbg && tid == 0) dbg[t * 16 + (i)] = wall_clock64(); } while (0)
+    for (int t = 0; t < T; ++t) {
+        dr.t = t;
+        XSTAMP(0);
+        const long long sp = (long long)t * B, sn = (long long)(t + 1) * B;       // row blocks of the previous / this state
+        // =========================== P1: LSTM cell ===========================
+        {
+            const rsrc_t rp = make_rsrc(p.recb + sp * p.RECB, (unsigned)B * p.RECB * 2u);
+            u32x4 a[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rp, (unsigned)(((b0 + arow) * p.RECB + wave * 128 + ks * 32 + g4 * 8) * 2));
+            // the x-part of this thread's epilogue element: requested one step ahead (at the start of the previous step's P3) -- zx_t was
+            // written before the launch and comes from HBM, 2 us away; asked for here it was the critical path of the phase
+            float pz[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pz[q] = pzn[q];
+            const int erow = tid >> 4, eu = tid & 15;
+            v4f acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); XSTAMP(9); }      // measurement only: when the A operand has arrived
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = mfma16(a[ks], wrt0[ks], acc[0]);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) acc[q] = mfma16(a[ks], wl[((q - 1) * 4 + ks) * 64], acc[q]);
+            }
+            // D layout: column = r16, row = g4 * 4 + i
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (g4 * 4 + i < NB) red[wave][g4 * 4 + i][q * 16 + r16] = acc[q][i];
+            XSTAMP(10);
+            __syncthreads();
+            XSTAMP(11);
+            if (tid < NB * 16) {
+                // TF-1.12 LSTMCell, gate order i, j, f, o, forget_bias 1.0 (attention_cell.py:71)
+                float g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float z = pz[q];
+#pragma unroll
+                    for (int w = 0; w < XW; ++w) z += red[w][erow][q * 16 + eu];
+                    g[q] = (q == 1) ? tanh_x(z) : sigm_x(q == 2 ? z + 1.0f : z);
+                }
+                const float c = g[2] * cst[erow][eu] + g[0] * g[1];
+                const float h = g[3] * tanh_x(c);
+                const int bb = b0 + erow, u = u0 + eu;
+                const float ht = h * drop_scale(dr, 1u, bb, u, XU);          // h~ = dropout(h) (attention_cell.py:72)
+                cst[erow][eu] = c;
+                float* gr = p.gates + (sp + bb) * 4 * XU + u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gr[q * XU] = g[q];
+                p.cs[(sn + bb) * XU + u] = c;
+                float* rr = p.rec + (sn + bb) * p.REC;
+                bf16_t* rb = p.recb + (sn + bb) * p.RECB;
+                rr[OFF_H + u] = h; rr[OFF_HT + u] = ht;
+                rb[OFF_H + u] = f2bf(h); rb[OFF_HT + u] = f2bf(ht);
+            }
+        }
+        XSTAMP(1);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(2);
+        // =========================== P2: att_h = h~ W ===========================
+        const rsrc_t rn = make_rsrc(p.recb + sn * p.RECB, (unsigned)B * p.RECB * 2u);
+        {
+            u32x4 a[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[ks] = l2_load16(rn, (unsigned)(((b0 + arow) * p.RECB + OFF_HT + wave * 64 + ks * 32 + g4 * 8) * 2));
+            v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc = mfma16(a[ks], wah[ks], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (g4 * 4 + i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+            __syncthreads();
+            if (tid < NB * 8) {
+                const int row = tid >> 3, e = tid & 7;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) v += red[w][row][e];
+                p.atth[(sp + b0 + row) * XE + e0 + e] = v;
+            }
+        }
+        XSTAMP(3);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(4);
+        // =========================== P3: attention chunk (scores, online softmax, context) ===========================
+        {
+            {   // next step's x-part (unconditional: the last step re-reads its own)
+                const int er = min(tid >> 4, NB - 1);
+                const float* zr = p.zx + ((long long)min(t + 1, T - 1) * B + b0 + er) * 4 * XU + u0 + (tid & 15);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pzn[q] = zr[q * XU];
+            }
+            const rsrc_t ra = make_rsrc(p.atth + sp * XE, (unsigned)B * XE * 4u);
+            const u32x4 a4 = l2_load16(ra, (unsigned)((ab * XE + lane * 4) * 4));
+            float ah[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ah[j] = __uint_as_float(a4[j]);
+            const int c0 = lane * 8;
+            float m = -3.0e38f, l = 0.f, acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            // blocks walked in alternating directions from step to step (what this step read last is what the next one reads first: L2 reuse)
+            const int rev = t & 1;
+#define XBASE(i, rv) (wave + XW * ATT_U * ((rv) ? nblk2 - 1 - (i) : (i)))
+            // entering: block 0 in A and block 1 in B (requested at the end of the previous step's P3).  Each buffer is refilled right
+            // after its block is computed -- with the block two ahead, or, at the end of the chunk, with the NEXT STEP's first two blocks
+            // (its direction is the other one): they land during P4 / P1 / P2
+            for (int it = 0; it < nblk2; it += 2) {
+                att_block<ATT_U>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, sc, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                att_load<ATT_U>(xiA, xaA, imq, aiq, (it + 2 < nblk2) ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                att_block<ATT_U>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, sc, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                att_load<ATT_U>(xiB, xaB, imq, aiq, (it + 2 < nblk2) ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef XBASE
+            // merge the 8 waves
+            if (lane == 0) wred[wave] = m;
+            __syncthreads();
+            float mc = wred[0];
+#pragma unroll
+            for (int w = 1; w < XW; ++w) mc = fmaxf(mc, wred[w]);
+            const float sw = (l > 0.f) ? __expf(m - mc) : 0.f;
+            if (lane == 0) wred[XW + wave] = l * sw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e] * sw;
+            __syncthreads();
+            if (tid == 0) {
+                float lt = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) lt += wred[XW + w];
+                pout[XC] = mc; pout[XC + 1] = lt;
+            }
+            {
+                float tsum = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) tsum += redc[w][tid];
+                pout[tid] = tsum;
+            }
+        }
+        XSTAMP(5);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(6);
+        // =========================== P4: merge the chunks; alpha; ctx; o projection ===========================
+        {
+            const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * PST, (unsigned)(NB * NQ * PST) * 4u);
+            // the h~ half of the A operand (waves 0..3) and the chunk partials of this thread's 4 channels for its thread group's samples
+            // (four groups of 128 threads split the NB samples): all requested up front, 16 bytes per request
+            u32x4 a[4];
+            if (wave < 4) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rn, (unsigned)(((b0 + arow) * p.RECB + OFF_HT + wave * 128 + ks * 32 + g4 * 8) * 2));
+            }
+            constexpr int SPG = NB >= 4 ? NB / 4 : 1, NG = NB / SPG;      // samples per thread group, groups that have samples
+            const int tg = tid >> 7, c4 = (tid & 127) * 4;
+            constexpr int QG = NQ < 8 ? NQ : 8;                           // chunks requested at a time (8 x 16 bytes in flight per thread; small batches have up to 32 chunks per sample)
+            u32x4 pc[SPG][QG];
+            if (tg < NG) {
+#pragma unroll
+                for (int si = 0; si < SPG; ++si)
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)((((tg * SPG + si) * NQ + q) * PST + c4) * 4));
+            }
+            if (tid < NB * NQ) {
+                const unsigned o = (unsigned)((tid * PST + XC) * 4);
+                (&stm[0][0])[tid] = l2_load4(rpart, o); (&stl[0][0])[tid] = l2_load4(rpart, o + 4);
+            }
+            __syncthreads();
+            if (tid < NB) {
+                float mm = -3.0e38f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) if (stl[tid][q] > 0.f) mm = fmaxf(mm, stm[tid][q]);
+                float ll = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { const float w = stl[tid][q] > 0.f ? __expf(stm[tid][q] - mm) : 0.f; wgt[tid][q] = w; ll += stl[tid][q] * w; }
+                const float inv = 1.0f / ll;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) wgt[tid][q] *= inv;
+                smax[tid] = mm; sinv[tid] = inv;
+            }
+            __syncthreads();
+            // ctx[s][c4 .. c4+3]: A tile of the o projection; the 16 channels this workgroup owns also go to the record
+            if (tg < NG) {
+#pragma unroll
+                for (int si = 0; si < SPG; ++si) {
+                    const int sidx = tg * SPG + si;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q0 = 0; q0 < NQ; q0 += QG) {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) {
+                            const float w = wgt[sidx][q0 + q];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(__uint_as_float(pc[si][q][e]), w, v[e]);
+                        }
+                        if (q0 + QG < NQ) {                       // next group of chunks (compile-time condition: NQ, QG are constants)
+#pragma unroll
+                            for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + q0 + QG + q) * PST + c4) * 4));
+                        }
+                    }
+                    const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(&actx[sidx][c4]) = vb;
+                    if ((c4 >> 4) == rank) {
+                        const f32x4 vf = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(p.rec + (sn + b0 + sidx) * p.REC + OFF_CTX + c4) = vf;
+                        *reinterpret_cast<u32x2*>(p.recb + (sn + b0 + sidx) * p.RECB + OFF_CTX + c4) = vb;
+                    }
+                }
+            }
+            // alpha of this workgroup's chunk (what the reference hands to its visualisation hook, attention_mechanism.py:96-105)
+            {
+                const float mm = smax[as], inv = sinv[as];
+                float* al = p.alpha + (sp + ab) * p.Rp + ar0;
+                for (int r = tid; r < an; r += 512) al[r] = __expf(sc[r] - mm) * inv;
+            }
+            __syncthreads();
+            if (wave >= 4) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const u32x4*>(&actx[r16][(wave - 4) * 128 + ks * 32 + g4 * 8]);
+            }
+            v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = mfma16(a[ks], wow[ks], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (g4 * 4 + i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+            __syncthreads();
+            if (tid < NB * 16) {
+                const int row = tid >> 4, cc = tid & 15;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) v += red[w][row][cc];
+                const int bb = b0 + row, n = o0 + cc;
+                v = tanh_x(v) * drop_scale(dr, 2u, bb, n, XO);            // o = dropout(tanh(.)) (attention_cell.py:82-83)
+                p.rec[(sn + bb) * p.REC + n] = v;
+                p.recb[(sn + bb) * p.RECB + n] = f2bf(v);
+            }
+        }
+        XSTAMP(7);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(8);
+    }
+#undef XSTAMP
+}
+
+template <int NB>
+int launch_nb(const XDecFwd& p, int att_u, hipStream_t st) {
+    constexpr int DYN = XW * 12 * 64 * 16;                        // the LDS-resident part of the LSTM weights: 96 KB
+#define XLAUNCH(U_) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(xdec_fwd_kernel<NB, U_>), hipFuncAttributeMaxDynamicSharedMemorySize, DYN)); attr_done = true; } \
+        hipLaunchKernelGGL((xdec_fwd_kernel<NB, U_>), dim3(256), dim3(512), DYN, st, p); } while (0)
+    switch (att_u) {
+    case 4: XLAUNCH(4); break;
+    case 5: XLAUNCH(5); break;
+    case 6: XLAUNCH(6); break;
+    default: XLAUNCH(7); break;
+    }
+#undef XLAUNCH
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+static thread_local unsigned long long* g_xdbg = nullptr;
+extern "C" int lxo_xdec_debug(unsigned long long* buf) { g_xdbg = buf; return 0; }
+int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream_t st) {
+    XDecFwd p = p0;
+    p.dbg = g_xdbg;
+    static int on = -1;                                          // LXO_XDEC=0: the launch-per-step chain everywhere (A/B runs)
+    if (on < 0) { const char* e = getenv("LXO_XDEC"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on) return -2;
+    if (U != XU || O != XO || C != XC || E != XE) return -2;
+    if (p.B % 8 != 0 || p.B > 64 || p.T < 1) return -2;
+    const int nb = p.B / 8;
+    if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return -2;
+    const int nq = 32 / nb, rows_per = (p.R + nq - 1) / nq;
+    if (rows_per > SCMAX || rows_per < 1) return -2;
+    if ((long long)p.B * p.RECB * 2 >= (1LL << 31) || p.ldrt % 8 || p.ldah % 8 || p.ldow % 8 || p.RECB % 8) return -2;
+    static int dev_ok = -1;                                      // the chain needs 8 XCDs x 32 CUs (MI355X); anything else: launch chain
+    if (dev_ok < 0) {
+        int dev = 0; hipDeviceProp_t pr;
+        dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
+    }
+    if (!dev_ok) return -2;
+    HIPRC(hipMemsetAsync(p.sync, 0, kXDecSyncBytes, st));
+    // rows per wave and block (two blocks in flight).  4: the largest count whose two blocks + the resident weights fit the register file
+    // without spills (5 .. 7 spill 68 .. 208 bytes per lane into the serial phases and lose more there than their fewer padded rows gain:
+    // 23.9 / 28.9 / 28.3 us per step against 22.2, profiles/r04_xdec_stamps_v2.txt).  LXO_XDEC_U = 4 .. 7 forces one (measurement).
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("LXO_XDEC_U"); forced = e ? atoi(e) : 0; }
+    int att_u = 4;
+    if (forced >= 4 && forced <= 7) att_u = forced;
+    switch (nb) {
+    case 1: return launch_nb<1>(p, att_u, st);
+    case 2: return launch_nb<2>(p, att_u, st);
+    case 4: return launch_nb<4>(p, att_u, st);
+    default: return launch_nb<8>(p, att_u, st);
+    }
+}
+#endif

@@ -1,5 +1,9 @@
-"""Data-parallel plumbing over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm;
-"gloo" for the CPU tests).  One process per GPU; samples are independent through encoder,
+"""Data-parallel plumbing.  DATA PLANE on a GPU: RCCL over xGMI through the C ABI of liblxo.so (lxo_comm_init /
+lxo_allreduce_bucket, csrc/comm.hip: ncclAllReduce on a side HIP stream) -- the same entry points a non-PyTorch binding would
+use.  CONTROL PLANE: a torch.distributed process group of any backend (gloo suffices) that carries the
+128-byte RCCL id from rank 0, host barriers and a few host scalars.  On CPU tensors (the gloo tests, bench.py --sim) and where
+two ranks share one GPU (tests/test_gpu_dp2.py: RCCL refuses duplicate devices) the data plane is torch.distributed itself.
+One process per GPU; samples are independent through encoder,
 decoder and loss, so the only exchanges are (1) the global token count that normalises the
 loss (model/img2seq.py:69-71 takes the mean over ALL unmasked tokens of the batch) and (2)
 the gradient sum.  Gradients are all-reduced in buckets on a side HIP stream as soon as
@@ -18,6 +22,7 @@ behaves the same, the reverse direction -- the compute stream waiting for anothe
 stream only RECORDS an event per bucket; a helper thread waits for it on the host and then enqueues the collective on
 the side stream ("host-ordered", the default on a GPU; LXO_DP_HOST_ORDERED=0 restores the stream-side wait).
 """
+import ctypes
 import os
 import queue
 import threading
@@ -25,13 +30,59 @@ import threading
 import torch
 import torch.distributed as td
 
+from . import _abi
+
+
+class LxoComm(object):
+    """RCCL communicator behind the C ABI (include/lxo.h: lxo_comm_*).  The id travels over the control-plane process group."""
+
+    def __init__(self, device, rank, world, lib=None):
+        self.lib = lib if lib is not None else _abi.load()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)                     # ncclCommInitRank binds the communicator to the current device
+        idbuf = ctypes.create_string_buffer(_abi.LXO_COMM_ID_BYTES)
+        if rank == 0:
+            self._ck(self.lib.lxo_comm_unique_id(idbuf), "lxo_comm_unique_id")
+        box = [bytes(idbuf.raw)]
+        if world > 1:
+            td.broadcast_object_list(box, src=0)
+        self.handle = ctypes.c_void_p()
+        self._ck(self.lib.lxo_comm_init(box[0], rank, world, ctypes.byref(self.handle)), "lxo_comm_init")
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._ck(self.lib.lxo_comm_info(self.handle, ctypes.byref(r), ctypes.byref(w)), "lxo_comm_info")
+        assert (r.value, w.value) == (rank, world), (r.value, w.value, rank, world)
+        self.ranks_seen = w.value
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, (self.lib.lxo_comm_last_error() or b"").decode()))
+
+    _DT = {torch.float32: _abi.LXO_F32, torch.bfloat16: _abi.LXO_BF16, torch.int32: _abi.LXO_I32}
+
+    def all_reduce(self, t, stream, ready_event=None):
+        """in-place sum of a contiguous CUDA tensor over ranks, enqueued on `stream` (behind ready_event when given)"""
+        assert t.is_cuda and t.is_contiguous() and t.dtype in self._DT, (t.device, t.dtype)
+        ev = ctypes.c_void_p(ready_event.cuda_event) if ready_event is not None else ctypes.c_void_p(0)
+        self._ck(self.lib.lxo_allreduce_bucket(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), self._DT[t.dtype],
+                                               ctypes.c_void_p(stream.cuda_stream), ev), "lxo_allreduce_bucket")
+
+    def close(self):
+        if self.handle:
+            self.lib.lxo_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
 
 class DataParallel(object):
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device="cuda:0", comm=None):
+        """comm: "abi" = gradient buckets and the token count on RCCL through liblxo's C ABI (default on a GPU; LXO_DP_COMM=torch
+        overrides), "torch" = on the torch.distributed process group (CPU tensors; two ranks sharing one GPU)."""
         self.device = torch.device(device)
         self.world = td.get_world_size()
         self.rank = td.get_rank()
         self.cuda = self.device.type == "cuda"
+        if comm is None:
+            comm = os.environ.get("LXO_DP_COMM", "abi") if self.cuda else "torch"
+        self.lxo = LxoComm(self.device, self.rank, self.world) if (self.cuda and comm == "abi") else None
         self.side = torch.cuda.Stream(self.device) if self.cuda else None
         self._pending = False
         # token-count exchange: its own stream (never queued behind gradient buckets), pinned staging ring
@@ -50,13 +101,21 @@ class DataParallel(object):
             self._thr = threading.Thread(target=self._bucket_worker, name="lxo-dp-buckets", daemon=True)
             self._thr.start()
 
+    def _sum(self, t, stream=None):
+        """in-place sum over ranks on the data plane; `stream` = the stream the collective is enqueued on (RCCL through the ABI)"""
+        if self.lxo is not None:
+            self.lxo.all_reduce(t, stream if stream is not None else torch.cuda.current_stream(self.device))
+        else:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+
     def _reduce(self, seg):
+        st = torch.cuda.current_stream(self.device) if self.cuda else None
         if self.grad_dtype is not None:
             low = seg.to(self.grad_dtype)
-            td.all_reduce(low, op=td.ReduceOp.SUM)
+            self._sum(low, st)
             seg.copy_(low)
         else:
-            td.all_reduce(seg, op=td.ReduceOp.SUM)
+            self._sum(seg, st)
 
     def _bucket_worker(self):
         """Host-ordered buckets: wait (on the host) for the event behind a bucket's gradients, then enqueue its all-reduce on the
@@ -87,6 +146,11 @@ class DataParallel(object):
             self._q.put(None)
             self._thr.join(timeout=10)
             self._q = None
+        if self.lxo is not None:
+            if self.cuda:
+                torch.cuda.synchronize(self.device)
+            self.lxo.close()
+            self.lxo = None
 
     def sum_count_async(self, n_local):
         """-> (device float32 tensor [1] holding the sum of n_local over ranks, event or None).  Asynchronous w.r.t. the
@@ -106,26 +170,43 @@ class DataParallel(object):
             copied = torch.cuda.Event()
             copied.record(self.cnt_stream)
             self._cnt_ev[slot] = copied
-            td.all_reduce(t, op=td.ReduceOp.SUM)
+            self._sum(t, self.cnt_stream)
             ev = torch.cuda.Event()
             ev.record(self.cnt_stream)
         return t, ev
 
+    # ---- control plane: host scalars and small statistics.  With the ABI data plane the process group may be gloo (CPU only), so
+    # these travel through host memory; they are off the step's critical path (end-of-epoch scores, bench.py's gathers) ----
+    def _ctl(self, t, op):
+        if self.lxo is None:
+            td.all_reduce(t, op=op)
+            return t
+        h = t.detach().to("cpu")
+        if td.get_backend() == "nccl":           # a device-only group: reduce a device copy
+            d = h.to(self.device); td.all_reduce(d, op=op); h = d.cpu()
+        else:
+            td.all_reduce(h, op=op)
+        t.copy_(h)
+        return t
+
     def sum_scalar(self, x):
-        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
-        td.all_reduce(t, op=td.ReduceOp.SUM)
-        return float(t.item())
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        return float(self._ctl(t, td.ReduceOp.SUM).item()) if self.lxo is not None else float(self._ctl(t.to(self.device), td.ReduceOp.SUM).item())
 
     def broadcast_scalar(self, x, src=0):
-        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
-        td.broadcast(t, src=src)
-        return float(t.item())
+        box = [float(x)]
+        td.broadcast_object_list(box, src=src)
+        return float(box[0])
 
     def all_reduce(self, t):
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        if self.lxo is not None and t.is_cuda:
+            torch.cuda.current_stream(self.device).synchronize()
+        self._ctl(t, td.ReduceOp.SUM)
 
     def all_reduce_max(self, t):
-        td.all_reduce(t, op=td.ReduceOp.MAX)
+        if self.lxo is not None and t.is_cuda:
+            torch.cuda.current_stream(self.device).synchronize()
+        self._ctl(t, td.ReduceOp.MAX)
 
     def barrier(self):
         td.barrier()

@@ -35,8 +35,10 @@ class Engine(object):
         # each decoder step only for the samples still inside their formula (lxo_decoder_train_*_active); same loss and gradients
         self.skip_padded = (os.environ.get("LXO_SKIP_PADDED", "0") == "1") if skip_padded is None else bool(skip_padded)
         self._active = None
-        # decoder step decomposition (lxo_shape.step_kernels): 0 = fused full-K step kernels, 1 = round 1's split-K slab path
-        self.step_kernels = 1 if os.environ.get("LXO_STEP_KERNELS", "0") == "1" else 0
+        # decoder step decomposition (lxo_shape.step_kernels): 0 = automatic (the persistent XCD-local chain of csrc/xdec.hip where the shape
+        # qualifies, else the fused step kernels), 2 = always the fused step kernels, 1 = round 1's split-K slab path
+        self.step_kernels = int(os.environ.get("LXO_STEP_KERNELS", "0"))
+        self._xdec_checked = False
         self.specs = PP.param_specs(self.n_tok, self.dims)
         self.n_params = PP.n_params(self.n_tok, self.dims)
         probe = self._shape(1, 32, 32, 1)
@@ -195,10 +197,32 @@ class Engine(object):
         if self._active is None:
             self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
                      "decoder_train_fwd")
+            if not self._xdec_checked and self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda":
+                self._check_chain(st)
         else:
             assert self._active.shape == (T,)
             self._ck(self.lib.lxo_decoder_train_fwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
                                                            self._active.ctypes.data_as(ctypes.c_void_p), st), "decoder_train_fwd_active")
+
+    def chain_status(self):
+        """(used, error) of the persistent XCD-local decoder chain (csrc/xdec.hip) in the last lxo_decoder_train_fwd: used = its 8 x 32
+        workgroups took their tickets; error != 0 = a chain did not assemble (a barrier timed out / an XCD got the wrong number of
+        workgroups) and the step's decoder outputs are invalid.  Synchronises the device."""
+        w = self.region("xdec_sync", "i32")[:8 * 64 + 1].cpu().numpy()
+        return bool(w[32:512:64].any()), int(w[512])
+
+    def _check_chain(self, st):
+        """Once per engine, after the first forward that may have run the persistent chain: it relies on how the hardware places a
+        256-workgroup grid (32 per XCD, one per CU).  If it reports an error, switch this engine to the launch-per-step chain for good
+        and redo the decoder forward."""
+        self._xdec_checked = True
+        used, err = self.chain_status()
+        self.chain_used = used and not err
+        if err:
+            self.step_kernels = 2
+            self.shape.step_kernels = 2
+            self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
+                     "decoder_train_fwd")
 
     def _bind_side(self):
         side = ctypes.c_void_p(self.side_stream.cuda_stream) if self.side_stream is not None else ctypes.c_void_p(0)

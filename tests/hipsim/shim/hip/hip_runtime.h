@@ -19,6 +19,7 @@
 #include <cstring>
 #include <functional>
 
+#define LXO_HIPSIM 1      // lets a source opt out of what a one-workgroup-at-a-time interpreter cannot run (csrc/xdec.hip)
 #define __global__
 #define __device__
 #define __host__

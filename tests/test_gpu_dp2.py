@@ -33,8 +33,8 @@ def _worker(rank, port, host_ordered, q):
     from latex_ocr_amd.dist import DataParallel
     from latex_ocr_amd.engine import Engine
     torch.cuda.set_device(0)
-    dp = DataParallel(device="cuda:0")
-    assert dp.host_ordered == bool(host_ordered)
+    dp = DataParallel(device="cuda:0", comm="torch")      # two ranks on ONE GPU: RCCL refuses duplicate devices, so the data plane is the gloo group here
+    assert dp.host_ordered == bool(host_ordered) and dp.lxo is None
     eng = Engine(V, dtype="f32", device="cuda:0", seed=0)
     img, f, l = _data()
     sl = slice(4 * rank, 4 * rank + 4)

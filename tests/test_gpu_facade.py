@@ -64,10 +64,11 @@ def test_train_eval_predict(tmp_path, monkeypatch):
     assert all(os.path.exists(f) for f in files)
 
 
-@pytest.mark.parametrize("host_ordered", ["1", "0"])
-def test_single_rank_rccl_path(host_ordered):
-    """bench.py through torch.distributed (nccl = RCCL) at world size 1: buckets ordered by the helper thread (default) and by stream waits"""
-    env = dict(os.environ, LXO_FORCE_DIST="1", LXO_DP_HOST_ORDERED=host_ordered, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+@pytest.mark.parametrize("host_ordered,comm", [("1", "abi"), ("0", "abi"), ("1", "torch")])
+def test_single_rank_rccl_path(host_ordered, comm):
+    """bench.py's data-parallel path at world size 1 on RCCL: through the C ABI (lxo_comm_init / lxo_allreduce_bucket; the default) with
+    buckets ordered by the helper thread and by stream waits, and through torch.distributed's nccl group (LXO_DP_COMM=torch)"""
+    env = dict(os.environ, LXO_FORCE_DIST="1", LXO_DP_HOST_ORDERED=host_ordered, LXO_DP_COMM=comm, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                                    "--no-cpu-baseline", "--batch", "8", "--height", "32", "--width", "128", "--vocab", "50"],
                                   env=env, cwd=ROOT, timeout=600)
@@ -75,3 +76,4 @@ def test_single_rank_rccl_path(host_ordered):
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert d["data_parallel"]["exposed_allreduce_ms_per_step"][0] is not None
+    assert d["data_parallel"]["rccl_ranks_seen"] == (1 if comm == "abi" else None), d["data_parallel"]

@@ -1,0 +1,98 @@
+"""-m gpu: the persistent XCD-local decoder chain (csrc/xdec.hip: the T teacher-forced steps of AttentionCell.step in ONE launch, 8 chains
+of B / 8 samples, hand-over through each XCD's L2) against the launch-per-step chain it replaces (csrc/rstep.hip + the attention pair,
+lxo_shape.step_kernels = 2), which is itself held to the oracle and to the reference-code fixtures by the other -m gpu tests.
+
+Both compute the same mathematics in bf16 mode (same operand roundings, same transcendental forms); the contraction of a step GEMM is
+split over 8 waves instead of 4, so sums differ in the last f32 bits and a bf16 mirror may round the other way here and there.  Every
+batch size the chain takes (8, 16, 32, 64: one to eight samples per XCD), dropout, and the error word / ticket counters of the chain."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_common import *  # noqa
+
+V = 120
+
+
+def _run(step_kernels, B, H, W, dropout=None, seed=5):
+    img, f, l = batch(B, H, W, V, 5, 24, seed=77 + B)
+    eng = Engine(V, dtype="bf16", seed=seed)
+    eng.step_kernels = step_kernels
+    eng.forward(img, f, dropout=dropout)
+    stats = eng.loss(l, 1.0 / int(l.sum())).cpu().numpy().copy()
+    torch.cuda.synchronize()
+    T = f.shape[1]
+    Bq = img.shape[0]
+    out = {"stats": stats,
+           "logits": eng.region("logits", "f32", (T, Bq, (V + 31) // 32 * 32))[:, :, :V].cpu().numpy().copy(),
+           "rec": eng.region("rec", "f32", (T + 1, Bq, 2048)).cpu().numpy().copy(),
+           "cs": eng.region("cs", "f32", (T + 1, Bq, 512)).cpu().numpy().copy(),
+           "gates": eng.region("gates", "f32", (T, Bq, 2048)).cpu().numpy().copy(),
+           "att_h": eng.region("att_h", "f32", (T, Bq, 256)).cpu().numpy().copy()}
+    R = (-(-H // 8) - 2) * (-(-W // 8) - 2)
+    Rp = (R + 7) // 8 * 8
+    out["alpha"] = eng.region("alpha", "f32", (T, Bq, Rp))[:, :, :R].cpu().numpy().copy()
+    used, err = eng.chain_status()
+    eng.backward()
+    torch.cuda.synchronize()
+    return out, eng.grad_dict(), used, err
+
+
+@pytest.mark.parametrize("B,H,W", [(64, 64, 256), (32, 48, 200), (16, 64, 128), (8, 40, 150)])
+def test_chain_equals_launch_per_step(B, H, W):
+    a, ga, used, err = _run(0, B, H, W)
+    assert used and err == 0, (used, err)                      # the chain ran: 8 x 32 tickets taken, no barrier timed out
+    b, gb, used_b, _ = _run(2, B, H, W)
+    assert not used_b
+    assert a["stats"][1] == b["stats"][1]
+    la, lb = a["stats"][0] / a["stats"][1], b["stats"][0] / b["stats"][1]
+    assert abs(la - lb) <= 2e-5 * abs(lb), (la, lb)
+    worst = {}
+    for k in ("logits", "rec", "cs", "gates", "att_h", "alpha"):
+        d = np.abs(a[k] - b[k]).max() / max(np.abs(b[k]).max(), 1e-30)
+        worst[k] = float(d)
+        # a bf16 mirror that rounds the other way moves a downstream value by ~2^-9 of its operand; states stay within a few of those
+        assert d < 2e-2, (k, d)
+        assert cosine(a[k], b[k]) > 0.99999, (k, cosine(a[k], b[k]))
+    assert np.abs(a["alpha"].sum(-1) - 1.0).max() < 1e-4       # every step's attention weights are a distribution
+    wc = (1.0, None)
+    for k in ga:
+        c = cosine(ga[k], gb[k])
+        if c < wc[0]:
+            wc = (c, k)
+        assert c > 0.9999, (k, c)
+    print("B=%d %dx%d: chain vs launch-per-step: loss %.6f vs %.6f; max rel %s; worst gradient cosine %.7f (%s)" % (
+        B, H, W, la, lb, {k: "%.1e" % v for k, v in worst.items()}, wc[0], wc[1]))
+
+
+def test_chain_with_dropout_equals_launch_per_step():
+    a, ga, used, err = _run(0, 16, 48, 160, dropout=(0.8, 1234))
+    assert used and err == 0
+    b, gb, _, _ = _run(2, 16, 48, 160, dropout=(0.8, 1234))
+    la, lb = a["stats"][0] / a["stats"][1], b["stats"][0] / b["stats"][1]
+    assert abs(la - lb) <= 5e-5 * abs(lb), (la, lb)
+    # the same counter-based masks in both: dropped elements are exact zeros in the same places
+    assert np.array_equal(a["rec"][1:, :, :512] == 0.0, b["rec"][1:, :, :512] == 0.0)
+    for k in ga:
+        assert cosine(ga[k], gb[k]) > 0.9999, (k, cosine(ga[k], gb[k]))
+
+
+def test_chain_vs_oracle_loss_and_greedy_weights():
+    """the chain against the CPU oracle directly (not only against the other kernel chain): loss within the bf16 bar at B = 16"""
+    img, f, l = batch(16, 64, 256, V, 5, 24, seed=3)
+    eng = Engine(V, dtype="bf16", seed=3)
+    P = oracle_params(eng)
+    eng.forward(img, f)
+    n = int(l.sum())
+    stats = eng.loss(l, 1.0 / n).cpu().numpy()
+    used, err = eng.chain_status()
+    assert used and err == 0
+    loss_ref, G, ce, nw = R.train_grads(P, torch.from_numpy(img), torch.from_numpy(f), torch.from_numpy(l))
+    assert abs(stats[0] / stats[1] - float(loss_ref)) / float(loss_ref) < 1e-3
+    eng.backward()
+    torch.cuda.synchronize()
+    got = eng.grad_dict()
+    for k in G:
+        assert cosine(got[k], G[k].numpy()) > 0.999, (k, cosine(got[k], G[k].numpy()))

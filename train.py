@@ -49,7 +49,8 @@ def main(argv=None):
         if use_gpu:
             torch.cuda.set_device(local)
             config.device = "cuda:%d" % local
-        td.init_process_group(backend="nccl" if use_gpu else "gloo")
+        # control plane (the RCCL id, barriers, end-of-epoch scalars) on gloo; the gradient buckets travel on RCCL through liblxo's C ABI
+        td.init_process_group(backend="nccl" if (use_gpu and os.environ.get("LXO_DP_COMM", "abi") == "torch") else "gloo")
         from latex_ocr_amd.dist import DataParallel
         dist = DataParallel(device=config.device if use_gpu else "cpu")
         # steps per epoch under data parallelism = what ShardedBuckets will yield (per shape bucket), not ceil(N / (bs * world))
@@ -65,6 +66,7 @@ def main(argv=None):
     best = model.train(config, train_set, val_set, lr_schedule)
     if dist is not None:
         dist.barrier()
+        dist.close()                     # the helper thread of the host-ordered buckets, the RCCL communicator
         td.destroy_process_group()
     return best
 
