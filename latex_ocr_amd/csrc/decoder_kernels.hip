@@ -606,7 +606,10 @@ __global__ __launch_bounds__(512) void attn_ctx_kernel(const CT* __restrict__ im
 }
 
 // ---- attention backward (per step): d_e and d_att_h in one pass; d_img / d_att_img are deferred ----
-template <typename CT, int KCT, int ATT_U>
+// EXPD (bf16 mode): `att_img` holds E_x = e^{2x} (ws region "att_exp") instead of x.  With E_a = e^{2 att_h} formed once per launch,
+// r = 1 / (1 + E_x E_a) gives tanh(x + a) = 1 - 2r and 1 - tanh^2 = 4 r (1 - r): ONE transcendental (the reciprocal) and three plain
+// operations per element where the x form needs two transcendentals and six -- this kernel is bound by its vector arithmetic.
+template <typename CT, int KCT, int ATT_U, bool EXPD = false>
 __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                            const float* __restrict__ att_h, const float* __restrict__ beta,
                                                            const float* __restrict__ alpha, Slabs dcs, int dcoff, float* __restrict__ dctx_out, int lddc,
@@ -690,6 +693,12 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
         }
     }
     }
+    if constexpr (EXPD) {
+#pragma unroll
+        for (int kc = 0; kc < KCT; ++kc)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ah[kc][j] = __builtin_amdgcn_exp2f(fminf(fmaxf(ah[kc][j] * 2.8853900817779268f, -60.f), 60.f));     // masked lanes hold 0 -> 1: harmless (their accumulators are not stored)
+    }
     const int nit = n > wave ? (n - wave + ATT_W * ATT_U - 1) / (ATT_W * ATT_U) : 0;
     for (int it = 0; it < nit; ++it) {
         const int base = wave + ATT_W * ATT_U * (rev ? nit - 1 - it : it);       // see attn_fwd_part_kernel
@@ -732,8 +741,13 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
                 if (kc < KC && k0 < E) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        if constexpr (EXPD) {
+                            const float rr = __builtin_amdgcn_rcpf(fmaf(x[kc][u][j], ah[kc][j], 1.f));
+                            acc[kc][j] = fmaf(4.f * d, fmaf(-rr, rr, rr), acc[kc][j]);
+                        } else {
                         const float tau = tanh_ct<CT>(x[kc][u][j] + ah[kc][j]);
                         acc[kc][j] = fmaf(d, 1.f - tau * tau, acc[kc][j]);
+                        }
                     }
                 }
             }
@@ -754,6 +768,129 @@ __global__ __launch_bounds__(512) void attn_bwd_part_kernel(const CT* __restrict
 #pragma unroll
         for (int w = 0; w < ATT_W; ++w) t += rede[w][k];
         atomicAdd(&datth[(long long)v * E + k], t);
+    }
+}
+
+// The same for the shipped widths in bf16 mode (E = 256, C = 512, d_ctx as final values): the chunk is walked in blocks of 8 waves x ATT_U
+// rows with TWO blocks in flight -- block i + 1 is requested before block i is computed (the kernel above issues a block, waits for
+// all of it, computes, issues the next: one memory round trip per block with nothing under it: 16.2 us for 85 MB where the forward
+// chain's stream phase moves the same bytes in 11.5).  Loads are buffer loads whose row offset is SCALAR (the row is wave-uniform) and
+// whose per-lane offset is one loop-invariant register; rows beyond the chunk are clamped and masked.
+typedef __amdgpu_buffer_rsrc_t ab_rsrc_t;
+template <int ATT_U>
+LXO_DEV void attb_load(u32x4 (&xi)[ATT_U], u32x2 (&xa)[ATT_U], float (&al)[ATT_U], ab_rsrc_t rim, ab_rsrc_t rai, ab_rsrc_t ral, int base, int n, int lane) {
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        const int r = max(min(base + ATT_W * u, n - 1), 0);
+        xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rim, lane * 16, r * 1024, 0);
+        xa[u] = __builtin_amdgcn_raw_buffer_load_b64(rai, lane * 8, r * 512, 0);
+        al[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ral, 0, r * 4, 0));
+    }
+}
+template <int ATT_U>
+LXO_DEV void attb_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], const float (&al)[ATT_U], int base, int n, const float (&dc)[8],
+                        const float (&ah)[4], float s, float (&acc)[4], float* de_row, int lane) {
+    float pt[ATT_U];
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a = fmaf(__uint_as_float(xi[u][e] << 16), dc[2 * e], a);
+            a = fmaf(__uint_as_float(xi[u][e] & 0xffff0000u), dc[2 * e + 1], a);
+        }
+        pt[u] = a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        const int r = base + ATT_W * u;
+        if (r >= n) continue;                                           // wave-uniform: a clamped row costs its loads, not its arithmetic
+        const float d = al[u] * (pt[u] - s);                            // softmax backward
+        if (lane == 0) de_row[r] = d;
+        const float x0 = __uint_as_float(xa[u][0] << 16), x1 = __uint_as_float(xa[u][0] & 0xffff0000u);
+        const float x2 = __uint_as_float(xa[u][1] << 16), x3 = __uint_as_float(xa[u][1] & 0xffff0000u);
+        const float t0 = tanh_ct<bf16_t>(x0 + ah[0]), t1 = tanh_ct<bf16_t>(x1 + ah[1]), t2 = tanh_ct<bf16_t>(x2 + ah[2]), t3 = tanh_ct<bf16_t>(x3 + ah[3]);
+        acc[0] = fmaf(d, 1.f - t0 * t0, acc[0]); acc[1] = fmaf(d, 1.f - t1 * t1, acc[1]);
+        acc[2] = fmaf(d, 1.f - t2 * t2, acc[2]); acc[3] = fmaf(d, 1.f - t3 * t3, acc[3]);
+    }
+}
+template <int ATT_U>
+__global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __restrict__ att_img, const bf16_t* __restrict__ img,
+                                                             const float* __restrict__ att_h, const float* __restrict__ beta,
+                                                             const float* __restrict__ alpha, const float* __restrict__ dctx, int lddc,
+                                                             const float* __restrict__ ctx, int ldctx,
+                                                             float* __restrict__ de, float* __restrict__ datth,
+                                                             int R, int Rp, int rows_per, int rev) {
+    constexpr int E = 256, C = 512;
+    __shared__ float rede[ATT_W][E];
+    const int ch = blockIdx.x, v = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = ch * rows_per;
+    const int n = min(R, r0 + rows_per) - r0;
+    if (n <= 0) return;                                  // block-uniform
+    const ab_rsrc_t rim = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(img + ((long long)v * R + r0) * C), 0, n * C * 2, 0x00020000);
+    const ab_rsrc_t rai = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(att_img + ((long long)v * R + r0) * E), 0, n * E * 2, 0x00020000);
+    const ab_rsrc_t ral = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(alpha + (long long)v * Rp + r0), 0, n * 4, 0x00020000);
+    const int nblk2 = ((n + ATT_W * ATT_U - 1) / (ATT_W * ATT_U) + 1) & ~1;          // blocks, rounded up to pairs (an extra block is all clamped rows)
+#define ABASE(i) (wave + ATT_W * ATT_U * (rev ? nblk2 - 1 - (i) : (i)))
+    u32x4 xiA[ATT_U], xiB[ATT_U]; u32x2 xaA[ATT_U], xaB[ATT_U]; float alA[ATT_U], alB[ATT_U];
+    attb_load<ATT_U>(xiA, xaA, alA, rim, rai, ral, ABASE(0), n, lane);               // the first two blocks are on their way before anything else is read
+    attb_load<ATT_U>(xiB, xaB, alB, rim, rai, ral, ABASE(1), n, lane);
+    // this lane's 8 channels of d_ctx and ctx, its 4 columns of att_h; every wave forms s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r by itself
+    const int c0 = lane * 8;
+    const float* dp = dctx + (long long)v * lddc + c0;
+    const float* cp = ctx + (long long)v * ldctx + c0;
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dp), d1 = *reinterpret_cast<const f32x4*>(dp + 4);
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(cp), x1 = *reinterpret_cast<const f32x4*>(cp + 4);
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(att_h + (long long)v * E + lane * 4);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + lane * 4);
+    float dc[8], ah[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dc[e] = d0[e]; dc[4 + e] = d1[e]; ah[e] = a4[e]; }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s = fmaf(x0[e], dc[e], fmaf(x1[e], dc[4 + e], s));
+    s = wave_sum(s);
+    float* de_row = de + (long long)v * Rp + r0;
+    for (int it = 0; it + 2 < nblk2; it += 2) {
+        attb_block<ATT_U>(xiA, xaA, alA, ABASE(it), n, dc, ah, s, acc, de_row, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        attb_load<ATT_U>(xiA, xaA, alA, rim, rai, ral, ABASE(it + 2), n, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        attb_block<ATT_U>(xiB, xaB, alB, ABASE(it + 1), n, dc, ah, s, acc, de_row, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        attb_load<ATT_U>(xiB, xaB, alB, rim, rai, ral, ABASE(it + 3), n, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the last pair: nothing left to request
+    attb_block<ATT_U>(xiA, xaA, alA, ABASE(nblk2 - 2), n, dc, ah, s, acc, de_row, lane);
+    attb_block<ATT_U>(xiB, xaB, alB, ABASE(nblk2 - 1), n, dc, ah, s, acc, de_row, lane);
+#undef ABASE
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rede[wave][lane * 4 + j] = acc[j] * b4[j];
+    __syncthreads();
+    if (tid < E) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_W; ++w) t += rede[w][tid];
+        atomicAdd(&datth[(long long)v * E + tid], t);
+    }
+}
+
+// E_x = e^{2x} of the projected features (bf16 -> bf16), once per batch: what the E-domain attention kernels read instead of x.
+// Exponent clamped to 2^+-60 so that E_x E_a stays finite (|x| > 20.8 is saturated tanh anyway).
+__global__ __launch_bounds__(256) void att_exp_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        float v[8];
+        load8(x + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_exp2f(fminf(fmaxf(v[e] * 2.8853900817779268f, -60.f), 60.f));
+        store8(out + i * 8, v);
     }
 }
 
@@ -1420,14 +1557,35 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     DONE;
 }
 // datth must be zero on entry (chunks accumulate with atomics; nch == 1 -- the f32 parity mode -- has one writer per element)
-int lxo_k_attn_bwd(int dt, const void* att_img, const void* img, const float* att_h, const float* beta, const float* alpha,
+int lxo_k_att_exp(const void* att_img, void* att_exp, long long n, hipStream_t st) {
+    if (n % 8) return -2;
+    LAUNCH(att_exp_kernel, grid1(n / 8, 256, 4096), (const bf16_t*)att_img, (bf16_t*)att_exp, n / 8);
+    DONE;
+}
+// att_exp (nullable, bf16 mode only): e^{2 att_img}; when given the kernel works in the E domain (one transcendental per element)
+int lxo_k_attn_bwd(int dt, const void* att_img, const void* att_exp, const void* img, const float* att_h, const float* beta, const float* alpha,
                    Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,
                    int nv, int R, int Rp, int E, int C, int nch, int rev, hipStream_t st) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     dim3 grid(nch, nv);
+    // LXO_ATT_BWD2=1: the variant with two row blocks in flight.  Measured SLOWER (decoder backward 3.42 vs 3.33 ms): the kernel is bound by
+    // its vector arithmetic (~380 issue cycles per row and wave, 10 us per launch), not by exposed latency -- with two workgroups per CU the
+    // other waves already cover the loads -- and 32-row blocks pad a 109-row chunk to 128.  Kept for A/B runs.
+    static int stream2 = -1;
+    if (stream2 < 0) { const char* e = getenv("LXO_ATT_BWD2"); stream2 = (e && e[0] == '1') ? 1 : 0; }
+    if (stream2 && dt == LXO_BF16 && E == 256 && C == 512 && dcs.n == 1 && lddc % 4 == 0 && ldctx % 4 == 0 && (long long)rows_per * 1024 < (1LL << 31)) {
+        const float* dctx = dcs.p + dcoff;
+        if (dctx_out) return -2;                           // (the fused path never asks for the summed copy)
+        hipLaunchKernelGGL((attn_bwd_stream_kernel<4>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, att_h, beta, alpha, dctx, dcs.ld,
+                           ctx, ldctx, de, datth, R, Rp, rows_per, rev);
+        DONE;
+    }
 #define AB_ARGS att_h, beta, alpha, dcs, dcoff, dctx_out, lddc, ctx, ldctx, de, datth, R, Rp, E, C, rows_per, rev
-    if (dt == LXO_BF16) {
+    if (dt == LXO_BF16 && att_exp && E <= 256) {
+        if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 8, true>), grid, dim3(512), 0, st, (const bf16_t*)att_exp, (const bf16_t*)img, AB_ARGS);
+        else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 7, true>), grid, dim3(512), 0, st, (const bf16_t*)att_exp, (const bf16_t*)img, AB_ARGS);
+    } else if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 1, 7>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
         else { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); else hipLaunchKernelGGL((attn_bwd_part_kernel<bf16_t, 4, 7>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AB_ARGS); }
     } else {

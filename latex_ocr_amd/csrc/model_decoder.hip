@@ -221,6 +221,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
                                hipStream_t st) {
     const int B = P.s.B, T = P.s.T, U = P.s.U, O = P.s.O, E = P.s.E, D = P.s.D, V = P.s.V, C = P.s.C;
     RC(attention_prepare(P, prm, wp, ws, 1, st));
+    if (P.att_exp()) RC(lxo_k_att_exp(P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_ATT_EXP), (long long)B * P.R * E, st));     // E_x = e^{2 att_img}: what the recurrence's attention kernels read
     RC(lxo_k_embed_gather(P.s.dtype, prm + P.poff[P_EMB], prm + P.poff[P_START], formula, P.ws<void>(ws, W_EMB_IN), B, T, D, P.Dp, V, st));
     float* zx = P.ws<float>(ws, W_ZX);
     RC(nt(P, false, true, false, P.ws<void>(ws, W_EMB_IN), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, T * B, 4 * U, P.Dp,
@@ -239,6 +240,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
         x.Wow = (const bf16_t*)P.pk(wp, K_OW_T); x.ldow = P.ldOWT;
         x.beta = prm + P.poff[P_BETA];
         x.att_img = P.ws<bf16_t>(ws, W_ATT_IMG); x.img = P.ws<bf16_t>(ws, W_IMG);
+        x.att_exp = P.att_exp() ? P.ws<bf16_t>(ws, W_ATT_EXP) : nullptr;
         x.zx = zx; x.rec = rec; x.recb = P.ws<bf16_t>(ws, W_RECB); x.cs = cs;
         x.gates = P.ws<float>(ws, W_GATES); x.atth = P.ws<float>(ws, W_ATTH); x.alpha = P.ws<float>(ws, W_ALPHA);
         x.part = P.ws<float>(ws, W_APART); x.sync = P.ws<unsigned>(ws, W_XSYNC);
@@ -369,7 +371,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             const Slabs dc1 = {dhc_t, 1, 0, P.HC};
             {
             LxoTimed tm("attn_bwd", "part", (double)nr * P.R * (E + C) * P.esz, st);
-            RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + (size_t)t * B * E, prm + P.poff[P_BETA],
+            RC(lxo_k_attn_bwd(P.s.dtype, att_img, P.att_exp() ? P.ws<void>(ws, W_ATT_EXP) : nullptr, img, atth + (size_t)t * B * E, prm + P.poff[P_BETA],
                               alpha + (size_t)t * B * P.Rp, dc1, U, nullptr, P.HC, rec_cur + P.OFF_CTX, P.REC,
                               de + (size_t)t * B * P.Rp, datth_t, nr, P.R, P.Rp, E, C, nchb, att_alternate() ? (t & 1) : 0, st));
             }
@@ -420,7 +422,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             RC(lxo_k_tanh_bwd(dolog + ((size_t)t * B + r0) * O, O, carry, rec_cur, P.REC, g_t, O, nullptr, 0, dr, crows, hb, O, sh));
             // [d_h~ | d_ctx] = g [o_W_h; o_W_c]^T
             RC(slab(P, g_t, O, P.pk(wp, K_OW), P.ldOW, sb1, hb, P.HC, O, sh));
-            RC(lxo_k_attn_bwd(P.s.dtype, att_img, img, atth + ((size_t)t * B + r0) * E, prm + P.poff[P_BETA],
+            RC(lxo_k_attn_bwd(P.s.dtype, att_img, P.att_exp() ? (const char*)P.ws<void>(ws, W_ATT_EXP) + r0 * P.R * E * P.esz : nullptr, img, atth + ((size_t)t * B + r0) * E, prm + P.poff[P_BETA],
                               alpha + ((size_t)t * B + r0) * P.Rp, view(sb1, O, hb, P.HC), U, dhc_t + U, P.HC, rec_cur + P.OFF_CTX, P.REC,
                               de + ((size_t)t * B + r0) * P.Rp, datth + ((size_t)t * B + r0) * E, hb, P.R, P.Rp, E, C, nchb, 0, sh));
             // d_h += d_att_h W_att_h^T

@@ -56,6 +56,7 @@ enum WsId {
     // d_z (+ mirror), upstream gradient, carried d_c, a zero block
     W_RXT, W_RZX, W_RG, W_RC, W_RH, W_RHB, W_RDZ, W_RDZB, W_RDH, W_RDCC, W_RZERO,
     W_M2, W_M4, W_M5,   // bf16 mode: pool masks of conv2 / conv4 / conv5 (one byte per pooled element; fused conv + pool epilogue)
+    W_ATT_EXP,          // bf16 mode: e^{2 att_img} (bf16), what the E-domain attention kernels of the training step read (att_exp)
     W_XSYNC,            // persistent decoder chain (xdec.hip): per-XCD flag lines, tickets, error word
     W_DET,              // f32 parity mode: slots of per-workgroup partial sums for the ordered (atomic-free) reductions (DetScratch)
     W_COUNT
@@ -100,6 +101,9 @@ struct Plan {
     // f32 mode is the PARITY mode: every reduction runs in a fixed order (no float atomics), so a step is reproducible bit for bit
     // (SURVEY.md Appendix D step 8); bf16 mode keeps the atomic epilogues
     bool det() const { return !bf; }
+    // bf16 training: the attention kernels of the recurrence read E_x = e^{2 att_img} (region att_exp) and form tanh from one reciprocal
+    // per element; LXO_ATT_EXP=0 keeps the x form (A/B)
+    bool att_exp() const;
     DetScratch det_scratch(void* base) const { DetScratch d = {nullptr, 0}; if (det()) { d.p = ws<float>(base, W_DET); d.floats = wbytes[W_DET] / 4; } return d; }   // with the row encoder "d_img" is the gradient w.r.t. ITS output: plain f32
     template <class T> T* ws(void* base, WsId id) const { return reinterpret_cast<T*>(static_cast<char*>(base) + woff[id]); }
     const void* pk(const void* base, PackId id) const { return static_cast<const char*>(base) + koff[id]; }

@@ -50,7 +50,7 @@ static const char* kWsNames[W_COUNT] = {
     "cols",
     "rxt", "rzx", "rg", "rc", "rh", "rhb", "rdz", "rdzb", "rdh", "rdcc", "rzero",
     "m2", "m4", "m5",
-    "xdec_sync", "det_part",
+    "att_exp", "xdec_sync", "det_part",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
 
@@ -139,6 +139,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_M2] = bf ? BL * H2 * W2 * 128 : 0;
     wb[W_M4] = (bf && !cnn) ? BL * H4 * W2 * 256 : 0;
     wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
+    wb[W_ATT_EXP] = bf ? BL * R * E * esz : 0;
     wb[W_XSYNC] = 4096;
     if (!bf) {        // the largest user: d_beta, one E-vector per (sample, 16 regions) workgroup; column sums use at most 1024 row blocks x 4U columns
         size_t need = BL * (size_t)((R + 15) / 16) * E * f4;
@@ -245,6 +246,11 @@ int Plan::validate(char* msg, size_t n) const {
     return 0;
 }
 
+bool Plan::att_exp() const {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LXO_ATT_EXP"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return bf && v == 1 && s.E <= 256 && (long long)s.B * R * s.E % 8 == 0;
+}
 // tf.nn.dropout(., config.dropout) masks of one decoder step (attention_cell.py:72,83)
 bool Plan::pool_fused() const {
     static int v = -1;

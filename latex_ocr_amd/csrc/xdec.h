@@ -13,6 +13,7 @@ struct XDecFwd {
     const bf16_t* Wow; int ldow;      // K_OW_T    [O][U + C]
     const float* beta;                // [E]
     const bf16_t* att_img;            // [B][R][E]
+    const bf16_t* att_exp;            // [B][R][E] e^{2 att_img} (nullable): when given, the scores are formed in the E domain (one reciprocal per element)
     const bf16_t* img;                // [B][R][C]
     const float* zx;                  // [T][B][4U]: emb_t K[0:D] + b
     float* rec; bf16_t* recb;         // [(T + 1)][B][REC] f32 record [o | h | h~ | ctx] and its bf16 mirror (pitch RECB); slot 0 = initial state

@@ -83,7 +83,9 @@ LXO_DEV void xbar(unsigned* flags, int rank, unsigned ph, unsigned* err, int* s_
 
 // One block of ATT_U rows per wave of the attention chunk: scores from the att_img rows (raw bf16 words in xa), online-softmax update of
 // (m, l, acc) with the img rows (xi).  Rows at or beyond `an` were loaded clamped and contribute nothing.
-template <int ATT_U>
+// EXPD: xa holds E_x = e^{2x}, ah holds E_a = e^{2 att_h}, bt holds -2 beta: with r = 1 / (1 + E_x E_a), tanh = 1 - 2r and the score is
+// sum_k beta_k - 2 sum_k beta_k r_k; the constant is the same for every region of the step, so the softmax does not see it and it is dropped.
+template <int ATT_U, bool EXPD>
 LXO_DEV void att_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], int base, int an, const float (&ah)[4], const float (&bt)[4],
                        float& m, float& l, float (&acc)[8], float* sc, int lane) {
     float pt[ATT_U];
@@ -91,10 +93,18 @@ LXO_DEV void att_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], int b
     for (int u = 0; u < ATT_U; ++u) {
         const float x0 = __uint_as_float(xa[u][0] << 16), x1 = __uint_as_float(xa[u][0] & 0xffff0000u);
         const float x2 = __uint_as_float(xa[u][1] << 16), x3 = __uint_as_float(xa[u][1] & 0xffff0000u);
-        float a = tanh_x(x0 + ah[0]) * bt[0];
-        a = fmaf(tanh_x(x1 + ah[1]), bt[1], a);
-        a = fmaf(tanh_x(x2 + ah[2]), bt[2], a);
-        a = fmaf(tanh_x(x3 + ah[3]), bt[3], a);
+        float a;
+        if constexpr (EXPD) {
+            a = __builtin_amdgcn_rcpf(fmaf(x0, ah[0], 1.f)) * bt[0];
+            a = fmaf(__builtin_amdgcn_rcpf(fmaf(x1, ah[1], 1.f)), bt[1], a);
+            a = fmaf(__builtin_amdgcn_rcpf(fmaf(x2, ah[2], 1.f)), bt[2], a);
+            a = fmaf(__builtin_amdgcn_rcpf(fmaf(x3, ah[3], 1.f)), bt[3], a);
+        } else {
+            a = tanh_x(x0 + ah[0]) * bt[0];
+            a = fmaf(tanh_x(x1 + ah[1]), bt[1], a);
+            a = fmaf(tanh_x(x2 + ah[2]), bt[2], a);
+            a = fmaf(tanh_x(x3 + ah[3]), bt[3], a);
+        }
         pt[u] = a;
     }
 #pragma unroll
@@ -137,7 +147,7 @@ LXO_DEV void att_load(u32x4 (&xi)[ATT_U], u32x2 (&xa)[ATT_U], rsrc_t rim, rsrc_t
     }
 }
 
-template <int NB, int ATT_U>
+template <int NB, int ATT_U, bool EXPD>
 __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     constexpr int NQ = 32 / NB;                                  // attention chunks per sample = workgroups per sample
     __shared__ float red[XW][8][64];                             // cross-wave partial tiles: [wave][row][column]          16 KB
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     for (int ks = 0; ks < 4; ++ks)
         wow[ks] = *reinterpret_cast<const u32x4*>(p.Wow + (long long)(o0 + r16) * p.ldow + wave * 128 + ks * 32 + g4 * 8);
     float bt[4];
-    { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + lane * 4); bt[0] = b4[0]; bt[1] = b4[1]; bt[2] = b4[2]; bt[3] = b4[3]; }
+    { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + lane * 4); const float f = EXPD ? -2.f : 1.f; bt[0] = f * b4[0]; bt[1] = f * b4[1]; bt[2] = f * b4[2]; bt[3] = f * b4[3]; }
     if (tid < NB * 16) cst[tid >> 4][tid & 15] = p.cs[(long long)(b0 + (tid >> 4)) * XU + u0 + (tid & 15)];
 
     // attention role of this workgroup
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     const int rows_per = (p.R + NQ - 1) / NQ;
     const int ar0 = aq * rows_per;
     const int an = min(p.R, ar0 + rows_per) - ar0;               // may be <= 0 for a trailing chunk
-    const bf16_t* ai = p.att_img + ((long long)ab * p.R + ar0) * XE;
+    const bf16_t* ai = (EXPD ? p.att_exp : p.att_img) + ((long long)ab * p.R + ar0) * XE;
     const bf16_t* im = p.img + ((long long)ab * p.R + ar0) * XC;
     float* pout = p.part + ((long long)ab * NQ + aq) * PST;
     const int arow = min(r16, NB - 1);                           // A-fragment row of this lane (rows >= NB repeat the last one; their products are dropped)
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     const int nblk2 = (nblk + 1) & ~1;
     const int anq = an > 0 ? an : 1;                             // an empty trailing chunk still issues (masked) loads: row 0 of the first sample
     const rsrc_t imq = make_rsrc(an > 0 ? im : p.img, (unsigned)anq * XC * 2u);
-    const rsrc_t aiq = make_rsrc(an > 0 ? ai : p.att_img, (unsigned)anq * XE * 2u);
+    const rsrc_t aiq = make_rsrc(an > 0 ? ai : (EXPD ? p.att_exp : p.att_img), (unsigned)anq * XE * 2u);
     u32x4 xiA[ATT_U], xiB[ATT_U]; u32x2 xaA[ATT_U], xaB[ATT_U];
     att_load<ATT_U>(xiA, xaA, imq, aiq, wave, anq, lane);        // step 0 walks forward: its first blocks are blocks 0 and 1
     att_load<ATT_U>(xiB, xaB, imq, aiq, wave + XW * ATT_U, anq, lane);
@@ -321,7 +331,10 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             const u32x4 a4 = l2_load16(ra, (unsigned)((ab * XE + lane * 4) * 4));
             float ah[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ah[j] = __uint_as_float(a4[j]);
+            for (int j = 0; j < 4; ++j) {
+                ah[j] = __uint_as_float(a4[j]);
+                if constexpr (EXPD) ah[j] = __builtin_amdgcn_exp2f(fminf(fmaxf(ah[j] * 2.8853900817779268f, -60.f), 60.f));      // E_a
+            }
             const int c0 = lane * 8;
             float m = -3.0e38f, l = 0.f, acc[8];
 #pragma unroll
@@ -333,11 +346,11 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             // after its block is computed -- with the block two ahead, or, at the end of the chunk, with the NEXT STEP's first two blocks
             // (its direction is the other one): they land during P4 / P1 / P2
             for (int it = 0; it < nblk2; it += 2) {
-                att_block<ATT_U>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, sc, lane);
+                att_block<ATT_U, EXPD>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, sc, lane);
                 __builtin_amdgcn_sched_barrier(0);
                 att_load<ATT_U>(xiA, xaA, imq, aiq, (it + 2 < nblk2) ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
                 __builtin_amdgcn_sched_barrier(0);
-                att_block<ATT_U>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, sc, lane);
+                att_block<ATT_U, EXPD>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, sc, lane);
                 __builtin_amdgcn_sched_barrier(0);
                 att_load<ATT_U>(xiB, xaB, imq, aiq, (it + 2 < nblk2) ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
                 __builtin_amdgcn_sched_barrier(0);
@@ -474,16 +487,12 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
 template <int NB>
 int launch_nb(const XDecFwd& p, int att_u, hipStream_t st) {
     constexpr int DYN = XW * 12 * 64 * 16;                        // the LDS-resident part of the LSTM weights: 96 KB
-#define XLAUNCH(U_) do { \
+#define XLAUNCH(U_, X_) do { \
         static bool attr_done = false; \
-        if (!attr_done) { HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(xdec_fwd_kernel<NB, U_>), hipFuncAttributeMaxDynamicSharedMemorySize, DYN)); attr_done = true; } \
-        hipLaunchKernelGGL((xdec_fwd_kernel<NB, U_>), dim3(256), dim3(512), DYN, st, p); } while (0)
-    switch (att_u) {
-    case 4: XLAUNCH(4); break;
-    case 5: XLAUNCH(5); break;
-    case 6: XLAUNCH(6); break;
-    default: XLAUNCH(7); break;
-    }
+        if (!attr_done) { HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(xdec_fwd_kernel<NB, U_, X_>), hipFuncAttributeMaxDynamicSharedMemorySize, DYN)); attr_done = true; } \
+        hipLaunchKernelGGL((xdec_fwd_kernel<NB, U_, X_>), dim3(256), dim3(512), DYN, st, p); } while (0)
+    (void)att_u;
+    if (p.att_exp) XLAUNCH(4, true); else XLAUNCH(4, false);
 #undef XLAUNCH
     return (int)hipGetLastError();
 }

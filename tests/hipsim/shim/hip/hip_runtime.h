@@ -125,6 +125,26 @@ template <class T> inline T __builtin_amdgcn_readfirstlane_sim(T v) {
 // other lanes of the SAME wave have been copied before this lane reads them (the hardware lands a wave's DMA as a unit)
 #define __builtin_amdgcn_s_waitcnt(n) hipsim::wave_sync()
 
+
+// ---- buffer resources + raw buffer loads (csrc: the double-buffered attention streams).  base + soffset + voffset; a request that
+// reaches beyond num_records returns zeros (the hardware's range check) ----
+struct __amdgpu_buffer_rsrc_t { const char* base; long long bytes; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_records, int) {
+    __amdgpu_buffer_rsrc_t r = {static_cast<const char*>(p), (long long)(unsigned)num_records};
+    return r;
+}
+template <class T> inline T hipsim_buffer_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    T v; memset(&v, 0, sizeof(T));
+    const long long o = (long long)(unsigned)voff + (long long)(unsigned)soff;
+    if (o + (long long)sizeof(T) <= r.bytes) memcpy(&v, r.base + o, sizeof(T));
+    return v;
+}
+typedef unsigned hipsim_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hipsim_u32x2 __attribute__((ext_vector_type(2)));
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) hipsim_buffer_load<hipsim_u32x4>(r, voff, soff)
+#define __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux) hipsim_buffer_load<hipsim_u32x2>(r, voff, soff)
+#define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) hipsim_buffer_load<unsigned>(r, voff, soff)
+
 // ---- atomics (single host thread: plain read-modify-write) ----
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

@@ -137,6 +137,24 @@ def test_forward_bf16_within_loss_bar():
     assert abs(st[0] / st[1] - float(GOLD["loss"])) / float(GOLD["loss"]) < 1e-3       # north_star loss bar
 
 
+def test_backward_bf16_default_widths_vs_golden():
+    """bf16 mode at the shipped widths (E = 256, C = 512: what the double-buffered attention backward kernel -- buffer loads with scalar
+    row offsets, two row blocks in flight, rows beyond the 8-region chunk clamped and masked -- is specialised for): every gradient the
+    golden file holds, against the f32 oracle's, under the SIMT interpreter."""
+    S, img, f, l = _run(1)
+    S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), None), "decbwd")
+    S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, None), "encbwd")
+    checked = 0
+    for k, _, _ in S.specs:
+        key = k.replace("/", "__")
+        if key in GOLD.files:
+            g, r = S.grad(k).reshape(-1).astype(np.float64), GOLD[key].reshape(-1).astype(np.float64)
+            c = float(g @ r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-300)
+            assert c > 0.995, (k, c)
+            checked += 1
+    assert checked >= 9
+
+
 def test_greedy_and_beam_f32_vs_golden():
     img = GOLD["img"]
     S = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, max_steps=9)

@@ -64,6 +64,8 @@ def test_kernel_generations_agree(tmp_path, h, w):
             ("att_scores_then_context", {"LXO_ATT_SPLIT": "1"}, (1e-5, 0.99999, 1e-2)),
             ("split_k_steps", {"LXO_STEP_KERNELS": "1"}, (1e-4, 0.9995, 5e-2)),
             ("fused_step_launches", {"LXO_STEP_KERNELS": "2"}, (1e-4, 0.9995, 5e-2)),
+            # attention backward with two row blocks in flight (off by default: measured slower): the same sums in another order
+            ("att_bwd_two_blocks_in_flight", {"LXO_ATT_BWD2": "1"}, (1e-5, 0.99999, 1e-2)),
             # the general halo conv kernel (what Cout % 64 != 0 or a tensor of 2 GB and more runs on) for every layer; no fused pools there
             ("general_halo_conv", {"LXO_CONV_2WG": "0"}, (1e-4, 0.9995, 5e-2)),
             # the two off-by-default stream switches: half-batch chains on two streams (on the split-K step kernels) and the
