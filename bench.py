@@ -34,9 +34,9 @@ HBM_PEAK = 8.0e12                # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s ach
 METRIC = "formula-images/sec training step (batch 64, 128x512)"
 
 
-def cpu_baseline(seconds_budget=15.0):
+def cpu_baseline(seconds_budget=20.0):
     """The oracle restatement of the reference trainer (kind "port": TF-1.12 cannot run here),
-    timed on the host cores on a bounded sample of the same workload: batch 2 of 128x512,
+    timed on the host cores on a bounded sample of the same workload: batch 4 of 128x512 (B = 4 .. 8),
     vocab 500, formula lengths U{30..100}."""
     import torch
     from latex_ocr_amd import synthetic
@@ -49,7 +49,7 @@ def cpu_baseline(seconds_budget=15.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))           # torch intra-op threads actually used (more only adds spin-wait on big hosts)
     torch.set_num_threads(cores)
-    V, B = 500, 2
+    V, B = 500, 4
     imgs, forms = synthetic.make_set(B, 128, 512, V, 30, 101, seed=99)
     img = torch.from_numpy(pad_batch_images(imgs))
     f, l = pad_batch_formulas(forms, V - 2, V - 1)
@@ -173,6 +173,71 @@ def roofline_from_records(recs, family, label, bound, peak, unit):
             "work_per_launch": work / len(sel), "avg_launch_us": round(secs / len(sel) * 1e6, 2),
             "source": "HIP events around each launch inside one real training step (lxo_timing_*)",
             "per_launch": {k: {"n": v[0], "us": round(v[2] / v[0] * 1e6, 2), "rate": round(v[1] / v[2] / scale, 1)} for k, v in sorted(per.items())}}
+
+
+def chain_phases(eng, torch):
+    """Per-phase time of one step of the persistent XCD-local decoder chain (csrc/xdec.hip) from its in-kernel 100 MHz timestamps
+    (lxo_xdec_debug): mean over the 256 workgroups and the steps of one more decoder forward on the bound shape.  None when the
+    chain does not run for this engine."""
+    import ctypes
+    from latex_ocr_amd.engine import _p
+    used, err = eng.chain_status()
+    if not used or err:
+        return None
+    T = int(eng.shape.T)
+    buf = torch.zeros(256 * T * 16, dtype=torch.int64, device=eng.device)
+    eng.lib.lxo_xdec_debug.argtypes = [ctypes.c_void_p]
+    eng.lib.lxo_xdec_debug(ctypes.c_void_p(buf.data_ptr()))
+    try:
+        eng._ck(eng.lib.lxo_decoder_train_fwd(eng.sref(), _p(eng.params), _p(eng.wpack), _p(eng.ws), _p(eng._formula), eng._stream()), "fwd")
+        torch.cuda.synchronize()
+    finally:
+        eng.lib.lxo_xdec_debug(ctypes.c_void_p(0))
+    s = buf.cpu().numpy().reshape(256, T, 16).astype(np.float64) * 0.01            # us
+    d = s[:, 2:, 1:9] - s[:, 2:, 0:8]
+    names = ["P1_lstm", "barrier1", "P2_att_h", "barrier2", "P3_attention_stream", "barrier3", "P4_merge_o", "barrier4"]
+    out = {n: round(float(d[:, :, i].mean()), 3) for i, n in enumerate(names)}
+    out["step_us"] = round(float((s[:, 2:, 8] - s[:, 2:, 0]).mean()), 3)
+    return out
+
+
+def pmc_traffic_inrun(patterns, timeout=200):
+    """HBM traffic per launch of the named kernels, measured NOW: this script re-runs itself for two short passes under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes) and
+    reads the counters back: bytes = 2 x FETCH_SIZE KB (gfx950 correction) + WRITE_SIZE KB.  None if rocprofv3 is not usable."""
+    import shutil, sqlite3, tempfile, glob
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="lxo_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-extras", "--no-secondary"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            dbs = glob.glob(os.path.join(d, "*", "*_results.db")) + glob.glob(os.path.join(d, "*_results.db"))
+            if r.returncode != 0 or not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            for pat in patterns:
+                n, v = db.execute("select count(*), avg(value) from counters_collection where kernel_name like ? and counter_name = ?",
+                                  ("%" + pat + "%", counter)).fetchone()
+                if n and v is not None:
+                    res.setdefault(pat, {"dispatches": n})[counter] = float(v)
+            db.close()
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for pat, v in res.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            out[pat] = {"dispatches": v["dispatches"], "fetch_bytes_per_launch": 2.0 * v["FETCH_SIZE"] * 1024.0, "write_bytes_per_launch": v["WRITE_SIZE"] * 1024.0,
+                        "hbm_bytes_per_launch": 2.0 * v["FETCH_SIZE"] * 1024.0 + v["WRITE_SIZE"] * 1024.0}
+    return out or None
 
 
 def count_set(n, seed, H, W):
@@ -355,6 +420,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline timing only (profiler runs): no instrumented step, no secondary keys")
     ap.add_argument("--no-secondary", action="store_true", help="skip configs[1] / T=151 / decode measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two in-run rocprofv3 --pmc passes (HBM traffic of the roofline kernels)")
     ap.add_argument("--sim", action="store_true", help="TEST ONLY: CPU tensors, gloo, the hipsim build of the kernels, tiny shapes")
     args = ap.parse_args()
     if args.dtype != "bf16" and not args.sim:
@@ -477,21 +543,49 @@ def main():
             roof = roofline_from_records(recs, ("conv_fwd", "conv_dgrad"),
                                          "conv_halo2wg_kernel (bf16 implicit-GEMM 3x3 conv, halo tiles): the 10 conv forward / data-gradient launches of a step (conv2/4/5 forward include their fused max pool; FLOPs count the convolution only)",
                                          "mfma", MFMA_BF16_PEAK, "TFLOP/s")
-            tpath = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
-            if roof is not None and os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = "profiles/r03_conv_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over real training steps (tools/gpu_call.sh traffic), FETCH x2 (gfx950)"
-                except Exception:
-                    pass
+            # HBM traffic measured in this run (two short PMC passes of this same script); the committed file only if rocprofv3 is unusable
+            traffic = None
+            if world == 1 and not args.no_pmc:
+                traffic = pmc_traffic_inrun(["conv_halo2wg_kernel", "conv_wgrad_kernel", "xdec_fwd_kernel", "attn_bwd_part_kernel", "attn_fwd_part_kernel", "rstep_kernel"])
+            if roof is not None:
+                if traffic and "conv_halo2wg_kernel" in traffic:
+                    roof["traffic"] = traffic["conv_halo2wg_kernel"]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over 3 training steps of this script, per launch; FETCH x2 (gfx950)"
+                else:
+                    tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
+                    if os.path.exists(tpath):
+                        try:
+                            tj = json.load(open(tpath))
+                            roof["traffic"] = tj["conv_halo2wg_kernel"]["hbm_bytes_per_launch"]
+                            roof["traffic_source"] = "profiles/r04_traffic.json (rocprofv3 was not usable inside this run): the same two PMC passes, taken earlier in round 4"
+                        except Exception:
+                            pass
+            if traffic:
+                out["pmc_traffic_per_launch"] = traffic
             out["roofline"] = roof
             out["roofline_wgrad"] = roofline_from_records(recs, ("conv_wgrad",), "conv_wgrad_kernel (bf16 3x3 weight gradient, tap reuse): 5 launches of a step",
                                                           "mfma", MFMA_BF16_PEAK, "TFLOP/s")
             out["roofline_attention"] = roofline_from_records(recs, ("attn_fwd",), "attn_fwd_part_kernel + attn_fwd_combine_kernel: one decoder step, B samples, att_img + img streamed once",
                                                               "hbm", HBM_PEAK, "GB/s")
+            if out["roofline_attention"] is None:
+                # the forward recurrence is ONE persistent launch (csrc/xdec.hip): the attention stream is its phase P3, timed by in-kernel stamps
+                ph = chain_phases(eng, torch)
+                chain = [r for r in recs if r[0] == "xdec_fwd"]
+                if ph and chain:
+                    bytes_step = chain[0][2] / T                     # algorithmic bytes of one step: B * R * (E + C) * 2
+                    a = bytes_step / (ph["P3_attention_stream"] * 1e-6)
+                    out["roofline_attention"] = {
+                        "kernel": "xdec_fwd_kernel, phase P3 (attention stream of one decoder step: B samples, att_exp + img streamed once; the other phases of the step are the LSTM / att_h / o-projection GEMMs and four XCD barriers)",
+                        "bound": "hbm", "achieved": round(a / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a / HBM_PEAK, 4),
+                        "traffic": (traffic["xdec_fwd_kernel"]["hbm_bytes_per_launch"] / T) if traffic and "xdec_fwd_kernel" in traffic else None,
+                        "launches": 1, "work_per_launch": bytes_step, "avg_launch_us": ph["P3_attention_stream"],
+                        "chain_us_per_step_by_phase": ph, "chain_ms_per_launch": round(chain[0][3] * 1e3, 4),
+                        "whole_chain_GBps": round(chain[0][2] / chain[0][3] / 1e9, 2),
+                        "source": "in-kernel 100 MHz timestamps (lxo_xdec_debug), mean over 256 workgroups x the steps of one launch; whole-launch time from HIP events (lxo_timing_*); traffic per STEP from the PMC passes of this run"}
             out["roofline_attention_bwd"] = roofline_from_records(recs, ("attn_bwd",), "attn_bwd_part_kernel: one BPTT step, the same two streams",
                                                                   "hbm", HBM_PEAK, "GB/s")
+            if traffic and out.get("roofline_attention_bwd") and "attn_bwd_part_kernel" in traffic:
+                out["roofline_attention_bwd"]["traffic"] = traffic["attn_bwd_part_kernel"]["hbm_bytes_per_launch"]
             out["ms_per_step_by_phase"] = phases
             if world == 1:
                 # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still

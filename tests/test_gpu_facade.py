@@ -70,7 +70,7 @@ def test_single_rank_rccl_path(host_ordered, comm):
     buckets ordered by the helper thread and by stream waits, and through torch.distributed's nccl group (LXO_DP_COMM=torch)"""
     env = dict(os.environ, LXO_FORCE_DIST="1", LXO_DP_HOST_ORDERED=host_ordered, LXO_DP_COMM=comm, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                                   "--no-cpu-baseline", "--batch", "8", "--height", "32", "--width", "128", "--vocab", "50"],
+                                   "--no-cpu-baseline", "--no-pmc", "--batch", "8", "--height", "32", "--width", "128", "--vocab", "50"],
                                   env=env, cwd=ROOT, timeout=600)
     line = [l for l in out.decode().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
