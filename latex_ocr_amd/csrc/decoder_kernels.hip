@@ -1039,8 +1039,11 @@ template <typename CT>
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const int* __restrict__ formula,
                                                      const int* __restrict__ lengths, CT* __restrict__ dlogits,
                                                      float* __restrict__ loss_acc, float* __restrict__ loss_part, float inv_ntok, const float* __restrict__ ntok_dev,
-                                                     int B, int T, int V, int Vp) {
+                                                     const unsigned* __restrict__ chain_err, int B, int T, int V, int Vp) {
     __shared__ float red[8];
+    // the persistent decoder chain (xdec.hip) flags a barrier that timed out: its logits are then garbage -- make the loss say so (NaN)
+    // instead of training on them silently
+    if (chain_err && blockIdx.x == 0 && threadIdx.x == 0 && chain_err[0] != 0u) atomicAdd(&loss_acc[0], __uint_as_float(0x7fc00000u));
     if (ntok_dev) inv_ntok = 1.0f / ntok_dev[0];      // data parallel: the global token count arrives by all-reduce, never through the host
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ce_sum = 0.f, n_sum = 0.f;
@@ -1621,12 +1624,12 @@ int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hi
     DONE;
 }
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
-                  const float* ntok_dev, int B, int T, int V, int Vp, DetScratch det, hipStream_t st) {
+                  const float* ntok_dev, const unsigned* chain_err, int B, int T, int V, int Vp, DetScratch det, hipStream_t st) {
     int g = cdiv(T * B, 4);
     if (g > 512) g = 512;
     float* part = (det.p && det.floats >= 1024) ? det.p : nullptr;      // loss_acc is zero on entry (lxo_impl_ce_loss)
-    if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, part, inv_ntok, ntok_dev, B, T, V, Vp);
-    else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, part, inv_ntok, ntok_dev, B, T, V, Vp);
+    if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, part, inv_ntok, ntok_dev, chain_err, B, T, V, Vp);
+    else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, part, inv_ntok, ntok_dev, chain_err, B, T, V, Vp);
     if (part) return lxo_k_det_reduce(part, g, 2, 2, loss_acc, st);
     DONE;
 }

@@ -251,6 +251,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
         if (rc == 0) chain_done = true;
         else if (rc != -2) return rc < 0 ? rc : -rc;
     }
+    if (P.bf && !chain_done) HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC) + 8 * 64, 0, 4, st));      // no chain in this call: clear its error word (the loss kernel reads it)
     if (fused && !chain_done) {
         bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         RC(mirror_oh(P, ws, 0, B, st));
@@ -292,7 +293,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
 int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, const float* ntok_dev, hipStream_t st) {
     HIPRC(hipMemsetAsync(P.ws<float>(ws, W_LOSS), 0, 64, st));
     RC(lxo_k_ce_loss(P.s.dtype, P.ws<float>(ws, W_LOGITS), formula, lengths, P.ws<void>(ws, W_DLOGITS), P.ws<float>(ws, W_LOSS),
-                     inv_ntok, ntok_dev, P.s.B, P.s.T, P.s.V, P.Vp, P.det_scratch(ws), st));
+                     inv_ntok, ntok_dev, P.bf ? P.ws<unsigned>(ws, W_XSYNC) + 8 * 64 : nullptr, P.s.B, P.s.T, P.s.V, P.Vp, P.det_scratch(ws), st));
     return 0;
 }
 

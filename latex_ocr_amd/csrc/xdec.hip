@@ -18,7 +18,7 @@
 //   P2  att_h = h~ W                                              every workgroup: its 8 columns                  (attention_mechanism.py:79)
 //   P3  scores / online softmax / context of one (sample, chunk)  workgroup = (rank / nq, rank % nq), nq = 32 / NB (attention_mechanism.py:80-94)
 //   P4  merge the chunks, alpha, ctx; o = dropout(tanh([h~ | ctx] o_W))   every workgroup: its 16 columns          (attention_cell.py:82-83)
-// with an XCD barrier after each.  A workgroup whose barrier does not complete within 50 ms (a chain that lost a member: fewer than
+// with an XCD barrier after each.  A workgroup whose barrier does not complete within 200 ms (a chain that lost a member: fewer than
 // 32 workgroups of the grid landed on its XCD) flags an error word and stops waiting; the host checks the word after the first use
 // of this path and falls back to the launch-per-step chain (engine.py).
 #include "xdec.h"
@@ -70,7 +70,7 @@ LXO_DEV void xbar(unsigned* flags, int rank, unsigned ph, unsigned* err, int* s_
             for (;;) {
                 const unsigned v = __hip_atomic_load(flags + (tid & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__ballot(v < ph) == 0ull) break;
-                if (wall_clock64() - t0 > 5000000ull) {          // 50 ms of a 100 MHz clock: the chain is broken
+                if (wall_clock64() - t0 > 20000000ull) {         // 200 ms of a 100 MHz clock: the chain is broken
                     if (tid == 0) { *s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 1u; }
                     break;
                 }

@@ -176,7 +176,7 @@ class Engine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
     # ---------------------------------------------------------------- steps --
-    def forward(self, img, formula, dropout=None, active_rows=None, phase_hook=None):
+    def forward(self, img, formula, dropout=None, active_rows=None, phase_hook=None, before_decoder=None):
         """Encoder + teacher-forced decoder; leaves logits in the workspace.  dropout = (keep_prob, seed)
         applies tf.nn.dropout on h and o (attention_cell.py:72,83) with this step's counter-based masks;
         backward() regenerates the same masks from the bound shape."""
@@ -193,6 +193,10 @@ class Engine(object):
         self._ck(self.lib.lxo_encoder_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), st), "encoder_fwd")
         if phase_hook:
             phase_hook("encoder_fwd")
+        if before_decoder is not None:
+            # data parallel: the token-count all-reduce (its own stream) must be OFF the GPU before the persistent decoder chain starts --
+            # the chain wants every CU, and a collective kernel that waits for a late rank would hold some of them
+            torch.cuda.current_stream(self.device).wait_event(before_decoder)
         self._active = None if active_rows is None else np.ascontiguousarray(active_rows, dtype=np.int32)
         if self._active is None:
             self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
@@ -333,7 +337,7 @@ class Engine(object):
         if dist is not None:
             # the global token count travels rank -> device -> all-reduce -> loss kernel; no host sync inside the step
             ntok, ev = dist.sum_count_async(n_local)
-            self.forward(img, formula, dropout=drop, active_rows=active)
+            self.forward(img, formula, dropout=drop, active_rows=active, before_decoder=ev)
             stats = self.loss(lengths, ntok_dev=ntok, ntok_event=ev)
         else:
             self.forward(img, formula, dropout=drop, active_rows=active)
