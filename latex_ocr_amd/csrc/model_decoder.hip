@@ -204,7 +204,7 @@ static bool rstep_k_ok(int K, bool bf) {
 }
 static bool fused_steps(const Plan& P) {
     if (P.s.step_kernels == 1) return false;
-    const int ks[6] = {P.XH, P.s.U, P.HC, P.s.O, P.s.E, 4 * P.s.U};
+    const int ks[7] = {P.XH, P.s.U, P.HC, P.s.O, P.s.E, 4 * P.s.U, P.s.C};     // C: the initial-state projections run on the step kernels too
     for (int k : ks) if (!rstep_k_ok(k, P.bf) || !rstep_k_ok(k, false)) return false;     // the f32-operand launches (A converted on load) use 32-k chunks
     return true;
 }
@@ -349,6 +349,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         int t_last = T - 1;
         while (active && t_last > 0 && active[t_last] <= 0) --t_last;
         const int n_last = active ? active[t_last] : B;
+        if (n_last <= 0) return -5;                       // malformed active_rows (the *_active entry points check it; a direct caller gets a clean error, not a zero-sized launch)
         // g_{t_last} = d_o(logits) * tanh'   (no carry yet)
         RC(lxo_k_tanh_bwd(dolog + (size_t)t_last * B * O, O, kNoSlabs, rec + (size_t)(t_last + 1) * B * P.REC, P.REC,
                           gall + (size_t)t_last * B * O, O, bf ? gb + (size_t)t_last * B * P.GBP : nullptr, P.GBP, P.drop(t_last, 0), 0, n_last, O, st));

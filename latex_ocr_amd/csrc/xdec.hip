@@ -261,10 +261,12 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 for (int q = 1; q < 4; ++q) acc[q] = mfma16(a[ks], wl[((q - 1) * 4 + ks) * 64], acc[q]);
             }
             // D layout: column = r16, row = g4 * 4 + i
+            if (g4 * 4 < NB) {                                    // ONE branch for the lanes that hold real rows (sixteen per-store branches otherwise)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (g4 * 4 + i < NB) red[wave][g4 * 4 + i][q * 16 + r16] = acc[q][i];
+                    for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][q * 16 + r16] = acc[q][i];
+            }
             XSTAMP(10);
             __syncthreads();
             XSTAMP(11);
@@ -305,8 +307,10 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) acc = mfma16(a[ks], wah[ks], acc);
+            if (g4 * 4 < NB) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (g4 * 4 + i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+                for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+            }
             __syncthreads();
             if (tid < NB * 8) {
                 const int row = tid >> 3, e = tid & 7;
@@ -463,8 +467,10 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) acc = mfma16(a[ks], wow[ks], acc);
+            if (g4 * 4 < NB) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (g4 * 4 + i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+                for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+            }
             __syncthreads();
             if (tid < NB * 16) {
                 const int row = tid >> 4, cc = tid & 15;

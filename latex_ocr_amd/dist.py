@@ -11,9 +11,14 @@ backward has finalised them (y_W_o before the recurrence, the rest of the decode
 then one bucket per encoder layer from conv6 down; conv2 + conv1 last), overlapping the
 remaining backward; Adam is replicated.
 
-The step never synchronises the host: the token count is a sum of host-known integers, so each rank
-uploads its own count at the START of the step and all-reduces it on a dedicated stream while the forward
-runs; the loss kernel reads the global count from device memory (lxo_ce_loss_fwd_bwd_dev).
+The token count never synchronises the host: it is a sum of host-known integers, so each rank uploads its own count at the START of
+the step and all-reduces it on a dedicated stream while the forward runs; the loss kernel reads the global count from device memory
+(lxo_ce_loss_fwd_bwd_dev).  With host-ordered buckets (the default on a GPU) finish() DOES block the host once per step, until the
+helper thread has enqueued the last bucket, i.e. until the GPU has produced the step's last gradients: the host then runs at most one
+step ahead of the device (measured: world-1 step 10.65 ms host-ordered against 10.55 plain).
+A failing collective is fatal for the job: the worker keeps draining its queue without issuing further collectives, finish() raises
+on this rank, and the caller must tear the process group down (train.py / bench.py do: an uncaught exception ends the process, which
+is what makes the peers' pending collectives fail instead of hanging).
 
 How a bucket's all-reduce is ordered behind the kernels that produce it: NOT with hipStreamWaitEvent.  On this runtime
 (ROCm 7.2, MI355X) a stream that waits for an event recorded on the compute stream slows the compute stream's own

@@ -84,10 +84,13 @@ class Img2SeqModel(BaseModel):
         if not keep > 0:
             raise ValueError("dropout is a keep probability and must be > 0, got {}".format(keep))
         depth = int(getattr(config, "prefetch_depth", 2))
-        batches = ShardedBuckets(train_set, batch_size, world, rank, n_steps=getattr(self, "_dp_nbatches", None)) if world > 1 else None
+        # steps per pass are counted once per (dataset, batch size, world): another train() call with other arguments must not reuse the count
+        key = (id(train_set), batch_size, world)
+        cached = getattr(self, "_dp_nbatches", None)
+        batches = ShardedBuckets(train_set, batch_size, world, rank, n_steps=cached[1] if cached and cached[0] == key else None) if world > 1 else None
         if batches is not None:
             nbatches = len(batches)        # steps this pass really takes (per shape bucket), what the LR schedule was scaled with
-            self._dp_nbatches = nbatches   # the same set every epoch: counted once
+            self._dp_nbatches = (key, nbatches)   # the same set every epoch: counted once
         prog = Progbar(nbatches)
         if depth > 0:
             feed = Prefetcher(train_set, batch_size, self._vocab.id_pad, self._vocab.id_end, device=self.engine.device,
