@@ -96,3 +96,45 @@ def test_chain_vs_oracle_loss_and_greedy_weights():
     got = eng.grad_dict()
     for k in G:
         assert cosine(got[k], G[k].numpy()) > 0.999, (k, cosine(got[k], G[k].numpy()))
+
+
+@pytest.mark.parametrize("step_kernels", [0, 2])
+def test_bf16_cell_transcendentals_over_pm20(step_kernels):
+    """The bf16 cell epilogues form tanh / sigmoid from v_exp_f32 + v_rcp_f32 (rstep.hip since round 3, xdec.hip since round 4) instead of
+    the library calls the f32 parity mode keeps.  Bracket them over pre-activations in [-20, 20]: with the LSTM kernel zeroed the
+    pre-activation of unit u is exactly lstm_cell/bias[u] (+ forget_bias 1 on the f gate), so the stored gates of step 0 ARE
+    sigmoid / tanh of a known ramp; c_1 and h_1 follow from c_0 = tanh(b_c_0).  Held against float64 to 4e-7 absolute on the gates
+    (measured 1.2e-7; the saturated ends must be exact 0 / 1 / +-1), through the launch-per-step kernels (2) and the persistent chain (0)."""
+    Vv = 50
+    img, f, l = batch(8, 32, 128, Vv, 3, 6, seed=21)
+    eng = Engine(Vv, dtype="bf16", seed=1)
+    eng.step_kernels = step_kernels
+    P = eng.get_params()
+    U = 512
+    ramp = np.linspace(-20.0, 20.0, 4 * U).astype(np.float32)
+    rng = np.random.default_rng(0)
+    rng.shuffle(ramp)                                            # every gate sees the whole range
+    P["Decoder/AttentionCell/rnn/lstm_cell/kernel"][:] = 0.0
+    P["Decoder/AttentionCell/rnn/lstm_cell/bias"][:] = ramp
+    bc0 = np.linspace(-3.0, 3.0, U).astype(np.float32)
+    P["Decoder/AttentionCell/att_mechanism/W_c_0"][:] = 0.0
+    P["Decoder/AttentionCell/att_mechanism/b_c_0"][:] = bc0
+    eng.load_params(P)
+    eng.forward(img, f)
+    torch.cuda.synchronize()
+    used, err = eng.chain_status()
+    assert err == 0 and used == (step_kernels == 0)
+    T = f.shape[1]
+    g = eng.region("gates", "f32", (T, 8, 4 * U))[0, 0].cpu().numpy().astype(np.float64)
+    z = ramp.astype(np.float64)
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    want = np.concatenate([sig(z[:U]), np.tanh(z[U:2 * U]), sig(z[2 * U:3 * U] + 1.0), sig(z[3 * U:])])
+    d = np.abs(g - want)
+    print("step_kernels=%d: gates vs float64 over [-20, 20]: max abs error %.2e" % (step_kernels, d.max()))
+    assert d.max() < 4e-7, d.max()
+    c0 = np.tanh(bc0.astype(np.float64))
+    c1 = want[2 * U:3 * U] * c0 + want[:U] * want[U:2 * U]
+    h1 = want[3 * U:] * np.tanh(c1)
+    cs = eng.region("cs", "f32", (T + 1, 8, U))[1, 0].cpu().numpy().astype(np.float64)
+    h = eng.region("rec", "f32", (T + 1, 8, 2048))[1, 0, 512:1024].cpu().numpy().astype(np.float64)
+    assert np.abs(cs - c1).max() < 2e-6 and np.abs(h - h1).max() < 2e-6, (np.abs(cs - c1).max(), np.abs(h - h1).max())
