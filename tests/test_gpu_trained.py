@@ -10,8 +10,8 @@ What "equivalent" can mean: Adam turns rounding noise into O(lr) steps wherever 
 arithmetic that differ only in summation order (the oracle with two intra-op thread counts: the CONTROL below) already part
 by ~1e-3 within 20 steps and by several per cent once the loss is small.  The bars: the first 10 steps (before that fork
 matters) are held to north_star's 1e-3 (f32 mode: 1e-4; measured 2.2e-4 / 4e-6); over the whole curve the 5-step moving average
-of |log loss - log oracle loss| must stay within 4x the control's own spread (floor 0.20; bf16 measured 0.164 against a control of
-0.049), and the mean loss of the last 10 steps within 10 % (measured 4.4 % / 1.5 %).  The f32 parity mode has no float atomics
+of |log loss - log oracle loss| must stay within 4x the control's own spread (floor 0.20 for the deterministic f32 mode, 0.30 for bf16,
+whose atomics make the curve vary from run to run: 0.135 .. 0.164 measured against a control of 0.049), and the mean loss of the last 10 steps within 10 % (measured 4.4 % / 1.5 %).  The f32 parity mode has no float atomics
 (round 4: every reduction ordered), so its 100-step curve is the SAME in every run: the test runs it twice and asserts bit equality
 (round 3's f32 curve moved between 0.146 and 0.204 from run to run of one binary; that is what forced a 0.30 floor then)."""
 import os
@@ -105,7 +105,10 @@ def test_loss_curve_100_steps_vs_oracle(curves, dtype, first_bar):
           rel[10:20].max(), sp, spc, got[-10:].mean(), ref[-10:].mean()))
     assert ref[-1] < 0.1 * ref[0], "the toy set was not learnt: %s" % ref[-5:]
     assert rel[:10].max() <= first_bar, rel[:10]
-    assert sp <= max(4.0 * spc, 0.20), (sp, spc)              # measured on MI355X: bf16 0.164, control 0.049; f32: one value per binary (deterministic)
+    # f32: the parity mode is deterministic -- one value per binary, measured 0.100 -- and is held to 4x the control, floor 0.20.
+    # bf16 keeps f32 atomics in its reductions, so its 100-step curve differs from run to run of one binary (0.135, 0.160, 0.164 observed):
+    # floor 0.30 there, as in round 3
+    assert sp <= max(4.0 * spc, 0.20 if dtype == "f32" else 0.30), (sp, spc)
     assert abs(got[-10:].mean() - ref[-10:].mean()) <= 0.10 * ref[-10:].mean()
     # decode: each side from its OWN 100-step weights (reported), then the engine from the ORACLE's weights (asserted)
     img = pad_batch_images(imgs[:40])
