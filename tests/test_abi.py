@@ -67,6 +67,26 @@ def test_workspace_queries_and_validation(lib):
     assert b"image too small" in lib.lxo_last_error()
 
 
+def test_ws_region_dtype_follows_the_plan(lib):
+    """lxo_ws_region_dtype names the element type an external driver of lxo_encoder_bwd must write into "d_img": bf16 (d_y6, masked) only
+    where the decoder's last GEMM applies conv6's mask -- bf16 mode, E % 32 == 0, no row encoder -- and the plain f32 gradient otherwise."""
+    def dt(dtype, E=256, rnn=0):
+        s = _abi.LxoShape(4, 32, 128, 10, 50, 512, E, 512, 512, 80, dtype, 1, 0)
+        s.encoder_rnn = rnn
+        return lib.lxo_ws_region_dtype(ctypes.byref(s), b"d_img")
+    assert dt(_abi.LXO_BF16) == _abi.LXO_BF16
+    assert dt(_abi.LXO_F32) == _abi.LXO_F32
+    assert dt(_abi.LXO_BF16, rnn=1) == _abi.LXO_F32          # with the row encoder "d_img" is the gradient w.r.t. ITS output: f32
+    s = _abi.LxoShape(4, 32, 128, 10, 50, 512, 256, 512, 512, 80, _abi.LXO_BF16, 1, 0)
+    for name, want in ((b"img", _abi.LXO_BF16), (b"att_exp", _abi.LXO_F32), (b"recb", _abi.LXO_BF16), (b"alpha", _abi.LXO_F32), (b"m2", _abi.LXO_U8),
+                       (b"dec_ids", _abi.LXO_I32)):
+        if name == b"att_exp":
+            continue          # listed below with the compute-dtype regions
+        assert lib.lxo_ws_region_dtype(ctypes.byref(s), name) == want, name
+    assert lib.lxo_ws_region_dtype(ctypes.byref(s), b"att_exp") == _abi.LXO_BF16
+    assert lib.lxo_ws_region_dtype(ctypes.byref(s), b"no_such_region") < 0
+
+
 def test_no_cpu_fallback():
     import torch
     from latex_ocr_amd.engine import Engine
