@@ -353,9 +353,31 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         // g_{t_last} = d_o(logits) * tanh'   (no carry yet)
         RC(lxo_k_tanh_bwd(dolog + (size_t)t_last * B * O, O, kNoSlabs, rec + (size_t)(t_last + 1) * B * P.REC, P.REC,
                           gall + (size_t)t_last * B * O, O, bf ? gb + (size_t)t_last * B * P.GBP : nullptr, P.GBP, P.drop(t_last, 0), 0, n_last, O, st));
+        bool chain_done = false;
+        if (bf && !active && P.s.step_kernels == 0) {
+            // the whole recurrence in one launch (xdec.hip, the backward chain); -2 = the shape does not qualify
+            XDecBwd x; memset(&x, 0, sizeof(x));
+            x.Wow = (const bf16_t*)P.pk(wp, K_OW); x.ldow = P.ldOW;
+            x.Wah = (const bf16_t*)P.pk(wp, K_ATT_H); x.ldah = P.ldAH;
+            x.Wk = (const bf16_t*)P.pk(wp, K_LSTM) + (size_t)D * P.ldK; x.ldk = P.ldK;
+            x.beta = prm + P.poff[P_BETA];
+            x.att_img = (const bf16_t*)att_img; x.img = (const bf16_t*)img;
+            x.att_exp = P.att_exp() ? P.ws<bf16_t>(ws, W_ATT_EXP) : nullptr;
+            x.rec = rec; x.REC = P.REC; x.cs = cs; x.gates = gates; x.atth = atth; x.alpha = alpha; x.Rp = P.Rp;
+            x.dolog = dolog; x.gall = gall; x.gb = gb; x.GBP = P.GBP; x.dhc = dhc; x.de = de; x.datth = datth;
+            x.dz = dz; x.dzb = dzb; x.DZBP = P.DZBP; x.carry_h = carry_h; x.dcc = dcc; x.dxh = dxh;
+            x.part = P.ws<float>(ws, W_APART);                       // the forward chain's chunk partials are dead by now
+            x.sync = P.ws<unsigned>(ws, W_XSYNC) + 1024;             // its own block (plan.hip)
+            x.T = T; x.B = B; x.R = P.R;
+            x.dr = P.drop(0, 0);
+            LxoTimed tm("xdec_bwd", "chain", (double)T * B * P.R * (E + C) * P.esz, st);
+            const int rc = lxo_launch_xdec_bwd(x, U, O, C, E, st);
+            if (rc == 0) chain_done = true;
+            else if (rc != -2) return rc < 0 ? rc : -rc;
+        }
         RStep a; memset(&a, 0, sizeof(a));
         a.U = U; a.O = O; a.zx_row = -1;
-        for (int t = t_last; t >= 0; --t) {
+        for (int t = t_last; t >= 0 && !chain_done; --t) {
             const int nr = active ? active[t] : B;
             const int nchb = P.det() ? 1 : P.attn_chunks(nr);      // parity mode: one chunk per sample = one writer per d_att_h element
             a.M = nr;

@@ -30,6 +30,36 @@ struct XDecFwd {
 
 // 0 = launched; -2 = the shape does not qualify (the caller runs the launch-per-step chain instead)
 int lxo_launch_xdec_fwd(const XDecFwd& p, int U, int O, int C, int E, hipStream_t st);
+
+// The same chain for BPTT (attention_cell.py:58-89 backwards, steps T-1 .. 0): per step [d_h~ | d_ctx] = g o_W^T, the attention stream
+// (d_e, d_att_h), d_h -> LSTM cell backward (d_z, d_c), the carries [d_o | d_h] = d_z K[D:]^T and g_{t-1}.  Everything a step hands to
+// the deferred all-step weight-gradient GEMMs (g, d_z and their bf16 mirrors, [d_h~ | d_ctx], d_e, d_att_h) is left in the same arrays
+// the launch-per-step chain fills.
+struct XDecBwd {
+    const bf16_t* Wow; int ldow;      // K_OW    [U + C][O]   ([out][in] of the backward product)
+    const bf16_t* Wah; int ldah;      // K_ATT_H [U][E]
+    const bf16_t* Wk; int ldk;        // K_LSTM rows D.. : [O + U][4U]
+    const float* beta;                // [E]
+    const bf16_t* att_img; const bf16_t* att_exp; const bf16_t* img;     // as in XDecFwd
+    const float* rec; int REC;        // forward record [(T + 1)][B][REC]
+    const float* cs; const float* gates; const float* atth; const float* alpha; int Rp;
+    const float* dolog;               // [T][B][O] d_o from the logits
+    float* gall; bf16_t* gb; int GBP; // g_t [T][B][O] + mirror; slot T-1 holds g_{T-1} on entry
+    float* dhc;                       // [T][B][U + C]
+    float* de;                        // [T][B][Rp]
+    float* datth;                     // [T][B][E]
+    float* dz; bf16_t* dzb; int DZBP; // [T][B][4U] + mirror
+    float* carry_h;                   // [B][U] scratch
+    float* dcc;                       // [B][U] out: d_c of the initial state
+    float* dxh;                       // [B][O + U] out: the raw carries of step 0
+    float* part;                      // [B][nq][E] d_att_h chunk partials
+    unsigned* sync;                   // as in XDecFwd (its own block)
+    int T, B, R;
+    Drop dr;
+    unsigned long long* dbg;          // as in XDecFwd
+};
+int lxo_launch_xdec_bwd(const XDecBwd& p, int U, int O, int C, int E, hipStream_t st);
+extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf);
 // measurement aid: the next launches of this host thread stamp their phases into buf (null = off)
 extern "C" int lxo_xdec_debug(unsigned long long* buf);
 // bytes of the `sync` block

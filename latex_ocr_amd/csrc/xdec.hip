@@ -29,7 +29,9 @@
 #ifdef LXO_HIPSIM
 // tests/hipsim interprets one workgroup after the other: a kernel whose workgroups wait for each other cannot run there
 int lxo_launch_xdec_fwd(const XDecFwd&, int, int, int, int, hipStream_t) { return -2; }
+int lxo_launch_xdec_bwd(const XDecBwd&, int, int, int, int, hipStream_t) { return -2; }
 extern "C" int lxo_xdec_debug(unsigned long long*) { return 0; }
+extern "C" int lxo_xdec_debug_bwd(unsigned long long*) { return 0; }
 #else
 
 HIP_DYNAMIC_SHARED(char, xdec_dyn_lds)
@@ -502,6 +504,356 @@ int launch_nb(const XDecFwd& p, int att_u, hipStream_t st) {
 #undef XLAUNCH
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------ backward chain ----
+// Steps T-1 .. 0 of BPTT in one launch, same chains, same identity, same barrier.  Per step:
+//   Q1  [d_h~ | d_ctx] = g_t o_W^T                                   every workgroup: its 32 columns, all NB rows
+//   Q2  attention stream of one (sample, chunk): d_alpha_r = <img_r, d_ctx>, d_e_r = alpha_r (d_alpha_r - s), d_att_h += d_e_r beta (1 - tanh^2)
+//   Q3  d_att_h = sum of the chunks; d_h = (d_h~ + d_att_h W_att_h^T) mask + carry; LSTM cell backward -> d_z, d_c     its 16 units
+//   Q4  [d_o | d_h] carries = d_z K[D:]^T; g_{t-1} = (d_o(logits) + d_o carry) mask tanh'                              its 32 columns
+// Resident per wave: its eighth of K_OW (2 x 2 fragments), of K_ATT_H (1) and of K_LSTM[D:] (16 fragments: 4 in registers, 12 in LDS).
+template <int ATT_U>
+LXO_DEV void attb_load(u32x4 (&xi)[ATT_U], u32x2 (&xa)[ATT_U], float (&al)[ATT_U], rsrc_t rim, rsrc_t rai, rsrc_t ral, int base, int an, int lane) {
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        const int r = max(min(base + XW * u, an - 1), 0);
+        xi[u] = __builtin_amdgcn_raw_buffer_load_b128(rim, lane * 16, r * (XC * 2), 0);
+        xa[u] = __builtin_amdgcn_raw_buffer_load_b64(rai, lane * 8, r * (XE * 2), 0);
+        al[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ral, 0, r * 4, 0));
+    }
+}
+// EXPD: xa holds E_x = e^{2x}, ah holds E_a: r = 1 / (1 + E_x E_a), 1 - tanh^2 = 4 r (1 - r)
+template <int ATT_U, bool EXPD>
+LXO_DEV void attb_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], const float (&al)[ATT_U], int base, int an, const float (&dc)[8],
+                        const float (&ah)[4], float s, float (&acc)[4], float* de_row, int lane) {
+    float pt[ATT_U];
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a = fmaf(__uint_as_float(xi[u][e] << 16), dc[2 * e], a);
+            a = fmaf(__uint_as_float(xi[u][e] & 0xffff0000u), dc[2 * e + 1], a);
+        }
+        pt[u] = a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) {
+        const int r = base + XW * u;
+        if (r >= an) continue;                                           // wave-uniform: a clamped row costs its loads, not its arithmetic
+        const float d = al[u] * (pt[u] - s);                            // softmax backward
+        if (lane == 0) de_row[r] = d;
+        const float x0 = __uint_as_float(xa[u][0] << 16), x1 = __uint_as_float(xa[u][0] & 0xffff0000u);
+        const float x2 = __uint_as_float(xa[u][1] << 16), x3 = __uint_as_float(xa[u][1] & 0xffff0000u);
+        if constexpr (EXPD) {
+            const float d4 = 4.f * d;
+            const float r0 = __builtin_amdgcn_rcpf(fmaf(x0, ah[0], 1.f)), r1 = __builtin_amdgcn_rcpf(fmaf(x1, ah[1], 1.f));
+            const float r2 = __builtin_amdgcn_rcpf(fmaf(x2, ah[2], 1.f)), r3 = __builtin_amdgcn_rcpf(fmaf(x3, ah[3], 1.f));
+            acc[0] = fmaf(d4, fmaf(-r0, r0, r0), acc[0]); acc[1] = fmaf(d4, fmaf(-r1, r1, r1), acc[1]);
+            acc[2] = fmaf(d4, fmaf(-r2, r2, r2), acc[2]); acc[3] = fmaf(d4, fmaf(-r3, r3, r3), acc[3]);
+        } else {
+            const float t0 = tanh_x(x0 + ah[0]), t1 = tanh_x(x1 + ah[1]), t2 = tanh_x(x2 + ah[2]), t3 = tanh_x(x3 + ah[3]);
+            acc[0] = fmaf(d, 1.f - t0 * t0, acc[0]); acc[1] = fmaf(d, 1.f - t1 * t1, acc[1]);
+            acc[2] = fmaf(d, 1.f - t2 * t2, acc[2]); acc[3] = fmaf(d, 1.f - t3 * t3, acc[3]);
+        }
+    }
+}
+
+template <int NB, int ATT_U, bool EXPD>
+__global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
+    constexpr int NQ = 32 / NB;                                  // attention chunks per sample
+    constexpr int QS = 8 / NB;                                   // Q3: thread groups (waves) that share one sample's NQ chunk partials, 4 chunks each
+    __shared__ float red[XW][8][32];                             // cross-wave partial tiles: [wave][row][column]           8 KB
+    __shared__ __attribute__((aligned(16))) float redc[XW][XE];  // Q2: the waves' partial d_att_h; Q3: the chunk groups' sums   8 KB
+    __shared__ __attribute__((aligned(16))) bf16_t adh[16][XE + 8];   // Q3: d_att_h as the A tile of the att_h product     8.3 KB
+    __shared__ float cst[8][16];                                 // d_c of this workgroup's 16 units (lives here for all T steps)
+    __shared__ int s_rank, s_dead;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g4 = lane >> 4;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    unsigned* xsync = p.sync + xcc * 64;
+    unsigned* err = p.sync + 8 * 64;
+    if (tid == 0) { s_dead = 0; s_rank = (int)atomicAdd(xsync + 32, 1u); }
+    for (int i = tid; i < 16 * (XE + 8); i += 512) (&adh[0][0])[i] = 0;      // rows >= NB of the A tile stay zero
+    if (tid < 128) (&cst[0][0])[tid] = 0.f;
+    __syncthreads();
+    const int rank = s_rank;
+    if (rank >= 32) { if (tid == 0) *reinterpret_cast<volatile unsigned*>(err) = 2u; return; }
+    const int B = p.B, T = p.T;
+    const int b0 = (int)xcc * NB;
+    const int u0 = rank * 16, n0 = rank * 32;
+
+    // ---- resident weights (MFMA B fragments: lane = (output column r16, k group g4)) ----
+    u32x4 wow[2][2], wahb, wk0[4];
+    u32x4* wl = reinterpret_cast<u32x4*>(xdec_dyn_lds) + (wave * 12) * 64 + lane;       // + (f - 4) * 64, f = nt * 8 + ks
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wow[nt][ks] = *reinterpret_cast<const u32x4*>(p.Wow + (long long)(n0 + nt * 16 + r16) * p.ldow + wave * 64 + ks * 32 + g4 * 8);
+    wahb = *reinterpret_cast<const u32x4*>(p.Wah + (long long)(u0 + r16) * p.ldah + wave * 32 + g4 * 8);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wk + (long long)(n0 + nt * 16 + r16) * p.ldk + wave * 256 + ks * 32 + g4 * 8);
+            const int f = nt * 8 + ks;
+            if (f < 4) wk0[f] = w; else wl[(f - 4) * 64] = w;
+        }
+    float bt[4];
+    { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + lane * 4); bt[0] = b4[0]; bt[1] = b4[1]; bt[2] = b4[2]; bt[3] = b4[3]; }
+
+    // attention role of this workgroup (as in the forward chain)
+    const int as = rank / NQ, aq = rank - as * NQ;
+    const int ab = b0 + as;
+    const int rows_per = (p.R + NQ - 1) / NQ;
+    const int ar0 = aq * rows_per;
+    const int an = min(p.R, ar0 + rows_per) - ar0;
+    const int arow = min(r16, NB - 1);
+    Drop dr = p.dr;
+    unsigned ph = 0;
+    const int nblk = an > 0 ? (an + XW * ATT_U - 1) / (XW * ATT_U) : 0;
+    const int nblk2 = (nblk + 1) & ~1;
+    const int anq = an > 0 ? an : 1;
+    const bf16_t* aibase = EXPD ? p.att_exp : p.att_img;
+    const rsrc_t imq = make_rsrc(an > 0 ? p.img + ((long long)ab * p.R + ar0) * XC : p.img, (unsigned)anq * XC * 2u);
+    const rsrc_t aiq = make_rsrc(an > 0 ? aibase + ((long long)ab * p.R + ar0) * XE : aibase, (unsigned)anq * XE * 2u);
+    const long long al_off = an > 0 ? (long long)ab * p.Rp + ar0 : 0;     // + t * B * Rp: this chunk's alpha rows of step t
+#define XBASE(i, rv) (wave + XW * ATT_U * ((rv) ? nblk2 - 1 - (i) : (i)))
+    u32x4 xiA[ATT_U], xiB[ATT_U]; u32x2 xaA[ATT_U], xaB[ATT_U]; float alA[ATT_U], alB[ATT_U];
+    {
+        const rsrc_t ral = make_rsrc(p.alpha + (long long)(T - 1) * B * p.Rp + al_off, (unsigned)anq * 4u);
+        attb_load<ATT_U>(xiA, xaA, alA, imq, aiq, ral, XBASE(0, (T - 1) & 1), anq, lane);
+        attb_load<ATT_U>(xiB, xaB, alB, imq, aiq, ral, XBASE(1, (T - 1) & 1), anq, lane);
+    }
+    // forward values the phases of a step need, requested a few phases ahead (they come from HBM): this lane's 8 channels of ctx_t and
+    // 4 columns of att_h_t (Q2); gates, c_t, c_{t-1} of this thread's LSTM element (Q3); d_o(logits) and o of step t-1 (Q4)
+    f32x4 cx0, cx1, ahn;
+    {
+        const float* cp = p.rec + ((long long)T * B + ab) * p.REC + OFF_CTX + lane * 8;
+        cx0 = *reinterpret_cast<const f32x4*>(cp); cx1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        ahn = *reinterpret_cast<const f32x4*>(p.atth + ((long long)(T - 1) * B + ab) * XE + lane * 4);
+    }
+    float lg[4], lcc = 0.f, lcp = 0.f, qd = 0.f, qo = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lg[q] = 0.f;
+    const int e3r = min(tid >> 4, NB - 1), e3u = tid & 15;       // Q3 epilogue element of this thread (threads < NB * 16)
+    const int e4r = min(tid >> 5, NB - 1), e4c = tid & 31;       // Q1 / Q4 epilogue element (threads < NB * 32)
+    unsigned long long* dbg = p.dbg ? p.dbg + ((long long)(xcc * 32 + rank) * T) * 16 : nullptr;
+#define XSTAMP(i) do { if (dbg && tid == 0) dbg[(T - 1 - t) * 16 + (i)] = wall_clock64(); } while (0)
+    for (int t = T - 1; t >= 0; --t) {
+        dr.t = t;
+        XSTAMP(0);
+        const long long sp = (long long)t * B;
+        const rsrc_t rdh = make_rsrc(p.dhc + sp * XHC, (unsigned)B * XHC * 4u);
+        // =========================== Q1: [d_h~ | d_ctx] = g o_W^T ===========================
+        {
+            const rsrc_t rg = make_rsrc(p.gb + sp * p.GBP, (unsigned)B * p.GBP * 2u);
+            u32x4 a[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[ks] = l2_load16(rg, (unsigned)(((b0 + arow) * p.GBP + wave * 64 + ks * 32 + g4 * 8) * 2));
+            v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { acc[0] = mfma16(a[ks], wow[0][ks], acc[0]); acc[1] = mfma16(a[ks], wow[1][ks], acc[1]); }
+            if (g4 * 4 < NB) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][nt * 16 + r16] = acc[nt][i];
+            }
+            __syncthreads();
+            if (tid < NB * 32) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) v += red[w][e4r][e4c];
+                p.dhc[(sp + b0 + e4r) * XHC + n0 + e4c] = v;
+            }
+        }
+        XSTAMP(1);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(2);
+        // =========================== Q2: attention stream ===========================
+        {
+            const u32x4 d0 = l2_load16(rdh, (unsigned)((ab * XHC + XU + lane * 8) * 4)), d1 = l2_load16(rdh, (unsigned)((ab * XHC + XU + lane * 8 + 4) * 4));
+            float dc[8], ah[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dc[e] = __uint_as_float(d0[e]); dc[4 + e] = __uint_as_float(d1[e]); }
+            float s = 0.f;                                       // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r: every wave forms it by itself
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(cx0[e], dc[e], fmaf(cx1[e], dc[4 + e], s));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ah[j] = ahn[j];
+                if constexpr (EXPD) ah[j] = __builtin_amdgcn_exp2f(fminf(fmaxf(ah[j] * 2.8853900817779268f, -60.f), 60.f));
+            }
+            float* de_row = p.de + (sp + ab) * p.Rp + ar0;
+            const int rev = t & 1;
+            const int tn = max(t - 1, 0);
+            const rsrc_t ral = make_rsrc(p.alpha + sp * p.Rp + al_off, (unsigned)anq * 4u);
+            const rsrc_t raln = make_rsrc(p.alpha + (long long)tn * B * p.Rp + al_off, (unsigned)anq * 4u);
+            for (int it = 0; it < nblk2; it += 2) {
+                const bool more = it + 2 < nblk2;
+                attb_block<ATT_U, EXPD>(xiA, xaA, alA, XBASE(it, rev), an, dc, ah, s, acc, de_row, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                attb_load<ATT_U>(xiA, xaA, alA, imq, aiq, more ? ral : raln, more ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                attb_block<ATT_U, EXPD>(xiB, xaB, alB, XBASE(it + 1, rev), an, dc, ah, s, acc, de_row, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                attb_load<ATT_U>(xiB, xaB, alB, imq, aiq, more ? ral : raln, more ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // forward values of the coming phases (unconditional, clamped indices)
+            {
+                const float* cp = p.rec + ((long long)(tn + 1) * B + ab) * p.REC + OFF_CTX + lane * 8;
+                cx0 = *reinterpret_cast<const f32x4*>(cp); cx1 = *reinterpret_cast<const f32x4*>(cp + 4);
+                ahn = *reinterpret_cast<const f32x4*>(p.atth + ((long long)tn * B + ab) * XE + lane * 4);
+                const float* gr = p.gates + (sp + b0 + e3r) * 4 * XU + u0 + e3u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lg[q] = gr[q * XU];
+                lcc = p.cs[(sp + B + b0 + e3r) * XU + u0 + e3u];
+                lcp = p.cs[(sp + b0 + e3r) * XU + u0 + e3u];
+                const int nq4 = min(n0 + e4c, XO - 1);
+                qd = p.dolog[((long long)tn * B + b0 + e4r) * XO + nq4];
+                qo = p.rec[((long long)(tn + 1) * B + b0 + e4r) * p.REC + nq4];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) redc[wave][lane * 4 + j] = acc[j] * bt[j];
+            __syncthreads();
+            if (tid < XE) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) v += redc[w][tid];
+                p.part[((long long)ab * NQ + aq) * XE + tid] = v;
+            }
+        }
+        XSTAMP(3);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(4);
+        // =========================== Q3: d_att_h; d_h; LSTM cell backward ===========================
+        {
+            const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * XE, (unsigned)(NB * NQ * XE) * 4u);
+            const rsrc_t rcar = make_rsrc(p.carry_h, (unsigned)B * XU * 4u);
+            // wave `slot` sums 4 of the NQ chunk partials of sample slot / QS; the QS groups of a sample meet in LDS
+            const int srow = wave / QS, sqg = wave - srow * QS;
+            u32x4 pc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pc[j] = l2_load16(rpart, (unsigned)((((srow * NQ + sqg * 4 + j) * XE) + lane * 4) * 4));
+            const float dhm = l2_load4(rdh, (unsigned)(((b0 + e3r) * XHC + u0 + e3u) * 4));
+            const float chv = l2_load4(rcar, (unsigned)(((b0 + e3r) * XU + u0 + e3u) * 4));
+            {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (__uint_as_float(pc[0][e]) + __uint_as_float(pc[1][e])) + (__uint_as_float(pc[2][e]) + __uint_as_float(pc[3][e]));
+                *reinterpret_cast<f32x4*>(&redc[wave][lane * 4]) = v;
+            }
+            __syncthreads();
+            if (tid < NB * 64) {
+                const int row = tid >> 6, k4 = (tid & 63) * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&redc[row * QS][k4]);
+#pragma unroll
+                for (int g = 1; g < QS; ++g) { const f32x4 w = *reinterpret_cast<const f32x4*>(&redc[row * QS + g][k4]); v += w; }
+                const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(&adh[row][k4]) = vb;
+                if (rank == row) *reinterpret_cast<f32x4*>(p.datth + (sp + b0 + row) * XE + k4) = v;      // kept for the deferred dW_att_h product
+            }
+            __syncthreads();
+            const u32x4 a = *reinterpret_cast<const u32x4*>(&adh[r16][wave * 32 + g4 * 8]);
+            v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+            acc = mfma16(a, wahb, acc);
+            if (g4 * 4 < NB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+            }
+            __syncthreads();
+            if (tid < NB * 16) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) v += red[w][e3r][e3u];
+                const int bb = b0 + e3r, u = u0 + e3u;
+                // backward of the TF-1.12 LSTMCell (gates i, j, f, o) -- the same expressions as the launch chain's epilogue (rstep.hip)
+                const float dh = (dhm + v) * drop_scale(dr, 1u, bb, u, XU) + (t == T - 1 ? 0.f : chv);
+                const float tc = tanh_x(lcc);
+                const float dcv = cst[e3r][e3u] + dh * lg[3] * (1.f - tc * tc);
+                const float dzi = dcv * lg[1] * lg[0] * (1.f - lg[0]);
+                const float dzj = dcv * lg[0] * (1.f - lg[1] * lg[1]);
+                const float dzf = dcv * lcp * lg[2] * (1.f - lg[2]);
+                const float dzo = dh * tc * lg[3] * (1.f - lg[3]);
+                cst[e3r][e3u] = dcv * lg[2];
+                float* dzr = p.dz + (sp + bb) * 4 * XU + u;
+                dzr[0] = dzi; dzr[XU] = dzj; dzr[2 * XU] = dzf; dzr[3 * XU] = dzo;
+                bf16_t* db = p.dzb + (sp + bb) * p.DZBP + u;
+                db[0] = f2bf(dzi); db[XU] = f2bf(dzj); db[2 * XU] = f2bf(dzf); db[3 * XU] = f2bf(dzo);
+            }
+        }
+        XSTAMP(5);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(6);
+        // =========================== Q4: carries = d_z K[D:]^T; g_{t-1} ===========================
+        {
+            const rsrc_t rdz = make_rsrc(p.dzb + sp * p.DZBP, (unsigned)B * p.DZBP * 2u);
+            u32x4 a[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) a[ks] = l2_load16(rdz, (unsigned)(((b0 + arow) * p.DZBP + wave * 256 + ks * 32 + g4 * 8) * 2));
+            v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                acc[0] = mfma16(a[ks], ks < 4 ? wk0[ks < 4 ? ks : 0] : wl[(ks - 4) * 64], acc[0]);
+                acc[1] = mfma16(a[ks], wl[(8 + ks - 4) * 64], acc[1]);
+            }
+            if (g4 * 4 < NB) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][nt * 16 + r16] = acc[nt][i];
+            }
+            __syncthreads();
+            if (tid < NB * 32) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) v += red[w][e4r][e4c];
+                const int bb = b0 + e4r, n = n0 + e4c;
+                if (t == 0) p.dxh[(long long)bb * XXH + n] = v;              // raw carries for the initial-state gradients
+                else if (n < XO) {
+                    // g_{t-1} = (d_o(logits) + d_o carry) * dropout mask * (1 - tanh^2), tanh from o_{t-1}   (attention_cell.py:82-83 backward)
+                    Drop dq = dr; dq.t = t - 1;
+                    const float sc = drop_scale(dq, 2u, bb, n, XO);
+                    const float th = (dq.thr == 0u) ? qo : qo / dq.inv_keep;   // rec holds the dropped o; where the mask is 1 tanh = o * keep
+                    const float g = (qd + v) * sc * (1.f - th * th);
+                    p.gall[(sp - B + bb) * XO + n] = g;
+                    p.gb[(sp - B + bb) * p.GBP + n] = f2bf(g);
+                } else p.carry_h[(long long)bb * XU + (n - XO)] = v;
+            }
+        }
+        XSTAMP(7);
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        XSTAMP(8);
+    }
+#undef XSTAMP
+#undef XBASE
+    if (tid < NB * 16) p.dcc[(long long)(b0 + e3r) * XU + u0 + e3u] = cst[e3r][e3u];
+}
+
+template <int NB>
+int launch_bwd_nb(const XDecBwd& p, hipStream_t st) {
+    constexpr int DYN = XW * 12 * 64 * 16;
+#define XLAUNCH(X_) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(xdec_bwd_kernel<NB, 4, X_>), hipFuncAttributeMaxDynamicSharedMemorySize, DYN)); attr_done = true; } \
+        hipLaunchKernelGGL((xdec_bwd_kernel<NB, 4, X_>), dim3(256), dim3(512), DYN, st, p); } while (0)
+    if (p.att_exp) XLAUNCH(true); else XLAUNCH(false);
+#undef XLAUNCH
+    return (int)hipGetLastError();
+}
 }  // namespace
 
 static thread_local unsigned long long* g_xdbg = nullptr;
@@ -538,6 +890,33 @@ int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream
     case 2: return launch_nb<2>(p, att_u, st);
     case 4: return launch_nb<4>(p, att_u, st);
     default: return launch_nb<8>(p, att_u, st);
+    }
+}
+static thread_local unsigned long long* g_xdbg_b = nullptr;
+extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf) { g_xdbg_b = buf; return 0; }
+int lxo_launch_xdec_bwd(const XDecBwd& p0, int U, int O, int C, int E, hipStream_t st) {
+    XDecBwd p = p0;
+    p.dbg = g_xdbg_b;
+    static int on = -1;                                          // LXO_XDEC_BWD=0: forward chain only (A/B runs); LXO_XDEC=0 switches both off
+    if (on < 0) { const char* e = getenv("LXO_XDEC_BWD"); const char* f = getenv("LXO_XDEC"); on = ((e && e[0] == '0') || (f && f[0] == '0')) ? 0 : 1; }
+    if (!on) return -2;
+    if (U != XU || O != XO || C != XC || E != XE) return -2;
+    if (p.B % 8 != 0 || p.B > 64 || p.T < 1) return -2;
+    const int nb = p.B / 8;
+    if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return -2;
+    const int nq = 32 / nb, rows_per = (p.R + nq - 1) / nq;
+    if (rows_per > SCMAX || rows_per < 1) return -2;
+    if (p.ldow % 8 || p.ldah % 8 || p.ldk % 8 || p.GBP % 8 || p.DZBP % 8 || p.REC % 4 || (long long)p.B * p.DZBP * 2 >= (1LL << 31)) return -2;
+    int dev = 0; hipDeviceProp_t pr;
+    static int dev_ok = -1;
+    if (dev_ok < 0) dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
+    if (!dev_ok) return -2;
+    HIPRC(hipMemsetAsync(p.sync, 0, kXDecSyncBytes, st));
+    switch (nb) {
+    case 1: return launch_bwd_nb<1>(p, st);
+    case 2: return launch_bwd_nb<2>(p, st);
+    case 4: return launch_bwd_nb<4>(p, st);
+    default: return launch_bwd_nb<8>(p, st);
     }
 }
 #endif

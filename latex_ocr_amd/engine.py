@@ -39,6 +39,8 @@ class Engine(object):
         # qualifies, else the fused step kernels), 2 = always the fused step kernels, 1 = round 1's split-K slab path
         self.step_kernels = int(os.environ.get("LXO_STEP_KERNELS", "0"))
         self._xdec_checked = False
+        self._xdec_bwd_checked = False
+        self.chain_used_bwd = False
         self.specs = PP.param_specs(self.n_tok, self.dims)
         self.n_params = PP.n_params(self.n_tok, self.dims)
         probe = self._shape(1, 32, 32, 1)
@@ -208,11 +210,13 @@ class Engine(object):
             self._ck(self.lib.lxo_decoder_train_fwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
                                                            self._active.ctypes.data_as(ctypes.c_void_p), st), "decoder_train_fwd_active")
 
-    def chain_status(self):
-        """(used, error) of the persistent XCD-local decoder chain (csrc/xdec.hip) in the last lxo_decoder_train_fwd: used = its 8 x 32
-        workgroups took their tickets; error != 0 = a chain did not assemble (a barrier timed out / an XCD got the wrong number of
-        workgroups) and the step's decoder outputs are invalid.  Synchronises the device."""
-        w = self.region("xdec_sync", "i32")[:8 * 64 + 1].cpu().numpy()
+    def chain_status(self, backward=False):
+        """(used, error) of the persistent XCD-local decoder chain (csrc/xdec.hip) in the last lxo_decoder_train_fwd (backward=True: the
+        backward chain of the last lxo_decoder_train_bwd): used = its 8 x 32 workgroups took their tickets; error != 0 = a chain did not
+        assemble (a barrier timed out / an XCD got the wrong number of workgroups) and the step's decoder outputs are invalid.
+        Synchronises the device."""
+        o = 1024 if backward else 0                              # the backward chain's block (plan.hip: W_XSYNC)
+        w = self.region("xdec_sync", "i32")[o:o + 8 * 64 + 1].cpu().numpy()
         return bool(w[32:512:64].any()), int(w[512])
 
     def _check_chain(self, st):
@@ -258,22 +262,43 @@ class Engine(object):
         part (bench.py's per-phase table)."""
         st = self._stream()
         self._bind_side()
-        self.grads.zero_()
         act = None if self._active is None else self._active.ctypes.data_as(ctypes.c_void_p)
+        # the recurrence may run as the persistent backward chain (csrc/xdec.hip): it wants every CU, so no collective kernel is put
+        # beside it -- y_W_o's all-reduce then follows the recurrence instead of overlapping it
+        chain = (self.dtype == _abi.LXO_BF16 and self.shape.step_kernels == 0 and self._active is None and self.device.type == "cuda")
+
+        def decoder_bwd(defer_b0):
+            self.grads.zero_()
+            if comm:
+                # y_W_o's gradient needs only d(logits): reduce it while the recurrence runs
+                self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                             _p(self.grads), act, 1, st), "decoder_train_bwd_part")
+                if not defer_b0:
+                    comm(*self.buckets[0])
+                self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                             _p(self.grads), act, 2, st), "decoder_train_bwd_part")
+            elif self._active is None:
+                self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                        _p(self.grads), st), "decoder_train_bwd")
+            else:
+                self._ck(self.lib.lxo_decoder_train_bwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
+                                                               _p(self.grads), act, st), "decoder_train_bwd_active")
+
+        decoder_bwd(chain)
+        if chain and not self._xdec_bwd_checked:
+            # once per engine, as for the forward chain: a chain that did not assemble leaves an error word -> launch chain from now on
+            self._xdec_bwd_checked = True
+            used, err = self.chain_status(backward=True)
+            self.chain_used_bwd = used and not err
+            if err:
+                self.step_kernels = 2
+                self.shape.step_kernels = 2
+                chain = False
+                decoder_bwd(False)
         if comm:
-            # y_W_o's gradient needs only d(logits): reduce it while the recurrence runs
-            self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                         _p(self.grads), act, 1, st), "decoder_train_bwd_part")
-            comm(*self.buckets[0])
-            self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                         _p(self.grads), act, 2, st), "decoder_train_bwd_part")
+            if chain:
+                comm(*self.buckets[0])
             comm(*self.buckets[1])
-        elif self._active is None:
-            self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                    _p(self.grads), st), "decoder_train_bwd")
-        else:
-            self._ck(self.lib.lxo_decoder_train_bwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                           _p(self.grads), act, st), "decoder_train_bwd_active")
         if phase_hook:
             phase_hook("decoder_bwd")
         if comm:

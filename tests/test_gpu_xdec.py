@@ -67,6 +67,51 @@ def test_chain_equals_launch_per_step(B, H, W):
         B, H, W, la, lb, {k: "%.1e" % v for k, v in worst.items()}, wc[0], wc[1]))
 
 
+@pytest.mark.parametrize("B,H,W,drop", [(64, 64, 256, None), (32, 48, 200, (0.85, 99)), (16, 64, 128, None), (8, 40, 150, (0.9, 7))])
+def test_backward_chain_equals_launch_per_step_backward(B, H, W, drop):
+    """The backward chain alone: ONE forward (the forward chain), then BPTT twice over the same record -- by the persistent backward
+    chain and by the launch-per-step kernels (lxo_shape.step_kernels = 2 for the second lxo_decoder_train_bwd).  Both apply the same
+    expressions to the same operands; a step GEMM's contraction is split over 8 waves instead of 4, so f32 sums differ in their last
+    bits and a bf16 mirror of g_t / d_z_t may round the other way here and there.  Per-step intermediates and every gradient."""
+    img, f, l = batch(B, H, W, V, 5, 24, seed=177 + B)
+    eng = Engine(V, dtype="bf16", seed=9)
+    eng.forward(img, f, dropout=drop)
+    eng.loss(l, 1.0 / int(l.sum()))
+    T = f.shape[1]
+    R = (-(-H // 8) - 2) * (-(-W // 8) - 2)
+    Rp = (R + 7) // 8 * 8
+
+    def snap():
+        torch.cuda.synchronize()
+        out = {"g": eng.region("g", "f32", (T, B, 512)), "dhc": eng.region("dhc", "f32", (T, B, 1024)),
+               "de": eng.region("de", "f32", (T, B, Rp))[:, :, :R], "datth": eng.region("datth", "f32", (T, B, 256)),
+               "dz": eng.region("dz", "f32", (T, B, 2048)), "dxh": eng.region("dxh", "f32", (B, 1024)), "dcc": eng.region("dcc", "f32", (B, 512))}
+        return {k: v.cpu().numpy().copy() for k, v in out.items()}, eng.grad_dict()
+
+    eng.backward()
+    used, err = eng.chain_status(backward=True)
+    assert used and err == 0, (used, err)
+    a, ga = snap()
+    eng.shape.step_kernels = 2                                   # the same record, the launch-per-step kernels
+    eng.backward()
+    b, gb = snap()
+    worst = {}
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        d = np.abs(a[k] - b[k]).max() / max(np.abs(b[k]).max(), 1e-30)
+        worst[k] = float(d)
+        assert d < 2e-2, (k, d)
+        assert cosine(a[k], b[k]) > 0.99999, (k, cosine(a[k], b[k]))
+    wc = (1.0, None)
+    for k in ga:
+        c = cosine(ga[k], gb[k])
+        if c < wc[0]:
+            wc = (c, k)
+        assert c > 0.99995, (k, c)
+    print("B=%d %dx%d drop=%s: backward chain vs launch-per-step: max rel %s; worst gradient cosine %.7f (%s)" % (
+        B, H, W, drop, {k: "%.1e" % v for k, v in worst.items()}, wc[0], wc[1]))
+
+
 def test_chain_with_dropout_equals_launch_per_step():
     a, ga, used, err = _run(0, 16, 48, 160, dropout=(0.8, 1234))
     assert used and err == 0
