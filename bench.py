@@ -175,27 +175,32 @@ def roofline_from_records(recs, family, label, bound, peak, unit):
             "per_launch": {k: {"n": v[0], "us": round(v[2] / v[0] * 1e6, 2), "rate": round(v[1] / v[2] / scale, 1)} for k, v in sorted(per.items())}}
 
 
-def chain_phases(eng, torch):
-    """Per-phase time of one step of the persistent XCD-local decoder chain (csrc/xdec.hip) from its in-kernel 100 MHz timestamps
-    (lxo_xdec_debug): mean over the 256 workgroups and the steps of one more decoder forward on the bound shape.  None when the
-    chain does not run for this engine."""
+def chain_phases(eng, torch, backward=False):
+    """Per-phase time of one step of the persistent XCD-local decoder chain (csrc/xdec.hip; backward=True: its BPTT twin) from the
+    in-kernel 100 MHz timestamps (lxo_xdec_debug / lxo_xdec_debug_bwd): mean over the 256 workgroups and the steps of one more
+    decoder forward (backward) on the bound shape.  None when the chain does not run for this engine."""
     import ctypes
     from latex_ocr_amd.engine import _p
-    used, err = eng.chain_status()
+    used, err = eng.chain_status(backward=backward)
     if not used or err:
         return None
     T = int(eng.shape.T)
     buf = torch.zeros(256 * T * 16, dtype=torch.int64, device=eng.device)
-    eng.lib.lxo_xdec_debug.argtypes = [ctypes.c_void_p]
-    eng.lib.lxo_xdec_debug(ctypes.c_void_p(buf.data_ptr()))
+    hook = eng.lib.lxo_xdec_debug_bwd if backward else eng.lib.lxo_xdec_debug
+    hook.argtypes = [ctypes.c_void_p]
+    hook(ctypes.c_void_p(buf.data_ptr()))
     try:
-        eng._ck(eng.lib.lxo_decoder_train_fwd(eng.sref(), _p(eng.params), _p(eng.wpack), _p(eng.ws), _p(eng._formula), eng._stream()), "fwd")
+        if backward:
+            eng._ck(eng.lib.lxo_decoder_train_bwd(eng.sref(), _p(eng.params), _p(eng.wpack), _p(eng.ws), _p(eng._formula), _p(eng.grads), eng._stream()), "bwd")
+        else:
+            eng._ck(eng.lib.lxo_decoder_train_fwd(eng.sref(), _p(eng.params), _p(eng.wpack), _p(eng.ws), _p(eng._formula), eng._stream()), "fwd")
         torch.cuda.synchronize()
     finally:
-        eng.lib.lxo_xdec_debug(ctypes.c_void_p(0))
+        hook(ctypes.c_void_p(0))
     s = buf.cpu().numpy().reshape(256, T, 16).astype(np.float64) * 0.01            # us
     d = s[:, 2:, 1:9] - s[:, 2:, 0:8]
-    names = ["P1_lstm", "barrier1", "P2_att_h", "barrier2", "P3_attention_stream", "barrier3", "P4_merge_o", "barrier4"]
+    names = (["Q1_dh_dctx", "barrier1", "Q2_attention_stream", "barrier2", "Q3_lstm_bwd", "barrier3", "Q4_carries", "barrier4"] if backward else
+             ["P1_lstm", "barrier1", "P2_att_h", "barrier2", "P3_attention_stream", "barrier3", "P4_merge_o", "barrier4"])
     out = {n: round(float(d[:, :, i].mean()), 3) for i, n in enumerate(names)}
     out["step_us"] = round(float((s[:, 2:, 8] - s[:, 2:, 0]).mean()), 3)
     return out
@@ -546,7 +551,7 @@ def main():
             # HBM traffic measured in this run (two short PMC passes of this same script); the committed file only if rocprofv3 is unusable
             traffic = None
             if world == 1 and not args.no_pmc:
-                traffic = pmc_traffic_inrun(["conv_halo2wg_kernel", "conv_wgrad_kernel", "xdec_fwd_kernel", "attn_bwd_part_kernel", "attn_fwd_part_kernel", "rstep_kernel"])
+                traffic = pmc_traffic_inrun(["conv_halo2wg_kernel", "conv_wgrad_kernel", "xdec_fwd_kernel", "xdec_bwd_kernel", "attn_bwd_part_kernel", "attn_fwd_part_kernel", "rstep_kernel"])
             if roof is not None:
                 if traffic and "conv_halo2wg_kernel" in traffic:
                     roof["traffic"] = traffic["conv_halo2wg_kernel"]["hbm_bytes_per_launch"]
@@ -586,6 +591,21 @@ def main():
                                                                   "hbm", HBM_PEAK, "GB/s")
             if traffic and out.get("roofline_attention_bwd") and "attn_bwd_part_kernel" in traffic:
                 out["roofline_attention_bwd"]["traffic"] = traffic["attn_bwd_part_kernel"]["hbm_bytes_per_launch"]
+            if out["roofline_attention_bwd"] is None:
+                # BPTT is ONE persistent launch as well (xdec_bwd_kernel): its attention stream is phase Q2
+                ph = chain_phases(eng, torch, backward=True)
+                chain = [r for r in recs if r[0] == "xdec_bwd"]
+                if ph and chain:
+                    bytes_step = chain[0][2] / T
+                    a = bytes_step / (ph["Q2_attention_stream"] * 1e-6)
+                    out["roofline_attention_bwd"] = {
+                        "kernel": "xdec_bwd_kernel, phase Q2 (attention stream of one BPTT step: d_e and d_att_h from att_exp + img streamed once; the other phases are the [d_h~ | d_ctx] / d_att_h W^T / carry GEMMs with the LSTM backward and four XCD barriers)",
+                        "bound": "hbm", "achieved": round(a / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a / HBM_PEAK, 4),
+                        "traffic": (traffic["xdec_bwd_kernel"]["hbm_bytes_per_launch"] / T) if traffic and "xdec_bwd_kernel" in traffic else None,
+                        "launches": 1, "work_per_launch": bytes_step, "avg_launch_us": ph["Q2_attention_stream"],
+                        "chain_us_per_step_by_phase": ph, "chain_ms_per_launch": round(chain[0][3] * 1e3, 4),
+                        "whole_chain_GBps": round(chain[0][2] / chain[0][3] / 1e9, 2),
+                        "source": "in-kernel 100 MHz timestamps (lxo_xdec_debug_bwd), as for the forward chain"}
             out["ms_per_step_by_phase"] = phases
             if world == 1:
                 # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still
