@@ -606,6 +606,14 @@ def main():
                         "chain_us_per_step_by_phase": ph, "chain_ms_per_launch": round(chain[0][3] * 1e3, 4),
                         "whole_chain_GBps": round(chain[0][2] / chain[0][3] / 1e9, 2),
                         "source": "in-kernel 100 MHz timestamps (lxo_xdec_debug_bwd), as for the forward chain"}
+            for key in ("roofline_attention", "roofline_attention_bwd"):
+                r = out.get(key)
+                if r and r.get("traffic") and r.get("avg_launch_us"):
+                    # `achieved` counts ALGORITHMIC bytes (every region row of att_exp + img once per step); consecutive steps walk the chunk in
+                    # opposite directions, so part of them is still in the XCD's L2 -- the PMC traffic is what HBM / Infinity Cache delivered
+                    r["hbm_GBps_from_traffic"] = round(r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9, 1)
+                    r["note"] = ("achieved = algorithmic bytes / phase time; %.0f %% of them are L2 hits (traffic < work_per_launch), so it can exceed the HBM peak: "
+                                 "the memory system delivered hbm_GBps_from_traffic" % (100.0 * (1.0 - r["traffic"] / r["work_per_launch"])))
             out["ms_per_step_by_phase"] = phases
             if world == 1:
                 # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still
