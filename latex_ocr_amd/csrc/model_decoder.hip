@@ -243,7 +243,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
         x.att_exp = P.att_exp() ? P.ws<bf16_t>(ws, W_ATT_EXP) : nullptr;
         x.zx = zx; x.rec = rec; x.recb = P.ws<bf16_t>(ws, W_RECB); x.cs = cs;
         x.gates = P.ws<float>(ws, W_GATES); x.atth = P.ws<float>(ws, W_ATTH); x.alpha = P.ws<float>(ws, W_ALPHA);
-        x.part = P.ws<float>(ws, W_APART); x.sync = P.ws<unsigned>(ws, W_XSYNC);
+        x.part = P.ws<float>(ws, W_APART); x.sync = P.ws<unsigned>(ws, W_XSYNC); x.ll = x.sync + 2048;
         x.T = T; x.B = B; x.R = P.R; x.Rp = P.Rp; x.REC = P.REC; x.RECB = P.RECB;
         x.dr = P.drop(0, 0);
         LxoTimed tm("xdec_fwd", "chain", (double)T * B * P.R * (E + C) * P.esz, st);
@@ -368,6 +368,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             x.dz = dz; x.dzb = dzb; x.DZBP = P.DZBP; x.carry_h = carry_h; x.dcc = dcc; x.dxh = dxh;
             x.part = P.ws<float>(ws, W_APART);                       // the forward chain's chunk partials are dead by now
             x.sync = P.ws<unsigned>(ws, W_XSYNC) + 1024;             // its own block (plan.hip)
+            x.ll = P.ws<unsigned>(ws, W_XSYNC) + 2048;
             x.T = T; x.B = B; x.R = P.R;
             x.dr = P.drop(0, 0);
             LxoTimed tm("xdec_bwd", "chain", (double)T * B * P.R * (E + C) * P.esz, st);

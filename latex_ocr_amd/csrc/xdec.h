@@ -23,6 +23,7 @@ struct XDecFwd {
     float* alpha;                     // [T][B][Rp]
     float* part;                      // [B][nq][C + 2] chunk partials (max, sum, unnormalised context)
     unsigned* sync;                   // [8][64] per-XCD {flag line (32 words), ticket line} + [512] error word; zero on entry
+    unsigned* ll;                     // hand-over words {value, step tag} (kXDecLLBytes, zeroed by the launcher): a consumer polls the DATA, no barrier
     int T, B, R, Rp, REC, RECB;
     Drop dr;                          // dropout of h and o (thr == 0: off); dr.t is set per step
     unsigned long long* dbg;          // measurement aid (null = off): [256 workgroups][T][16] 100 MHz timestamps at the phase boundaries (tools/xdec_stamps.py)
@@ -54,6 +55,7 @@ struct XDecBwd {
     float* dxh;                       // [B][O + U] out: the raw carries of step 0
     float* part;                      // [B][nq][E] d_att_h chunk partials
     unsigned* sync;                   // as in XDecFwd (its own block)
+    unsigned* ll;                     // as in XDecFwd (the same area; the backward chain's words lie behind the forward chain's)
     int T, B, R;
     Drop dr;
     unsigned long long* dbg;          // as in XDecFwd
@@ -64,3 +66,7 @@ extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf);
 extern "C" int lxo_xdec_debug(unsigned long long* buf);
 // bytes of the `sync` block
 constexpr size_t kXDecSyncBytes = (8 * 64 + 64) * 4;
+// the hand-over area behind the two sync blocks (ws region "xdec_sync" at byte 8192): 8-byte words {value, tag}, up to 64 samples
+constexpr size_t kXDecLLBytes = 2u << 20;
+constexpr size_t kLLFwdHt = 0, kLLFwdAh = 128u << 10, kLLFwdO = 256u << 10, kLLFwdEnd = 384u << 10;       // byte offsets: h~ [B][256 pairs], att_h [B][256], o [B][256 pairs]
+constexpr size_t kLLBwdGb = 384u << 10, kLLBwdDctx = 512u << 10, kLLBwdEnd = 768u << 10;                    // g [B][256 pairs], d_ctx [B][512]

@@ -41,6 +41,18 @@ constexpr int XU = 512, XO = 512, XC = 512, XE = 256;           // the shipped a
 constexpr int XXH = XO + XU, XHC = XU + XC;
 constexpr int OFF_H = XO, OFF_HT = XO + XU, OFF_CTX = XO + 2 * XU;
 constexpr int XW = 8;                                            // waves per workgroup
+// which hand-overs of the forward chain are polled from {value, tag} words instead of meeting at an XCD barrier: 1 = h~ (P1 -> P2),
+// 2 = att_h (P2 -> P3), 8 = o (P4 -> the next step's P1).  A compile-time choice (a run-time one costs registers the chain does not have);
+// `make EXTRA=-DLXO_XDEC_LLMASK=0` builds the all-barriers variant for A/B runs (LXO_LIB_PATH selects the library).
+#ifndef LXO_XDEC_LLMASK
+#define LXO_XDEC_LLMASK 11
+#endif
+constexpr int kLL = LXO_XDEC_LLMASK;
+// the same for the backward chain: 1 = g_{t-1} (Q4 -> the next step's Q1), 2 = d_ctx (Q1 -> Q2)
+#ifndef LXO_XDEC_LLMASK_B
+#define LXO_XDEC_LLMASK_B 3
+#endif
+constexpr int kLLB = LXO_XDEC_LLMASK_B;
 constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
 constexpr int SCMAX = 2048;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB)
 
@@ -81,6 +93,27 @@ LXO_DEV void xbar(unsigned* flags, int rank, unsigned ph, unsigned* err, int* s_
         }
     }
     __syncthreads();
+}
+
+// Hand-over WITHOUT a barrier: the producer stores 8-byte words {value, tag} (one store, so the pair arrives together), the consumer
+// polls the words it needs until every tag is the current step's.  Saves the producer's wait for its store acknowledgements, the flag
+// round trip and the consumer's separate load behind the barrier (~1 us of the 1.0 + 0.5 a barrier-and-load costs inside the chain).
+// ll_wait: all lanes of the wave load `N` 16-byte pieces (two words each) and repeat until all their tags match; 200 ms timeout as in xbar.
+template <int N>
+LXO_DEV bool ll_wait(u32x4 (&w)[N], rsrc_t r, const unsigned (&off)[N], unsigned tag, unsigned* err, int* s_dead) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { w[j] = l2_load16(r, off[j]); }
+#pragma unroll
+        for (int j = 0; j < N; ++j) ok = ok && w[j][1] == tag && w[j][3] == tag;
+        if (__ballot(!ok) == 0ull) return true;
+        if (*s_dead || wall_clock64() - t0 > 20000000ull) {
+            if ((threadIdx.x & 63) == 0) { *s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 3u; }
+            return false;
+        }
+    }
 }
 
 // One block of ATT_U rows per wave of the attention chunk: scores from the att_img rows (raw bf16 words in xa), online-softmax update of
@@ -180,13 +213,15 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     // ---- resident weights: this wave's eighth of every contraction, as MFMA B fragments (lane = (column r16, k group g4)) ----
     // K_LSTM_RT: gate i in registers, gates j, f, o in LDS (96 KB, fragment-shaped: [wave][gate][k-step][lane] x 16 B, read back by the
     // lane that wrote it) -- 88 resident VGPRs left no room for the attention stream's two row blocks in flight
+    // P1's contraction index [o (512) | h (512)]: k-steps 0, 1 of a wave lie in o (polled hand-over words), 2, 3 in h (plain loads)
+#define P1K(ks) ((ks) < 2 ? wave * 64 + (ks) * 32 : XO + wave * 64 + ((ks) - 2) * 32)
     u32x4 wrt0[4], wah[2], wow[4];
     u32x4* wl = reinterpret_cast<u32x4*>(xdec_dyn_lds) + (wave * 12) * 64 + lane;       // + (gate - 1) * 4 * 64 + ks * 64
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wrt + (long long)(q * XU + u0 + r16) * p.ldrt + wave * 128 + ks * 32 + g4 * 8);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wrt + (long long)(q * XU + u0 + r16) * p.ldrt + P1K(ks) + g4 * 8);
             if (q == 0) wrt0[ks] = w; else wl[((q - 1) * 4 + ks) * 64] = w;
         }
 #pragma unroll
@@ -234,6 +269,12 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) pzn[q] = zr[q * XU];
     }
+    unsigned* ll_ah = p.ll + kLLFwdAh / 4;
+    unsigned* ll_ht = p.ll + kLLFwdHt / 4;
+    unsigned* ll_o = p.ll + kLLFwdO / 4;
+    const rsrc_t rll_ah = make_rsrc(ll_ah, (unsigned)B * XE * 8u);
+    const rsrc_t rll_ht = make_rsrc(ll_ht, (unsigned)B * 256u * 8u);
+    const rsrc_t rll_o = make_rsrc(ll_o, (unsigned)B * 256u * 8u);
     unsigned long long* dbg = p.dbg ? p.dbg + ((long long)(xcc * 32 + rank) * T) * 16 : nullptr;
 #define XSTAMP(i) do { if (dbg && tid == 0) dbg[t * 16 + (i)] = wall_clock64(); } while (0)
     for (int t = 0; t < T; ++t) {
@@ -244,8 +285,21 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
         {
             const rsrc_t rp = make_rsrc(p.recb + sp * p.RECB, (unsigned)B * p.RECB * 2u);
             u32x4 a[4];
+            if ((kLL & 8) && t > 0) {
+                // o_{t-1}: polled from the hand-over words the o projection of the previous step left (no barrier behind P4)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rp, (unsigned)(((b0 + arow) * p.RECB + wave * 128 + ks * 32 + g4 * 8) * 2));
+                for (int ks = 2; ks < 4; ++ks) a[ks] = l2_load16(rp, (unsigned)(((b0 + arow) * p.RECB + P1K(ks) + g4 * 8) * 2));
+                u32x4 w[4];
+                unsigned off[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((b0 + arow) * 256 + ((P1K(j >> 1) + g4 * 8) >> 1)) * 8 + (j & 1) * 16);
+                ll_wait<4>(w, rll_o, off, (unsigned)t, err, &s_dead);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[ks] = u32x4{w[2 * ks][0], w[2 * ks][2], w[2 * ks + 1][0], w[2 * ks + 1][2]};
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rp, (unsigned)(((b0 + arow) * p.RECB + P1K(ks) + g4 * 8) * 2));
+            }
             // the x-part of this thread's epilogue element: requested one step ahead (at the start of the previous step's P3) -- zx_t was
             // written before the launch and comes from HBM, 2 us away; asked for here it was the critical path of the phase
             float pz[4];
@@ -294,18 +348,33 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 float* rr = p.rec + (sn + bb) * p.REC;
                 bf16_t* rb = p.recb + (sn + bb) * p.RECB;
                 rr[OFF_H + u] = h; rr[OFF_HT + u] = ht;
-                rb[OFF_H + u] = f2bf(h); rb[OFF_HT + u] = f2bf(ht);
+                const bf16_t htb = f2bf(ht);
+                rb[OFF_H + u] = f2bf(h); rb[OFF_HT + u] = htb;
+                // hand-over words for P2: two units per word (the even lane of a pair stores)
+                const unsigned mine = (unsigned)htb, other = (unsigned)__shfl_xor((int)mine, 1);
+                if (!(eu & 1)) { const u32x2 wv = {mine | (other << 16), (unsigned)(t + 1)}; *reinterpret_cast<u32x2*>(ll_ht + ((bb * 256 + (u >> 1)) * 2)) = wv; }
             }
         }
         XSTAMP(1);
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        if (kLL & 1) __syncthreads();                       // (the partial tiles in LDS are rewritten by P2)
+        else xbar(xsync, rank, ++ph, err, &s_dead);
         XSTAMP(2);
         // =========================== P2: att_h = h~ W ===========================
         const rsrc_t rn = make_rsrc(p.recb + sn * p.RECB, (unsigned)B * p.RECB * 2u);
         {
             u32x4 a[2];
+            if (kLL & 1) {
+                u32x4 w[4];
+                unsigned off[4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a[ks] = l2_load16(rn, (unsigned)(((b0 + arow) * p.RECB + OFF_HT + wave * 64 + ks * 32 + g4 * 8) * 2));
+                for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((b0 + arow) * 256 + ((wave * 64 + (j >> 1) * 32 + g4 * 8) >> 1)) * 8 + (j & 1) * 16);
+                ll_wait<4>(w, rll_ht, off, (unsigned)(t + 1), err, &s_dead);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[ks] = u32x4{w[2 * ks][0], w[2 * ks][2], w[2 * ks + 1][0], w[2 * ks + 1][2]};
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[ks] = l2_load16(rn, (unsigned)(((b0 + arow) * p.RECB + OFF_HT + wave * 64 + ks * 32 + g4 * 8) * 2));
+            }
             v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) acc = mfma16(a[ks], wah[ks], acc);
@@ -320,10 +389,12 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
 #pragma unroll
                 for (int w = 0; w < XW; ++w) v += red[w][row][e];
                 p.atth[(sp + b0 + row) * XE + e0 + e] = v;
+                const u32x2 wv = {__float_as_uint(v), (unsigned)(t + 1)};
+                *reinterpret_cast<u32x2*>(ll_ah + ((b0 + row) * XE + e0 + e) * 2) = wv;      // the attention workgroups poll these words: no barrier
             }
         }
         XSTAMP(3);
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        if (!(kLL & 2)) xbar(xsync, rank, ++ph, err, &s_dead);
         XSTAMP(4);
         // =========================== P3: attention chunk (scores, online softmax, context) ===========================
         {
@@ -333,12 +404,12 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pzn[q] = zr[q * XU];
             }
-            const rsrc_t ra = make_rsrc(p.atth + sp * XE, (unsigned)B * XE * 4u);
-            const u32x4 a4 = l2_load16(ra, (unsigned)((ab * XE + lane * 4) * 4));
+            u32x4 aw[2];
+            { const unsigned off[2] = {(unsigned)((ab * XE + lane * 4) * 8), (unsigned)((ab * XE + lane * 4) * 8 + 16)}; ll_wait<2>(aw, rll_ah, off, (unsigned)(t + 1), err, &s_dead); }
             float ah[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ah[j] = __uint_as_float(a4[j]);
+                ah[j] = __uint_as_float(aw[j >> 1][(j & 1) * 2]);      // (behind a barrier the tags already match: one pass)
                 if constexpr (EXPD) ah[j] = __builtin_amdgcn_exp2f(fminf(fmaxf(ah[j] * 2.8853900817779268f, -60.f), 60.f));      // E_a
             }
             const int c0 = lane * 8;
@@ -482,11 +553,15 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 const int bb = b0 + row, n = o0 + cc;
                 v = tanh_x(v) * drop_scale(dr, 2u, bb, n, XO);            // o = dropout(tanh(.)) (attention_cell.py:82-83)
                 p.rec[(sn + bb) * p.REC + n] = v;
-                p.recb[(sn + bb) * p.RECB + n] = f2bf(v);
+                const bf16_t vb = f2bf(v);
+                p.recb[(sn + bb) * p.RECB + n] = vb;
+                const unsigned mine = (unsigned)vb, other = (unsigned)__shfl_xor((int)mine, 1);
+                if (!(cc & 1)) { const u32x2 wv = {mine | (other << 16), (unsigned)(t + 1)}; *reinterpret_cast<u32x2*>(ll_o + ((bb * 256 + (n >> 1)) * 2)) = wv; }
             }
         }
         XSTAMP(7);
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        if (kLL & 8) __syncthreads();                       // (the partial tiles in LDS are rewritten by the next step's P1)
+        else xbar(xsync, rank, ++ph, err, &s_dead);
         XSTAMP(8);
     }
 #undef XSTAMP
@@ -647,6 +722,10 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
     for (int q = 0; q < 4; ++q) lg[q] = 0.f;
     const int e3r = min(tid >> 4, NB - 1), e3u = tid & 15;       // Q3 epilogue element of this thread (threads < NB * 16)
     const int e4r = min(tid >> 5, NB - 1), e4c = tid & 31;       // Q1 / Q4 epilogue element (threads < NB * 32)
+    unsigned* ll_gb = p.ll + kLLBwdGb / 4;
+    unsigned* ll_dc = p.ll + kLLBwdDctx / 4;
+    const rsrc_t rll_gb = make_rsrc(ll_gb, (unsigned)B * 256u * 8u);
+    const rsrc_t rll_dc = make_rsrc(ll_dc, (unsigned)B * XC * 8u);
     unsigned long long* dbg = p.dbg ? p.dbg + ((long long)(xcc * 32 + rank) * T) * 16 : nullptr;
 #define XSTAMP(i) do { if (dbg && tid == 0) dbg[(T - 1 - t) * 16 + (i)] = wall_clock64(); } while (0)
     for (int t = T - 1; t >= 0; --t) {
@@ -658,8 +737,19 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
         {
             const rsrc_t rg = make_rsrc(p.gb + sp * p.GBP, (unsigned)B * p.GBP * 2u);
             u32x4 a[2];
+            if ((kLLB & 1) && t < T - 1) {
+                // g_t: polled from the hand-over words Q4 of the previous step left (no barrier behind it)
+                u32x4 w[4];
+                unsigned off[4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a[ks] = l2_load16(rg, (unsigned)(((b0 + arow) * p.GBP + wave * 64 + ks * 32 + g4 * 8) * 2));
+                for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((b0 + arow) * 256 + ((wave * 64 + (j >> 1) * 32 + g4 * 8) >> 1)) * 8 + (j & 1) * 16);
+                ll_wait<4>(w, rll_gb, off, (unsigned)(t + 1), err, &s_dead);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[ks] = u32x4{w[2 * ks][0], w[2 * ks][2], w[2 * ks + 1][0], w[2 * ks + 1][2]};
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[ks] = l2_load16(rg, (unsigned)(((b0 + arow) * p.GBP + wave * 64 + ks * 32 + g4 * 8) * 2));
+            }
             v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) { acc[0] = mfma16(a[ks], wow[0][ks], acc[0]); acc[1] = mfma16(a[ks], wow[1][ks], acc[1]); }
@@ -675,17 +765,31 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
 #pragma unroll
                 for (int w = 0; w < XW; ++w) v += red[w][e4r][e4c];
                 p.dhc[(sp + b0 + e4r) * XHC + n0 + e4c] = v;
+                if ((kLLB & 2) && n0 >= XU) {                     // the d_ctx half: hand-over words for the attention workgroups
+                    const u32x2 wv = {__float_as_uint(v), (unsigned)(t + 1)};
+                    *reinterpret_cast<u32x2*>(ll_dc + (((b0 + e4r) * XC + (n0 - XU) + e4c) * 2)) = wv;
+                }
             }
         }
         XSTAMP(1);
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        if (!(kLLB & 2)) xbar(xsync, rank, ++ph, err, &s_dead);
         XSTAMP(2);
         // =========================== Q2: attention stream ===========================
         {
-            const u32x4 d0 = l2_load16(rdh, (unsigned)((ab * XHC + XU + lane * 8) * 4)), d1 = l2_load16(rdh, (unsigned)((ab * XHC + XU + lane * 8 + 4) * 4));
             float dc[8], ah[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (kLLB & 2) {
+                u32x4 w[4];
+                unsigned off[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { dc[e] = __uint_as_float(d0[e]); dc[4 + e] = __uint_as_float(d1[e]); }
+                for (int j = 0; j < 4; ++j) off[j] = (unsigned)((ab * XC + lane * 8 + 2 * j) * 8);
+                ll_wait<4>(w, rll_dc, off, (unsigned)(t + 1), err, &s_dead);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dc[e] = __uint_as_float(w[e >> 1][(e & 1) * 2]);
+            } else {
+                const u32x4 d0 = l2_load16(rdh, (unsigned)((ab * XHC + XU + lane * 8) * 4)), d1 = l2_load16(rdh, (unsigned)((ab * XHC + XU + lane * 8 + 4) * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dc[e] = __uint_as_float(d0[e]); dc[4 + e] = __uint_as_float(d1[e]); }
+            }
             float s = 0.f;                                       // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r: every wave forms it by itself
 #pragma unroll
             for (int e = 0; e < 4; ++e) s = fmaf(cx0[e], dc[e], fmaf(cx1[e], dc[4 + e], s));
@@ -830,12 +934,18 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
                     const float th = (dq.thr == 0u) ? qo : qo / dq.inv_keep;   // rec holds the dropped o; where the mask is 1 tanh = o * keep
                     const float g = (qd + v) * sc * (1.f - th * th);
                     p.gall[(sp - B + bb) * XO + n] = g;
-                    p.gb[(sp - B + bb) * p.GBP + n] = f2bf(g);
+                    const bf16_t gbv = f2bf(g);
+                    p.gb[(sp - B + bb) * p.GBP + n] = gbv;
+                    if (kLLB & 1) {                              // hand-over words for the next step's Q1: two columns per word
+                        const unsigned mine = (unsigned)gbv, other = (unsigned)__shfl_xor((int)mine, 1);
+                        if (!(e4c & 1)) { const u32x2 wv = {mine | (other << 16), (unsigned)t}; *reinterpret_cast<u32x2*>(ll_gb + ((bb * 256 + (n >> 1)) * 2)) = wv; }
+                    }
                 } else p.carry_h[(long long)bb * XU + (n - XO)] = v;
             }
         }
         XSTAMP(7);
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        if (kLLB & 1) __syncthreads();                           // (the partial tiles in LDS are rewritten by the next step's Q1)
+        else xbar(xsync, rank, ++ph, err, &s_dead);
         XSTAMP(8);
     }
 #undef XSTAMP
@@ -878,6 +988,8 @@ int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream
     }
     if (!dev_ok) return -2;
     HIPRC(hipMemsetAsync(p.sync, 0, kXDecSyncBytes, st));
+    HIPRC(hipMemsetAsync(p.ll, 0, kLLFwdEnd, st));                // tags of an earlier launch must not pass for this one's
+
     // rows per wave and block (two blocks in flight).  4: the largest count whose two blocks + the resident weights fit the register file
     // without spills (5 .. 7 spill 68 .. 208 bytes per lane into the serial phases and lose more there than their fewer padded rows gain:
     // 23.9 / 28.9 / 28.3 us per step against 22.2, profiles/r04_xdec_stamps_v2.txt).  LXO_XDEC_U = 4 .. 7 forces one (measurement).
@@ -912,6 +1024,7 @@ int lxo_launch_xdec_bwd(const XDecBwd& p0, int U, int O, int C, int E, hipStream
     if (dev_ok < 0) dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
     if (!dev_ok) return -2;
     HIPRC(hipMemsetAsync(p.sync, 0, kXDecSyncBytes, st));
+    HIPRC(hipMemsetAsync(reinterpret_cast<char*>(p.ll) + kLLBwdGb, 0, kLLBwdEnd - kLLBwdGb, st));
     switch (nb) {
     case 1: return launch_bwd_nb<1>(p, st);
     case 2: return launch_bwd_nb<2>(p, st);
