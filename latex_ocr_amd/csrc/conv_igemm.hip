@@ -374,6 +374,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         w_lane[ks] = (int)wst_off + (lane & 31) * 64 + (((2 * ks + khalf) ^ (((lane & 31) >> 2) & 3)) << 4);
 
     const int nchunk = p.Cin / WKC;
+    // A tile whose last two rows lie below the image (conv6 forward: 14 output rows in two 8-row tiles) skips their MFMAs and fragment
+    // reads: 12.5 % of that launch's matrix work.  Wave-uniform (scalar branch); the accumulators of those rows keep the bias and are
+    // masked by every epilogue like any row >= Ho.
+    const bool short_tile = __builtin_amdgcn_readfirstlane((RI == 8 && oy0 + 6 >= p.Ho) ? 1 : 0) != 0;
 #define CSTAMP(i) do { if (p.dbg && tid == 0 && (i) < 64) p.dbg[(long long)bid * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
     CSTAMP(0);
     if (p.dbg && tid == 0) p.dbg[(long long)bid * 64 + 63] = __builtin_amdgcn_s_getreg(63492);      // HW_ID: which CU / SIMD this workgroup landed on
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
             bfr[1] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + w_lane[1] + (tap % 3) * WWSTAGE);
 #pragma unroll
             for (int i = 0; i < RI; ++i) {
+                if (RI == 8 && i >= 6 && short_tile) continue;
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[0]),
                                                                  __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
                 af[i] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + a_lane + ((i + kh) * QPW + kw) * WPIX + 32);
@@ -435,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
             const int kh1 = (tap + 1) / 3, kw1 = (tap + 1) % 3;
 #pragma unroll
             for (int i = 0; i < RI; ++i) {
+                if (RI == 8 && i >= 6 && short_tile) continue;      // (the bookkeeping below sits at i == 0 and i == RI - 3)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[1]),
                                                                  __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
                 if (i == 0 && (tap + 3 < 9 || !last)) issue_w(tap + 3 < 9 ? c : c + 1, t3, tap % 3);
