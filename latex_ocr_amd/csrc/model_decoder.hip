@@ -243,7 +243,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
         x.att_exp = P.att_exp() ? P.ws<bf16_t>(ws, W_ATT_EXP) : nullptr;
         x.zx = zx; x.rec = rec; x.recb = P.ws<bf16_t>(ws, W_RECB); x.cs = cs;
         x.gates = P.ws<float>(ws, W_GATES); x.atth = P.ws<float>(ws, W_ATTH); x.alpha = P.ws<float>(ws, W_ALPHA);
-        x.part = P.ws<float>(ws, W_APART); x.sync = P.ws<unsigned>(ws, W_XSYNC); x.ll = x.sync + 2048;
+        x.part = P.ws<float>(ws, W_APART); x.sync = P.ws<unsigned>(ws, W_XSYNC);
         x.T = T; x.B = B; x.R = P.R; x.Rp = P.Rp; x.REC = P.REC; x.RECB = P.RECB;
         x.dr = P.drop(0, 0);
         LxoTimed tm("xdec_fwd", "chain", (double)T * B * P.R * (E + C) * P.esz, st);
@@ -321,8 +321,14 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     }
     if (!(parts & 2)) return 0;
 
-    HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
-    HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));     // attention chunks accumulate d_att_h with atomics
+    // the launch-per-step kernels accumulate d_c in place and d_att_h with atomics; the backward chain writes both with plain stores
+    const bool want_chain = fused && P.bf && !active && P.s.step_kernels == 0;
+    auto zero_acc = [&]() -> int {
+        HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
+        HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));
+        return 0;
+    };
+    if (!want_chain) RC(zero_acc());
     if (active) {    // rows of skipped steps must read as zero in the deferred all-step GEMMs below
         HIPRC(hipMemsetAsync(gall, 0, (size_t)TB * O * 4, st));
         HIPRC(hipMemsetAsync(dhc, 0, (size_t)TB * P.HC * 4, st));
@@ -354,7 +360,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_k_tanh_bwd(dolog + (size_t)t_last * B * O, O, kNoSlabs, rec + (size_t)(t_last + 1) * B * P.REC, P.REC,
                           gall + (size_t)t_last * B * O, O, bf ? gb + (size_t)t_last * B * P.GBP : nullptr, P.GBP, P.drop(t_last, 0), 0, n_last, O, st));
         bool chain_done = false;
-        if (bf && !active && P.s.step_kernels == 0) {
+        if (want_chain) {
             // the whole recurrence in one launch (xdec.hip, the backward chain); -2 = the shape does not qualify
             XDecBwd x; memset(&x, 0, sizeof(x));
             x.Wow = (const bf16_t*)P.pk(wp, K_OW); x.ldow = P.ldOW;
@@ -367,14 +373,14 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             x.dolog = dolog; x.gall = gall; x.gb = gb; x.GBP = P.GBP; x.dhc = dhc; x.de = de; x.datth = datth;
             x.dz = dz; x.dzb = dzb; x.DZBP = P.DZBP; x.carry_h = carry_h; x.dcc = dcc; x.dxh = dxh;
             x.part = P.ws<float>(ws, W_APART);                       // the forward chain's chunk partials are dead by now
-            x.sync = P.ws<unsigned>(ws, W_XSYNC) + 1024;             // its own block (plan.hip)
-            x.ll = P.ws<unsigned>(ws, W_XSYNC) + 2048;
+            x.sync = P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4;      // its own block
             x.T = T; x.B = B; x.R = P.R;
             x.dr = P.drop(0, 0);
             LxoTimed tm("xdec_bwd", "chain", (double)T * B * P.R * (E + C) * P.esz, st);
             const int rc = lxo_launch_xdec_bwd(x, U, O, C, E, st);
             if (rc == 0) chain_done = true;
             else if (rc != -2) return rc < 0 ? rc : -rc;
+            else RC(zero_acc());
         }
         RStep a; memset(&a, 0, sizeof(a));
         a.U = U; a.O = O; a.zx_row = -1;

@@ -140,7 +140,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_M4] = (bf && !cnn) ? BL * H4 * W2 * 256 : 0;
     wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
     wb[W_ATT_EXP] = bf ? BL * R * E * esz : 0;
-    wb[W_XSYNC] = 8192 + (bf ? (2u << 20) : 0);    // the forward chain's block at 0, the backward chain's at 4096 (xdec.h: kXDecSyncBytes each), the hand-over words at 8192 (kXDecLLBytes)
+    wb[W_XSYNC] = bf ? 2 * ((size_t)4096 + (384u << 10)) : 8192;     // one block per chain, forward then backward (xdec.h: kXDecBlockBytes)
     if (!bf) {        // the largest user: d_beta, one E-vector per (sample, 16 regions) workgroup; column sums use at most 1024 row blocks x 4U columns
         size_t need = BL * (size_t)((R + 15) / 16) * E * f4;
         const size_t floor_ = (size_t)1024 * (4 * U > 2048 ? 4 * U : 2048) * f4;

@@ -22,8 +22,7 @@ struct XDecFwd {
     float* atth;                      // [T][B][E]
     float* alpha;                     // [T][B][Rp]
     float* part;                      // [B][nq][C + 2] chunk partials (max, sum, unnormalised context)
-    unsigned* sync;                   // [8][64] per-XCD {flag line (32 words), ticket line} + [512] error word; zero on entry
-    unsigned* ll;                     // hand-over words {value, step tag} (kXDecLLBytes, zeroed by the launcher): a consumer polls the DATA, no barrier
+    unsigned* sync;                   // this chain's block of ws region "xdec_sync" (kXDecBlockBytes, see below; zeroed by the launcher)
     int T, B, R, Rp, REC, RECB;
     Drop dr;                          // dropout of h and o (thr == 0: off); dr.t is set per step
     unsigned long long* dbg;          // measurement aid (null = off): [256 workgroups][T][16] 100 MHz timestamps at the phase boundaries (tools/xdec_stamps.py)
@@ -55,7 +54,6 @@ struct XDecBwd {
     float* dxh;                       // [B][O + U] out: the raw carries of step 0
     float* part;                      // [B][nq][E] d_att_h chunk partials
     unsigned* sync;                   // as in XDecFwd (its own block)
-    unsigned* ll;                     // as in XDecFwd (the same area; the backward chain's words lie behind the forward chain's)
     int T, B, R;
     Drop dr;
     unsigned long long* dbg;          // as in XDecFwd
@@ -64,9 +62,9 @@ int lxo_launch_xdec_bwd(const XDecBwd& p, int U, int O, int C, int E, hipStream_
 extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf);
 // measurement aid: the next launches of this host thread stamp their phases into buf (null = off)
 extern "C" int lxo_xdec_debug(unsigned long long* buf);
-// bytes of the `sync` block
-constexpr size_t kXDecSyncBytes = (8 * 64 + 64) * 4;
-// the hand-over area behind the two sync blocks (ws region "xdec_sync" at byte 8192): 8-byte words {value, tag}, up to 64 samples
-constexpr size_t kXDecLLBytes = 2u << 20;
-constexpr size_t kLLFwdHt = 0, kLLFwdAh = 128u << 10, kLLFwdO = 256u << 10, kLLFwdEnd = 384u << 10;       // byte offsets: h~ [B][256 pairs], att_h [B][256], o [B][256 pairs]
-constexpr size_t kLLBwdGb = 384u << 10, kLLBwdDctx = 512u << 10, kLLBwdEnd = 768u << 10;                    // g [B][256 pairs], d_ctx [B][512]
+// One block per chain in ws region "xdec_sync": [sync words, 4096 B: per-XCD flag line + ticket line, error word at [512]]
+// [hand-over words, 384 KB: 8-byte {value, tag} pairs for up to 64 samples]; the launcher zeroes the whole block (tags of an earlier
+// launch must not pass for this one's).  Forward chain: block 0, backward chain: block 1.
+constexpr size_t kXDecSyncBytes = 4096, kXDecLLBytes = 384u << 10, kXDecBlockBytes = kXDecSyncBytes + kXDecLLBytes;
+constexpr size_t kLLFwdHt = 0, kLLFwdAh = 128u << 10, kLLFwdO = 256u << 10;      // h~ [B][256 pairs], att_h [B][256], o [B][256 pairs]
+constexpr size_t kLLBwdGb = 0, kLLBwdDctx = 128u << 10;                          // g [B][256 pairs], d_ctx [B][512]

@@ -269,9 +269,9 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) pzn[q] = zr[q * XU];
     }
-    unsigned* ll_ah = p.ll + kLLFwdAh / 4;
-    unsigned* ll_ht = p.ll + kLLFwdHt / 4;
-    unsigned* ll_o = p.ll + kLLFwdO / 4;
+    unsigned* ll_ah = p.sync + kXDecSyncBytes / 4 + kLLFwdAh / 4;
+    unsigned* ll_ht = p.sync + kXDecSyncBytes / 4 + kLLFwdHt / 4;
+    unsigned* ll_o = p.sync + kXDecSyncBytes / 4 + kLLFwdO / 4;
     const rsrc_t rll_ah = make_rsrc(ll_ah, (unsigned)B * XE * 8u);
     const rsrc_t rll_ht = make_rsrc(ll_ht, (unsigned)B * 256u * 8u);
     const rsrc_t rll_o = make_rsrc(ll_o, (unsigned)B * 256u * 8u);
@@ -722,8 +722,8 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
     for (int q = 0; q < 4; ++q) lg[q] = 0.f;
     const int e3r = min(tid >> 4, NB - 1), e3u = tid & 15;       // Q3 epilogue element of this thread (threads < NB * 16)
     const int e4r = min(tid >> 5, NB - 1), e4c = tid & 31;       // Q1 / Q4 epilogue element (threads < NB * 32)
-    unsigned* ll_gb = p.ll + kLLBwdGb / 4;
-    unsigned* ll_dc = p.ll + kLLBwdDctx / 4;
+    unsigned* ll_gb = p.sync + kXDecSyncBytes / 4 + kLLBwdGb / 4;
+    unsigned* ll_dc = p.sync + kXDecSyncBytes / 4 + kLLBwdDctx / 4;
     const rsrc_t rll_gb = make_rsrc(ll_gb, (unsigned)B * 256u * 8u);
     const rsrc_t rll_dc = make_rsrc(ll_dc, (unsigned)B * XC * 8u);
     unsigned long long* dbg = p.dbg ? p.dbg + ((long long)(xcc * 32 + rank) * T) * 16 : nullptr;
@@ -987,8 +987,7 @@ int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream
         dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
     }
     if (!dev_ok) return -2;
-    HIPRC(hipMemsetAsync(p.sync, 0, kXDecSyncBytes, st));
-    HIPRC(hipMemsetAsync(p.ll, 0, kLLFwdEnd, st));                // tags of an earlier launch must not pass for this one's
+    HIPRC(hipMemsetAsync(p.sync, 0, kXDecBlockBytes, st));
 
     // rows per wave and block (two blocks in flight).  4: the largest count whose two blocks + the resident weights fit the register file
     // without spills (5 .. 7 spill 68 .. 208 bytes per lane into the serial phases and lose more there than their fewer padded rows gain:
@@ -1023,8 +1022,7 @@ int lxo_launch_xdec_bwd(const XDecBwd& p0, int U, int O, int C, int E, hipStream
     static int dev_ok = -1;
     if (dev_ok < 0) dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
     if (!dev_ok) return -2;
-    HIPRC(hipMemsetAsync(p.sync, 0, kXDecSyncBytes, st));
-    HIPRC(hipMemsetAsync(reinterpret_cast<char*>(p.ll) + kLLBwdGb, 0, kLLBwdEnd - kLLBwdGb, st));
+    HIPRC(hipMemsetAsync(p.sync, 0, kXDecBlockBytes, st));
     switch (nb) {
     case 1: return launch_bwd_nb<1>(p, st);
     case 2: return launch_bwd_nb<2>(p, st);

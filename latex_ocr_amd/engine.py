@@ -177,6 +177,30 @@ class Engine(object):
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
+    def _lengths_dev(self, lengths):
+        """Formula lengths on the device WITHOUT stalling the host: a pageable host array goes through a small ring of pinned staging
+        buffers and an asynchronous copy.  (A plain `.to(device)` of pageable memory blocks the host until the compute stream has
+        drained -- in the middle of a step that is the whole decoder forward: the kernels behind it were then enqueued ~30 us late.)"""
+        if isinstance(lengths, torch.Tensor) or self.device.type != "cuda":
+            return self._to_dev(lengths, torch.int32)
+        a = np.ascontiguousarray(lengths, dtype=np.int32).reshape(-1)
+        n = int(a.shape[0])
+        ring = getattr(self, "_len_ring", None)
+        if not ring or ring[0]["host"].numel() < n:
+            cap = max(64, n)
+            ring = [{"host": torch.empty(cap, dtype=torch.int32).pin_memory(), "dev": torch.empty(cap, dtype=torch.int32, device=self.device), "ev": None}
+                    for _ in range(4)]
+            self._len_ring, self._len_i = ring, 0
+        slot = ring[self._len_i % len(ring)]
+        self._len_i += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()                             # the copy that last read this staging buffer (four steps ago) is long done
+        slot["host"][:n].numpy()[:] = a
+        slot["dev"][:n].copy_(slot["host"][:n], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record(torch.cuda.current_stream(self.device))
+        return slot["dev"][:n]
+
     # ---------------------------------------------------------------- steps --
     def forward(self, img, formula, dropout=None, active_rows=None, phase_hook=None, before_decoder=None):
         """Encoder + teacher-forced decoder; leaves logits in the workspace.  dropout = (keep_prob, seed)
@@ -215,7 +239,7 @@ class Engine(object):
         backward chain of the last lxo_decoder_train_bwd): used = its 8 x 32 workgroups took their tickets; error != 0 = a chain did not
         assemble (a barrier timed out / an XCD got the wrong number of workgroups) and the step's decoder outputs are invalid.
         Synchronises the device."""
-        o = 1024 if backward else 0                              # the backward chain's block (plan.hip: W_XSYNC)
+        o = (4096 + (384 << 10)) // 4 if backward else 0         # the backward chain's block (csrc/xdec.h: kXDecBlockBytes)
         w = self.region("xdec_sync", "i32")[o:o + 8 * 64 + 1].cpu().numpy()
         return bool(w[32:512:64].any()), int(w[512])
 
@@ -242,7 +266,7 @@ class Engine(object):
     def loss(self, lengths, inv_ntok=None, ntok_dev=None, ntok_event=None):
         """Loss statistics + d(logits).  Either inv_ntok (host float) or ntok_dev (device float32 [1] = the global token count,
         e.g. from DataParallel.sum_count_async; the compute stream waits for ntok_event, the host does not)."""
-        self._lengths = self._to_dev(lengths, torch.int32)
+        self._lengths = self._lengths_dev(lengths)
         if ntok_dev is not None:
             if ntok_event is not None:
                 torch.cuda.current_stream(self.device).wait_event(ntok_event)
