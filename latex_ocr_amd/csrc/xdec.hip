@@ -53,6 +53,7 @@ constexpr int kLL = LXO_XDEC_LLMASK;
 #define LXO_XDEC_LLMASK_B 3
 #endif
 constexpr int kLLB = LXO_XDEC_LLMASK_B;
+
 constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
 constexpr int SCMAX = 2048;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB)
 
@@ -93,6 +94,36 @@ LXO_DEV void xbar(unsigned* flags, int rank, unsigned ph, unsigned* err, int* s_
         }
     }
     __syncthreads();
+}
+
+// Wave-wide sums WITHOUT the LDS crossbar: `__shfl_xor` compiles to ds_bpermute_b32 (an LDS-pipe round trip per butterfly step: 197 ns per
+// dependent 64-lane reduction, tools/dpp_probe.hip); the four steps inside a row of 16 lanes are v_add_f32_dpp (quad_perm, row_half_mirror,
+// row_mirror: the partner's value arrives as an operand modifier), the two across rows v_permlane16_swap / v_permlane32_swap (gfx950):
+// 69 ns, every lane ends with the same bits.  STEP-wise so that the rows of a block can be interleaved.
+template <int CTRL> LXO_DEV float dpp_add(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int STEP> LXO_DEV float xsum_step(float v) {
+    if constexpr (STEP == 0) return dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]
+    else if constexpr (STEP == 1) return dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+    else if constexpr (STEP == 2) return dpp_add<0x141>(v);      // row_half_mirror
+    else if constexpr (STEP == 3) return dpp_add<0x140>(v);      // row_mirror
+    else if constexpr (STEP == 4) { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); return __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); return __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+}
+// (Measured: decoder backward 2.80 -> 2.72 ms; the forward chain, whose stream phase has the crossbar to spare, 2.42 either way -- also with
+// only the two cross-row steps left on ds_bpermute.)
+template <int N> LXO_DEV void xsum_rows(float (&v)[N]) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = xsum_step<0>(v[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = xsum_step<1>(v[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = xsum_step<2>(v[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = xsum_step<3>(v[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = xsum_step<4>(v[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = xsum_step<5>(v[u]);
 }
 
 // Hand-over WITHOUT a barrier: the producer stores 8-byte words {value, tag} (one store, so the pair arrives together), the consumer
@@ -142,11 +173,7 @@ LXO_DEV void att_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], int b
         }
         pt[u] = a;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
-    }
+    xsum_rows<ATT_U>(pt);
     float mn = m;
 #pragma unroll
     for (int u = 0; u < ATT_U; ++u) if (base + XW * u < an) mn = fmaxf(mn, pt[u]);
@@ -251,9 +278,9 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     unsigned ph = 0;
     // The chunk is walked in blocks of XW * ATT_U rows, two blocks per loop trip (buffers A and B): block i+1 is in flight while block i is
     // computed, and the FIRST block of the next step is requested before this step's last block is computed -- it lands during P4 / P1 / P2,
-    // so P3 starts on data that is already in registers.  An odd block count is rounded up (the extra block is all clamped rows).
+    // so P3 starts on data that is already in registers.  An odd block count ends on an A half (no padded block: its clamped loads cost 1 / 8 of
+    // the benchmark chunk's requests).
     const int nblk = an > 0 ? (an + XW * ATT_U - 1) / (XW * ATT_U) : 0;
-    const int nblk2 = (nblk + 1) & ~1;
     const int anq = an > 0 ? an : 1;                             // an empty trailing chunk still issues (masked) loads: row 0 of the first sample
     const rsrc_t imq = make_rsrc(an > 0 ? im : p.img, (unsigned)anq * XC * 2u);
     const rsrc_t aiq = make_rsrc(an > 0 ? ai : (EXPD ? p.att_exp : p.att_img), (unsigned)anq * XE * 2u);
@@ -418,19 +445,21 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             for (int e = 0; e < 8; ++e) acc[e] = 0.f;
             // blocks walked in alternating directions from step to step (what this step read last is what the next one reads first: L2 reuse)
             const int rev = t & 1;
-#define XBASE(i, rv) (wave + XW * ATT_U * ((rv) ? nblk2 - 1 - (i) : (i)))
+#define XBASE(i, rv) (wave + XW * ATT_U * ((rv) ? nblk - 1 - (i) : (i)))
             // entering: block 0 in A and block 1 in B (requested at the end of the previous step's P3).  Each buffer is refilled right
             // after its block is computed -- with the block two ahead, or, at the end of the chunk, with the NEXT STEP's first two blocks
             // (its direction is the other one): they land during P4 / P1 / P2
-            for (int it = 0; it < nblk2; it += 2) {
+            for (int it = 0; it < nblk; it += 2) {
                 att_block<ATT_U, EXPD>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, sc, lane);
                 __builtin_amdgcn_sched_barrier(0);
-                att_load<ATT_U>(xiA, xaA, imq, aiq, (it + 2 < nblk2) ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
+                att_load<ATT_U>(xiA, xaA, imq, aiq, (it + 2 < nblk) ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
                 __builtin_amdgcn_sched_barrier(0);
-                att_block<ATT_U, EXPD>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, sc, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                att_load<ATT_U>(xiB, xaB, imq, aiq, (it + 2 < nblk2) ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
-                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < nblk) {                              // (an odd block count ends on an A half: B already holds the next step's block 1)
+                    att_block<ATT_U, EXPD>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, sc, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    att_load<ATT_U>(xiB, xaB, imq, aiq, (it + 3 < nblk) ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #undef XBASE
             // merge the 8 waves
@@ -612,11 +641,7 @@ LXO_DEV void attb_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], cons
         }
         pt[u] = a;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
-    }
+    xsum_rows<ATT_U>(pt);
 #pragma unroll
     for (int u = 0; u < ATT_U; ++u) {
         const int r = base + XW * u;
@@ -696,13 +721,12 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
     Drop dr = p.dr;
     unsigned ph = 0;
     const int nblk = an > 0 ? (an + XW * ATT_U - 1) / (XW * ATT_U) : 0;
-    const int nblk2 = (nblk + 1) & ~1;
     const int anq = an > 0 ? an : 1;
     const bf16_t* aibase = EXPD ? p.att_exp : p.att_img;
     const rsrc_t imq = make_rsrc(an > 0 ? p.img + ((long long)ab * p.R + ar0) * XC : p.img, (unsigned)anq * XC * 2u);
     const rsrc_t aiq = make_rsrc(an > 0 ? aibase + ((long long)ab * p.R + ar0) * XE : aibase, (unsigned)anq * XE * 2u);
     const long long al_off = an > 0 ? (long long)ab * p.Rp + ar0 : 0;     // + t * B * Rp: this chunk's alpha rows of step t
-#define XBASE(i, rv) (wave + XW * ATT_U * ((rv) ? nblk2 - 1 - (i) : (i)))
+#define XBASE(i, rv) (wave + XW * ATT_U * ((rv) ? nblk - 1 - (i) : (i)))
     u32x4 xiA[ATT_U], xiB[ATT_U]; u32x2 xaA[ATT_U], xaB[ATT_U]; float alA[ATT_U], alB[ATT_U];
     {
         const rsrc_t ral = make_rsrc(p.alpha + (long long)(T - 1) * B * p.Rp + al_off, (unsigned)anq * 4u);
@@ -793,8 +817,7 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
             float s = 0.f;                                       // s = <ctx, d_ctx> = sum_r alpha_r d_alpha_r: every wave forms it by itself
 #pragma unroll
             for (int e = 0; e < 4; ++e) s = fmaf(cx0[e], dc[e], fmaf(cx1[e], dc[4 + e], s));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            { float sv[1] = {s}; xsum_rows<1>(sv); s = sv[0]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 ah[j] = ahn[j];
@@ -805,16 +828,18 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
             const int tn = max(t - 1, 0);
             const rsrc_t ral = make_rsrc(p.alpha + sp * p.Rp + al_off, (unsigned)anq * 4u);
             const rsrc_t raln = make_rsrc(p.alpha + (long long)tn * B * p.Rp + al_off, (unsigned)anq * 4u);
-            for (int it = 0; it < nblk2; it += 2) {
-                const bool more = it + 2 < nblk2;
+            for (int it = 0; it < nblk; it += 2) {
+                const bool moreA = it + 2 < nblk, moreB = it + 3 < nblk;
                 attb_block<ATT_U, EXPD>(xiA, xaA, alA, XBASE(it, rev), an, dc, ah, s, acc, de_row, lane);
                 __builtin_amdgcn_sched_barrier(0);
-                attb_load<ATT_U>(xiA, xaA, alA, imq, aiq, more ? ral : raln, more ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
+                attb_load<ATT_U>(xiA, xaA, alA, imq, aiq, moreA ? ral : raln, moreA ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
                 __builtin_amdgcn_sched_barrier(0);
-                attb_block<ATT_U, EXPD>(xiB, xaB, alB, XBASE(it + 1, rev), an, dc, ah, s, acc, de_row, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                attb_load<ATT_U>(xiB, xaB, alB, imq, aiq, more ? ral : raln, more ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
-                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < nblk) {                              // (an odd block count ends on an A half: B already holds the next step's block 1)
+                    attb_block<ATT_U, EXPD>(xiB, xaB, alB, XBASE(it + 1, rev), an, dc, ah, s, acc, de_row, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    attb_load<ATT_U>(xiB, xaB, alB, imq, aiq, moreB ? ral : raln, moreB ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // forward values of the coming phases (unconditional, clamped indices)
             {
