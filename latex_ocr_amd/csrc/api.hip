@@ -67,7 +67,7 @@ extern "C" int lxo_ws_region_dtype(const lxo_shape* s, const char* name) {
     const bool bf = s->dtype == LXO_BF16;
     static const char* const kCompute[] = {"p1", "y2", "p2", "y3", "y4", "p4", "y5", "p5", "y6", "img", "att_img", "emb_in", "dlogits",
                                            "d_att_img", "g0", "g1", "g2", "cols", "dec_emb", "dec_txe", "rxt"};
-    static const char* const kBf16[] = {"recb", "gb", "dzb", "rhb", "rdzb", "att_exp"};
+    static const char* const kBf16[] = {"recb", "gb", "dzb", "rhb", "rdzb", "att_exp", "datth_b"};
     static const char* const kI32[] = {"dec_ids", "dec_flags", "beam_par"};
     static const char* const kU8[] = {"m2", "m4", "m5"};
     for (const char* n : kCompute) if (strcmp(name, n) == 0) return bf ? LXO_BF16 : LXO_F32;

@@ -323,6 +323,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
 
     // the launch-per-step kernels accumulate d_c in place and d_att_h with atomics; the backward chain writes both with plain stores
     const bool want_chain = fused && P.bf && !active && P.s.step_kernels == 0;
+    bool bwd_chain = false;                              // the backward chain ran (and left the bf16 mirror of d_att_h)
     auto zero_acc = [&]() -> int {
         HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
         HIPRC(hipMemsetAsync(datth, 0, (size_t)TB * E * 4, st));
@@ -370,7 +371,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             x.att_img = (const bf16_t*)att_img; x.img = (const bf16_t*)img;
             x.att_exp = P.att_exp() ? P.ws<bf16_t>(ws, W_ATT_EXP) : nullptr;
             x.rec = rec; x.REC = P.REC; x.cs = cs; x.gates = gates; x.atth = atth; x.alpha = alpha; x.Rp = P.Rp;
-            x.dolog = dolog; x.gall = gall; x.gb = gb; x.GBP = P.GBP; x.dhc = dhc; x.de = de; x.datth = datth;
+            x.dolog = dolog; x.gall = gall; x.gb = gb; x.GBP = P.GBP; x.dhc = dhc; x.de = de; x.datth = datth; x.datthb = P.ws<bf16_t>(ws, W_DATTHB);
             x.dz = dz; x.dzb = dzb; x.DZBP = P.DZBP; x.carry_h = carry_h; x.dcc = dcc; x.dxh = dxh;
             x.part = P.ws<float>(ws, W_APART);                       // the forward chain's chunk partials are dead by now
             x.sync = P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4;      // its own block
@@ -378,7 +379,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             x.dr = P.drop(0, 0);
             LxoTimed tm("xdec_bwd", "chain", (double)T * B * P.R * (E + C) * P.esz, st);
             const int rc = lxo_launch_xdec_bwd(x, U, O, C, E, st);
-            if (rc == 0) chain_done = true;
+            if (rc == 0) chain_done = bwd_chain = true;
             else if (rc != -2) return rc < 0 ? rc : -rc;
             else RC(zero_acc());
         }
@@ -480,7 +481,8 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         const bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         const bf16_t* gb = P.ws<bf16_t>(ws, W_GB); const bf16_t* dzb = P.ws<bf16_t>(ws, W_DZB);
         RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
-        RC(tn(P, false, true, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, datth, E, gw(P_ATT_H), E, TB, U, E, st));         // dW_att_h
+        if (bwd_chain) RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, P.ws<bf16_t>(ws, W_DATTHB), E, gw(P_ATT_H), E, TB, U, E, st));      // dW_att_h
+        else RC(tn(P, false, true, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, datth, E, gw(P_ATT_H), E, TB, U, E, st));
         RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st));           // dK rows 0..D
         RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st));     // dK rows D..
     } else {

@@ -59,6 +59,7 @@ enum WsId {
     W_ATT_EXP,          // bf16 mode: e^{2 att_img} (bf16), what the E-domain attention kernels of the training step read (att_exp)
     W_XSYNC,            // persistent decoder chain (xdec.hip): per-XCD flag lines, tickets, error word
     W_DET,              // f32 parity mode: slots of per-workgroup partial sums for the ordered (atomic-free) reductions (DetScratch)
+    W_DATTHB,           // bf16 mirror of d_att_h [T][B][E], left by the backward chain: operand of the deferred dW_att_h product
     W_COUNT
 };
 

@@ -50,7 +50,7 @@ static const char* kWsNames[W_COUNT] = {
     "cols",
     "rxt", "rzx", "rg", "rc", "rh", "rhb", "rdz", "rdzb", "rdh", "rdcc", "rzero",
     "m2", "m4", "m5",
-    "att_exp", "xdec_sync", "det_part",
+    "att_exp", "xdec_sync", "det_part", "datth_b",
 };
 const char* lxo_ws_name(int id) { return (id >= 0 && id < W_COUNT) ? kWsNames[id] : ""; }
 
@@ -149,6 +149,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     const int nb = s.beam > 1 ? s.beam : 1;
     const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)
     const size_t TB = (size_t)T * B;
+    wb[W_DATTHB] = bf ? TB * E * 2 : 0;
     wb[W_ATT_IMG] = BL * R * E * esz;
     wb[W_APART] = BK_ * 32 * (C + 4) * f4;         // chunk partials of the attention forward: at most 32 chunks per row, [max, sum, context] (the persistent chain pads a partial to C + 4)
     wb[W_MEAN] = BL * C * f4;

@@ -48,6 +48,7 @@ struct XDecBwd {
     float* dhc;                       // [T][B][U + C]
     float* de;                        // [T][B][Rp]
     float* datth;                     // [T][B][E]
+    bf16_t* datthb;                   // [T][B][E] bf16 mirror of it (nullable)
     float* dz; bf16_t* dzb; int DZBP; // [T][B][4U] + mirror
     float* carry_h;                   // [B][U] scratch
     float* dcc;                       // [B][U] out: d_c of the initial state
@@ -60,6 +61,9 @@ struct XDecBwd {
 };
 int lxo_launch_xdec_bwd(const XDecBwd& p, int U, int O, int C, int E, hipStream_t st);
 extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf);
+// test aid: the next forward (bit 0) / backward (bit 1) chain launch of this host thread reports a broken chain (its error word is set
+// behind the kernel), so that the caller's fall-back to the launch-per-step chain can be exercised on hardware that never breaks one
+extern "C" int lxo_xdec_inject_error(int which);
 // measurement aid: the next launches of this host thread stamp their phases into buf (null = off)
 extern "C" int lxo_xdec_debug(unsigned long long* buf);
 // One block per chain in ws region "xdec_sync": [sync words, 4096 B: per-XCD flag line + ticket line, error word at [512]]

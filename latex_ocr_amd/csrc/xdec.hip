@@ -32,6 +32,7 @@ int lxo_launch_xdec_fwd(const XDecFwd&, int, int, int, int, hipStream_t) { retur
 int lxo_launch_xdec_bwd(const XDecBwd&, int, int, int, int, hipStream_t) { return -2; }
 extern "C" int lxo_xdec_debug(unsigned long long*) { return 0; }
 extern "C" int lxo_xdec_debug_bwd(unsigned long long*) { return 0; }
+extern "C" int lxo_xdec_inject_error(int) { return 0; }
 #else
 
 HIP_DYNAMIC_SHARED(char, xdec_dyn_lds)
@@ -893,7 +894,10 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
                 for (int g = 1; g < QS; ++g) { const f32x4 w = *reinterpret_cast<const f32x4*>(&redc[row * QS + g][k4]); v += w; }
                 const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
                 *reinterpret_cast<u32x2*>(&adh[row][k4]) = vb;
-                if (rank == row) *reinterpret_cast<f32x4*>(p.datth + (sp + b0 + row) * XE + k4) = v;      // kept for the deferred dW_att_h product
+                if (rank == row) {                               // kept for the deferred dW_att_h product (f32 + the bf16 mirror its GEMM reads)
+                    *reinterpret_cast<f32x4*>(p.datth + (sp + b0 + row) * XE + k4) = v;
+                    if (p.datthb) *reinterpret_cast<u32x2*>(p.datthb + (sp + b0 + row) * XE + k4) = vb;
+                }
             }
             __syncthreads();
             const u32x4 a = *reinterpret_cast<const u32x4*>(&adh[r16][wave * 32 + g4 * 8]);
@@ -992,7 +996,16 @@ int launch_bwd_nb(const XDecBwd& p, hipStream_t st) {
 }  // namespace
 
 static thread_local unsigned long long* g_xdbg = nullptr;
+static thread_local int g_xinject = 0;
 extern "C" int lxo_xdec_debug(unsigned long long* buf) { g_xdbg = buf; return 0; }
+extern "C" int lxo_xdec_inject_error(int which) { g_xinject = which; return 0; }
+// after a chain launch: the armed test error (word 512 of the chain's block = 7)
+static int inject_after_launch(int bit, unsigned* sync, hipStream_t st) {
+    if (!(g_xinject & bit)) return 0;
+    g_xinject &= ~bit;
+    HIPRC(hipMemsetD32Async((hipDeviceptr_t)(sync + 8 * 64), 7, 1, st));
+    return 0;
+}
 int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream_t st) {
     XDecFwd p = p0;
     p.dbg = g_xdbg;
@@ -1021,12 +1034,15 @@ int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream
     if (forced < 0) { const char* e = getenv("LXO_XDEC_U"); forced = e ? atoi(e) : 0; }
     int att_u = 4;
     if (forced >= 4 && forced <= 7) att_u = forced;
+    int rc;
     switch (nb) {
-    case 1: return launch_nb<1>(p, att_u, st);
-    case 2: return launch_nb<2>(p, att_u, st);
-    case 4: return launch_nb<4>(p, att_u, st);
-    default: return launch_nb<8>(p, att_u, st);
+    case 1: rc = launch_nb<1>(p, att_u, st); break;
+    case 2: rc = launch_nb<2>(p, att_u, st); break;
+    case 4: rc = launch_nb<4>(p, att_u, st); break;
+    default: rc = launch_nb<8>(p, att_u, st); break;
     }
+    if (rc == 0) RC(inject_after_launch(1, p.sync, st));
+    return rc;
 }
 static thread_local unsigned long long* g_xdbg_b = nullptr;
 extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf) { g_xdbg_b = buf; return 0; }
@@ -1048,11 +1064,14 @@ int lxo_launch_xdec_bwd(const XDecBwd& p0, int U, int O, int C, int E, hipStream
     if (dev_ok < 0) dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
     if (!dev_ok) return -2;
     HIPRC(hipMemsetAsync(p.sync, 0, kXDecBlockBytes, st));
+    int rc;
     switch (nb) {
-    case 1: return launch_bwd_nb<1>(p, st);
-    case 2: return launch_bwd_nb<2>(p, st);
-    case 4: return launch_bwd_nb<4>(p, st);
-    default: return launch_bwd_nb<8>(p, st);
+    case 1: rc = launch_bwd_nb<1>(p, st); break;
+    case 2: rc = launch_bwd_nb<2>(p, st); break;
+    case 4: rc = launch_bwd_nb<4>(p, st); break;
+    default: rc = launch_bwd_nb<8>(p, st); break;
     }
+    if (rc == 0) RC(inject_after_launch(2, p.sync, st));
+    return rc;
 }
 #endif

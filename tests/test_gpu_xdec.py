@@ -112,6 +112,51 @@ def test_backward_chain_equals_launch_per_step_backward(B, H, W, drop):
         B, H, W, drop, {k: "%.1e" % v for k, v in worst.items()}, wc[0], wc[1]))
 
 
+def test_engine_falls_back_when_a_chain_reports_an_error():
+    """The chains rely on how the hardware places a 256-workgroup grid; a chain that does not assemble sets an error word and the engine
+    switches to the launch-per-step kernels for good and repeats the call.  No MI355X here has ever broken one, so the error is injected
+    (`lxo_xdec_inject_error`: the word is set behind the kernel): the repeated forward must be the launch chain's bit for bit (no atomics
+    in the forward), the repeated backward its gradients."""
+    import ctypes
+    img, f, l = batch(16, 48, 160, V, 5, 24, seed=31)
+    n = int(l.sum())
+    ref = Engine(V, dtype="bf16", seed=4)
+    ref.step_kernels = 2
+    ref.forward(img, f)
+    sr = ref.loss(l, 1.0 / n).cpu().numpy().copy()
+    T = f.shape[1]
+    lr = ref.region("logits", "f32", (T, 16, (V + 31) // 32 * 32)).cpu().numpy().copy()
+    ref.backward()
+    torch.cuda.synchronize()
+    gr = ref.grad_dict()
+
+    eng = Engine(V, dtype="bf16", seed=4)
+    eng.lib.lxo_xdec_inject_error.argtypes = [ctypes.c_int]
+    eng.lib.lxo_xdec_inject_error(1)                           # the next forward chain launch reports a broken chain
+    eng.forward(img, f)
+    assert eng.step_kernels == 2 and not eng.chain_used         # noticed, switched, repeated
+    s = eng.loss(l, 1.0 / n).cpu().numpy().copy()
+    assert np.array_equal(eng.region("logits", "f32", (T, 16, (V + 31) // 32 * 32)).cpu().numpy(), lr)
+    assert s[1] == sr[1] and abs(s[0] - sr[0]) <= 1e-6 * abs(sr[0])
+    eng.backward()
+    torch.cuda.synchronize()
+    for k, g in eng.grad_dict().items():
+        assert cosine(g, gr[k]) > 0.999999, (k, cosine(g, gr[k]))
+
+    eng2 = Engine(V, dtype="bf16", seed=4)                      # forward chain fine, backward chain reports the error
+    eng2.forward(img, f)
+    assert eng2.chain_used
+    eng2.loss(l, 1.0 / n)
+    eng2.lib.lxo_xdec_inject_error(2)
+    eng2.backward()
+    torch.cuda.synchronize()
+    assert eng2.step_kernels == 2 and not eng2.chain_used_bwd
+    for k, g in eng2.grad_dict().items():
+        assert np.isfinite(g).all() and cosine(g, gr[k]) > 0.9999, (k, cosine(g, gr[k]))
+    eng2.forward(img, f)                                        # and the engine stays on the launch chain
+    assert not eng2.chain_status()[0] or eng2.step_kernels == 2
+
+
 def test_chain_with_dropout_equals_launch_per_step():
     a, ga, used, err = _run(0, 16, 48, 160, dropout=(0.8, 1234))
     assert used and err == 0
