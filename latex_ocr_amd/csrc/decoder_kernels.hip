@@ -1078,6 +1078,70 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     }
 }
 
+// The same with the row held in registers (Vp <= 64 * KV): ONE pass over the logits -- 16-byte loads, a lane owns 4 consecutive columns per
+// quarter of KV -- instead of three passes of 4-byte loads, and every row has its own wave from the start (the three-pass kernel: 31 us for
+// 13 MB at the benchmark shape, a chain of dependent passes per row; this one 8).  bf16 mode: v_exp_f32 (1 ulp); f32 parity mode: expf.
+template <typename CT, int KV>
+__global__ __launch_bounds__(256) void ce_loss_rows_kernel(const float* __restrict__ logits, const int* __restrict__ formula,
+                                                          const int* __restrict__ lengths, CT* __restrict__ dlogits,
+                                                          float* __restrict__ loss_acc, float* __restrict__ loss_part, float inv_ntok, const float* __restrict__ ntok_dev,
+                                                          const unsigned* __restrict__ chain_err, int B, int T, int V, int Vp) {
+    __shared__ float red[8];
+    if (chain_err && blockIdx.x == 0 && threadIdx.x == 0 && chain_err[0] != 0u) atomicAdd(&loss_acc[0], __uint_as_float(0x7fc00000u));
+    if (ntok_dev) inv_ntok = 1.0f / ntok_dev[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ce_sum = 0.f, n_sum = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < T * B; row += gridDim.x * 4) {
+        const int t = row / B, b = row - t * B;
+        const float* lg = logits + (long long)row * Vp;
+        CT* dl = dlogits + (long long)row * Vp;
+        const bool valid = t < lengths[b];
+        int tgt = formula[(long long)b * T + t];
+        tgt = tgt < 0 ? 0 : (tgt >= V ? V - 1 : tgt);
+        const float xt = lg[tgt];
+        float x[KV];
+#pragma unroll
+        for (int q = 0; q < KV / 4; ++q) {
+            const int j0 = 4 * (lane + 64 * q);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lg + (j0 < Vp ? j0 : 0));          // unconditional (clamped) load
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = (j0 + e < V) ? v[e] : -3.0e38f;
+        }
+        float m = x[0];
+#pragma unroll
+        for (int e = 1; e < KV; ++e) m = fmaxf(m, x[e]);
+        m = wave_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int e = 0; e < KV; ++e) l += is_bf16<CT>::value ? __expf(x[e] - m) : expf(x[e] - m);
+        l = wave_sum(l);
+        const float lse = m + logf(l);
+        const float scale = valid ? inv_ntok : 0.f;
+#pragma unroll
+        for (int q = 0; q < KV / 4; ++q) {
+            const int j0 = 4 * (lane + 64 * q);
+            if (j0 >= Vp) continue;
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + e;
+                const float pr = is_bf16<CT>::value ? __expf(x[4 * q + e] - lse) : expf(x[4 * q + e] - lse);
+                g[e] = j < V ? (pr - (j == tgt ? 1.f : 0.f)) * scale : 0.f;
+            }
+            if constexpr (is_bf16<CT>::value) { const u32x2 pk = {pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3])}; *reinterpret_cast<u32x2*>(dl + j0) = pk; }
+            else { const f32x4 gv = {g[0], g[1], g[2], g[3]}; *reinterpret_cast<f32x4*>(dl + j0) = gv; }
+        }
+        if (valid) { ce_sum += lse - xt; n_sum += 1.0f; }
+    }
+    if (lane == 0) { red[wave] = ce_sum; red[4 + wave] = n_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float c = red[0] + red[1] + red[2] + red[3], n = red[4] + red[5] + red[6] + red[7];
+        if (loss_part) { loss_part[2 * blockIdx.x] = c; loss_part[2 * blockIdx.x + 1] = n; }
+        else if (n > 0.f) { atomicAdd(&loss_acc[0], c); atomicAdd(&loss_acc[1], n); }
+    }
+}
+
 // out[n] += sum_m a[m][n]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N, int rows_per_block) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -1626,8 +1690,18 @@ int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hi
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
                   const float* ntok_dev, const unsigned* chain_err, int B, int T, int V, int Vp, DetScratch det, hipStream_t st) {
     int g = cdiv(T * B, 4);
-    if (g > 512) g = 512;
     float* part = (det.p && det.floats >= 1024) ? det.p : nullptr;      // loss_acc is zero on entry (lxo_impl_ce_loss)
+    if (Vp % 4 == 0 && Vp <= 1024 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0) {
+        // a wave per row, the row in registers (one pass); the f32 parity mode keeps at most 512 workgroups (its ordered partial sums)
+        if (g > (part ? 512 : 2048)) g = part ? 512 : 2048;
+#define CE_ROWS(CT_, KV_) LAUNCH((ce_loss_rows_kernel<CT_, KV_>), g, logits, formula, lengths, (CT_*)dlogits, loss_acc, part, inv_ntok, ntok_dev, chain_err, B, T, V, Vp)
+        if (dt == LXO_BF16) { if (Vp <= 256) CE_ROWS(bf16_t, 4); else if (Vp <= 512) CE_ROWS(bf16_t, 8); else CE_ROWS(bf16_t, 16); }
+        else { if (Vp <= 256) CE_ROWS(float, 4); else if (Vp <= 512) CE_ROWS(float, 8); else CE_ROWS(float, 16); }
+#undef CE_ROWS
+        if (part) return lxo_k_det_reduce(part, g, 2, 2, loss_acc, st);
+        DONE;
+    }
+    if (g > 512) g = 512;
     if (dt == LXO_BF16) LAUNCH((ce_loss_kernel<bf16_t>), g, logits, formula, lengths, (bf16_t*)dlogits, loss_acc, part, inv_ntok, ntok_dev, chain_err, B, T, V, Vp);
     else LAUNCH((ce_loss_kernel<float>), g, logits, formula, lengths, (float*)dlogits, loss_acc, part, inv_ntok, ntok_dev, chain_err, B, T, V, Vp);
     if (part) return lxo_k_det_reduce(part, g, 2, 2, loss_acc, st);
