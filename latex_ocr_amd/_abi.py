@@ -112,6 +112,10 @@ def load():
             raise RuntimeError(
                 "latex_ocr_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        try:
+            import torch  # noqa: F401  -- first, so that the library shares the HIP runtime PyTorch carries (load order)
+        except ImportError:
+            pass
         _lib = bind(ctypes.CDLL(LIB_PATH))
         if _lib._lxo_missing:
             raise RuntimeError("liblxo.so lacks entry points: %s" % _lib._lxo_missing)
