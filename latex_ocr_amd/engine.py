@@ -21,6 +21,11 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+# csrc/xdec.h: kXDecBlockBytes -- ws region "xdec_sync" holds one such block per chain (forward, then backward): 4 KB of flag lines, tickets
+# and the error word (word 512) + 384 KB of hand-over words (tests/test_abi.py keeps the two definitions together)
+XDEC_BLOCK_BYTES = 4096 + (384 << 10)
+
+
 class Engine(object):
     def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None, skip_padded=None):
         self.lib = lib if lib is not None else _abi.load()
@@ -239,7 +244,7 @@ class Engine(object):
         backward chain of the last lxo_decoder_train_bwd): used = its 8 x 32 workgroups took their tickets; error != 0 = a chain did not
         assemble (a barrier timed out / an XCD got the wrong number of workgroups) and the step's decoder outputs are invalid.
         Synchronises the device."""
-        o = (4096 + (384 << 10)) // 4 if backward else 0         # the backward chain's block (csrc/xdec.h: kXDecBlockBytes)
+        o = XDEC_BLOCK_BYTES // 4 if backward else 0             # the backward chain's block
         w = self.region("xdec_sync", "i32")[o:o + 8 * 64 + 1].cpu().numpy()
         return bool(w[32:512:64].any()), int(w[512])
 

@@ -87,6 +87,19 @@ def test_ws_region_dtype_follows_the_plan(lib):
     assert lib.lxo_ws_region_dtype(ctypes.byref(s), b"no_such_region") < 0
 
 
+def test_xdec_sync_region_is_two_chain_blocks(lib):
+    """Engine.chain_status reads the error word of the forward / backward chain at block 0 / 1 of region "xdec_sync": the block size the
+    Python side assumes must be the one the plan lays out (csrc/xdec.h: kXDecBlockBytes)."""
+    from latex_ocr_amd.engine import XDEC_BLOCK_BYTES
+    s = _abi.LxoShape(8, 32, 128, 10, 50, 512, 256, 512, 512, 80, _abi.LXO_BF16, 1, 0)
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.lxo_ws_region(ctypes.byref(s), b"xdec_sync", ctypes.byref(off), ctypes.byref(nb)) == 0
+    assert nb.value >= 2 * XDEC_BLOCK_BYTES and off.value % 128 == 0, (off.value, nb.value)
+    s32 = _abi.LxoShape(8, 32, 128, 10, 50, 512, 256, 512, 512, 80, _abi.LXO_F32, 1, 0)      # no chains in f32 mode: the flag words only
+    assert lib.lxo_ws_region(ctypes.byref(s32), b"xdec_sync", ctypes.byref(off), ctypes.byref(nb)) == 0
+    assert 0 < nb.value < XDEC_BLOCK_BYTES
+
+
 def test_no_cpu_fallback():
     import torch
     from latex_ocr_amd.engine import Engine
