@@ -158,6 +158,8 @@ LXO_DEV void att_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], int b
     float pt[ATT_U];
 #pragma unroll
     for (int u = 0; u < ATT_U; ++u) {
+        pt[u] = 0.f;
+        if (base + XW * u >= an) continue;                       // wave-uniform: a clamped row (the chunk's last block) costs its loads, not its arithmetic
         const float x0 = __uint_as_float(xa[u][0] << 16), x1 = __uint_as_float(xa[u][0] & 0xffff0000u);
         const float x2 = __uint_as_float(xa[u][1] << 16), x3 = __uint_as_float(xa[u][1] & 0xffff0000u);
         float a;
@@ -186,8 +188,9 @@ LXO_DEV void att_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], int b
 #pragma unroll
     for (int u = 0; u < ATT_U; ++u) {
         const int r = base + XW * u;
-        const bool ok = r < an;
-        const float pw = ok ? __expf(pt[u] - m) : 0.f;
+        if (r >= an) continue;
+        const bool ok = true;
+        const float pw = __expf(pt[u] - m);
         l += pw;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
