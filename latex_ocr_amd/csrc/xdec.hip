@@ -216,8 +216,12 @@ LXO_DEV void att_load(u32x4 (&xi)[ATT_U], u32x2 (&xa)[ATT_U], rsrc_t rim, rsrc_t
 template <int NB, int ATT_U, bool EXPD>
 __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     constexpr int NQ = 32 / NB;                                  // attention chunks per sample = workgroups per sample
-    __shared__ float red[XW][8][64];                             // cross-wave partial tiles: [wave][row][column]          16 KB
-    __shared__ float redc[XW][XC];                               // P3: the waves' partial contexts                        16 KB
+    // cross-wave partial tiles of the GEMM phases ([wave][row][column]) and the waves' partial contexts of P3 ([wave][channel]) share 16 KB:
+    // the phases that use one are a workgroup barrier away from the phases that use the other
+    __shared__ __attribute__((aligned(16))) float redbuf[XW * 8 * 64];
+    float (*red)[8][64] = reinterpret_cast<float (*)[8][64]>(redbuf);
+    float (*redc)[XC] = reinterpret_cast<float (*)[XC]>(redbuf);
+    __shared__ u32x4 wahs[XW][2][64];                            // the att_h projection's B fragments (fragment-shaped, read back by the lane that wrote them)  16 KB
     __shared__ __attribute__((aligned(16))) bf16_t actx[16][XC + 8];   // P4: merged contexts as the A tile of the o projection   16.6 KB
     __shared__ float sc[SCMAX];                                  // raw scores of this workgroup's chunk                   16 KB
     __shared__ float cst[8][16];                                 // c state of this workgroup's 16 units (lives here for all T steps)
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     // lane that wrote it) -- 88 resident VGPRs left no room for the attention stream's two row blocks in flight
     // P1's contraction index [o (512) | h (512)]: k-steps 0, 1 of a wave lie in o (polled hand-over words), 2, 3 in h (plain loads)
 #define P1K(ks) ((ks) < 2 ? wave * 64 + (ks) * 32 : XO + wave * 64 + ((ks) - 2) * 32)
-    u32x4 wrt0[4], wah[2], wow[4];
+    u32x4 wrt0[4], wow[4];
     u32x4* wl = reinterpret_cast<u32x4*>(xdec_dyn_lds) + (wave * 12) * 64 + lane;       // + (gate - 1) * 4 * 64 + ks * 64
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     for (int ks = 0; ks < 2; ++ks) {
         const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wah + (long long)(e0 + (r16 & 7)) * p.ldah + wave * 64 + ks * 32 + g4 * 8);
         const u32x4 z = {0u, 0u, 0u, 0u};
-        wah[ks] = r16 < 8 ? w : z;                               // an 8-column slice in a 16-column tile
+        wahs[wave][ks][lane] = r16 < 8 ? w : z;                  // an 8-column slice in a 16-column tile
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             }
             v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) acc = mfma16(a[ks], wah[ks], acc);
+            for (int ks = 0; ks < 2; ++ks) acc = mfma16(a[ks], wahs[wave][ks][lane], acc);
             if (g4 * 4 < NB) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
@@ -505,7 +509,11 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             }
             constexpr int SPG = NB >= 4 ? NB / 4 : 1, NG = NB / SPG;      // samples per thread group, groups that have samples
             const int tg = tid >> 7, c4 = (tid & 127) * 4;
-            constexpr int QG = NQ < 8 ? NQ : 8;                           // chunks requested at a time (8 x 16 bytes in flight per thread; small batches have up to 32 chunks per sample)
+            // chunks requested at a time per sample.  Every request in flight pins four destination registers, and this merge is where the
+            // kernel's register demand peaks: with 8 x 16 bytes in flight per thread the allocator kept 17 dwords of loop-invariant
+            // addresses in scratch and reloaded them (behind `vmcnt(0)`) in every serial phase -- 4 in flight (2 samples x 2 chunks at
+            // B = 64) costs the merge one more L2 round trip and the step 1 us less: decoder forward 2.40 -> 2.30 ms
+            constexpr int QG = NB >= 4 ? 2 : 4;
             u32x4 pc[SPG][QG];
             if (tg < NG) {
 #pragma unroll
