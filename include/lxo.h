@@ -14,16 +14,20 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* liblxo.so is built with -fvisibility=hidden: what this header (and include/lxo_debug.h, the measurement hooks) declares is the
+ * library's whole dynamic symbol table (tests/test_abi.py compares `nm -D` with the two headers) */
+#pragma GCC visibility push(default)
 
 #define LXO_F32 0
 #define LXO_BF16 1
 
 const char* lxo_last_error(void);
 /* ABI version of this header.  Bumped whenever lxo_shape grows or an entry point changes (round 4: 4 -- lxo_comm_*,
- * lxo_allreduce_bucket, LXO_GNORM_FLOATS behind lxo_global_norm_scale's scale_out).  A binding must check
+ * lxo_allreduce_bucket, LXO_GNORM_FLOATS behind lxo_global_norm_scale's scale_out; round 5: 5 -- lxo_shape.deterministic,
+ * lxo_chain_guard, lxo_decode_state_get / _set, lxo_decode_cell_step; a NaN *scale_dev drops an optimizer step).  A binding must check
  * lxo_version() == LXO_ABI_VERSION and lxo_shape_size() == sizeof(its own lxo_shape) before the first call: a caller built
  * against an older header passes a shorter struct and the library would read past its end. */
-#define LXO_ABI_VERSION 4
+#define LXO_ABI_VERSION 5
 int lxo_version(void);
 int lxo_shape_size(void);
 
@@ -125,6 +129,12 @@ typedef struct lxo_shape {
      * row of the H' x W' feature map is run through a bidirectional TF-style LSTMCell (C/2 units per direction, zero initial
      * state) along W'; the concatenated outputs replace the features the attention reads.  Needs C in {256, 512}. */
     int encoder_rnn;
+    /* bf16 mode only (the f32 parity mode is always run-to-run reproducible): != 0 = every reduction of the training step runs in a
+     * fixed order -- the float atomics of the bf16 epilogues (conv weight gradients, the deferred all-step weight gradients, bias
+     * sums, d_beta, the embedding scatter, the loss statistics) go through ordered partial slots (ws region "det_part") -- so that
+     * two runs of one binary on the same inputs give bit-identical losses, gradients and weights.  Costs a few per cent of a step
+     * (bench.py: secondary.deterministic_bf16); off by default.  SURVEY.md Appendix D step 8. */
+    int deterministic;
 } lxo_shape;
 
 /* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF
@@ -210,6 +220,26 @@ int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* w
 int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                                const int32_t* formula, float* grads, const int32_t* active_rows, int parts, void* stream);
 
+/* Health of the persistent decoder chains (lxo_shape.step_kernels == 0, bf16: lxo_decoder_train_fwd / _bwd run the recurrence as ONE
+ * launch of 8 XCD-local chains that rely on the hardware placing 32 workgroups of the grid on every XCD).  A chain that does not
+ * assemble within 200 ms gives up (no hang) and leaves a non-zero ERROR WORD; the call's outputs are then invalid.  The words live in
+ * ws region "xdec_sync": int32 index LXO_XDEC_ERR_WORD of block 0 (forward chain) and of block 1 (backward chain), a block being
+ * LXO_XDEC_BLOCK_BYTES bytes; both are cleared by every lxo_decoder_train_fwd / _bwd call, whether a chain runs in it or not.
+ * The forward chain's word also turns the loss of lxo_ce_loss_fwd_bwd* into NaN.
+ * lxo_chain_guard folds both words into the optimizer's scale ON THE DEVICE (no host synchronisation): scale_io[0] becomes NaN when
+ * either word is set, else stays (have_scale != 0: the value lxo_global_norm_scale left) or becomes 1 (have_scale == 0);
+ * lxo_adam_step / lxo_optimizer_step DROP the step (touch nothing) when *scale_dev is NaN.  Data parallel: lxo_decoder_train_bwd[_part]
+ * turns the LAST element of `grads` (y_W_o's last) into NaN when a chain of this rank failed, the gradient all-reduce spreads it, and
+ * lxo_chain_guard (grads != NULL) also drops the step when it reads a NaN there -- every rank drops the same steps, the replicas stay
+ * identical.  status_out (device, 3 words, may be NULL) receives {forward word, backward word, 1 if the step is dropped} so that a
+ * caller can copy them to the host asynchronously, switch to lxo_shape.step_kernels = 2 (the launch-per-step kernels) when one of its
+ * own words is set, and take back the time step of a dropped Adam update.  Call it behind lxo_decoder_train_bwd and the gradient
+ * exchange, on the stream the optimizer runs on.
+ * Reference: the step this protects is model/img2seq.py:169 (one sess.run = forward, loss, gradients, update). */
+#define LXO_XDEC_BLOCK_BYTES (4096 + (384 << 10))
+#define LXO_XDEC_ERR_WORD 512
+int lxo_chain_guard(const lxo_shape* s, void* ws, const float* grads, float* scale_io, int have_scale, uint32_t* status_out, void* stream);
+
 /* tf.clip_by_global_norm scale (img2seq.py:119-121): scale_out[0] = clip / max(||g||, clip),
  * scale_out[1] = ||g|| ; device memory, no host sync.  clip <= 0 -> scale 1.  scale_out must hold LXO_GNORM_FLOATS floats:
  * the rest is scratch for one partial sum of squares per workgroup, which are added in workgroup order (no float atomics:
@@ -217,7 +247,8 @@ int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const vo
 #define LXO_GNORM_FLOATS (2 + 1024)
 int lxo_global_norm_scale(long long n, const float* grads, float clip, float* scale_out, void* stream);
 /* tf.train.AdamOptimizer update (img2seq.py:101), TF epsilon placement:
- * m,v updated; theta -= lr_t * m / (sqrt(v) + eps), grads pre-multiplied by *scale_dev if given. */
+ * m,v updated; theta -= lr_t * m / (sqrt(v) + eps), grads pre-multiplied by *scale_dev if given.
+ * A NaN *scale_dev (lxo_chain_guard) drops the step: params, m and v are left untouched. */
 int lxo_adam_step(long long n, float* params, const float* grads, float* m, float* v,
                   float lr_t, float beta1, float beta2, float eps, const float* scale_dev, void* stream);
 
@@ -249,6 +280,20 @@ int lxo_greedy_decode_attn(const lxo_shape* s, const float* params, const void* 
 int lxo_decode_begin(const lxo_shape* s, const float* params, const void* wpack, void* ws, void* stream);
 int lxo_decode_step(const lxo_shape* s, const float* params, const void* wpack, void* ws, int id_end, int time,
                     int32_t* ids_out, int32_t* parents_out, int32_t* finished_host, int* unfinished_host, void* stream);
+/* The AttentionState of the step-wise decode (attention_cell.py:8: AttentionState(cell_state = LSTMStateTuple(c, h), o)) as data:
+ * the state that lxo_decode_step(time) / lxo_decode_cell_step(time) steps FROM (after lxo_decode_begin: time 0 = the initial state
+ * of attention_cell.py:51-56; after a step at `time`: time + 1).  c, h f32 [B * beam][U], o f32 [B * beam][O], DEVICE pointers, any
+ * may be NULL (skipped).  _set also takes ids_prev int32 [B * beam] = the tokens whose embeddings are the step's input
+ * (greedy_decoder_cell.py:61: embedding_lookup(E, new_ids)); NULL leaves them.  With these a caller can run AttentionCell.step from
+ * a state of its choosing, as the reference's cell allows (attention_cell.py:58: step(embedding, attn_cell_state)). */
+int lxo_decode_state_get(const lxo_shape* s, void* ws, int time, float* c, float* h, float* o, void* stream);
+int lxo_decode_state_set(const lxo_shape* s, void* ws, int time, const float* c, const float* h, const float* o,
+                         const int32_t* ids_prev, void* stream);
+/* AttentionCell.step alone (attention_cell.py:58-89): LSTM cell, attention context, o and logits projections for every decoder row,
+ * from the state of `time` to the state of time + 1; logits f32 [B * beam][Vp] in ws region "dec_logits" (Vp = V rounded up to 32).
+ * start_token != 0: the input is the learnt start token (greedy_decoder_cell.py:40-43), else the embeddings of the ids last set /
+ * produced.  No arg-max, no finished flags, no beam bookkeeping: those belong to the decoder cells (lxo_decode_step). */
+int lxo_decode_cell_step(const lxo_shape* s, const float* params, const void* wpack, void* ws, int time, int start_token, void* stream);
 /* dynamic_decode + BeamSearchDecoderCell (beam_search_decoder_cell.py:98-250),
  * reference-faithful finalize (parents not followed): ids_out int32 [B, max_steps, beam],
  * parents_out same shape (may be NULL). */
@@ -280,6 +325,7 @@ int lxo_allreduce_bucket(void* comm, void* ptr, long long count, int dtype, void
 int lxo_comm_destroy(void* comm);
 const char* lxo_comm_last_error(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

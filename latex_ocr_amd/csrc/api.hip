@@ -253,6 +253,31 @@ extern "C" int lxo_conv3x3_wgrad(int dt, const void* in, const void* dout, float
     return 0;
 }
 
+extern "C" int lxo_chain_guard(const lxo_shape* s, void* ws, const float* grads, float* scale_io, int have_scale, uint32_t* status_out, void* stream) {
+    MAKE_PLAN(P, s);
+    if (!ws || !scale_io) return fail(-1, "lxo_chain_guard: null workspace / scale");
+    CHECK_LAUNCH(lxo_impl_chain_guard(P, ws, grads, scale_io, have_scale, status_out, (hipStream_t)stream), "lxo_chain_guard");
+    return 0;
+}
+extern "C" int lxo_decode_state_get(const lxo_shape* s, void* ws, int time, float* c, float* h, float* o, void* stream) {
+    MAKE_PLAN(P, s);
+    if (time < 0) return fail(-5, "lxo_decode_state_get: time < 0");
+    CHECK_LAUNCH(lxo_impl_decode_state_get(P, ws, time, c, h, o, (hipStream_t)stream), "lxo_decode_state_get");
+    return 0;
+}
+extern "C" int lxo_decode_state_set(const lxo_shape* s, void* ws, int time, const float* c, const float* h, const float* o,
+                                    const int32_t* ids_prev, void* stream) {
+    MAKE_PLAN(P, s);
+    if (time < 0) return fail(-5, "lxo_decode_state_set: time < 0");
+    CHECK_LAUNCH(lxo_impl_decode_state_set(P, ws, time, c, h, o, ids_prev, (hipStream_t)stream), "lxo_decode_state_set");
+    return 0;
+}
+extern "C" int lxo_decode_cell_step(const lxo_shape* s, const float* params, const void* wpack, void* ws, int time, int start_token, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_decode_cell_step(P, params, wpack, ws, time, start_token, (hipStream_t)stream), "lxo_decode_cell_step");
+    return 0;
+}
+
 extern "C" int lxo_set_side_stream(void* stream) {
     CHECK_LAUNCH(lxo_impl_set_side_stream((hipStream_t)stream), "lxo_set_side_stream");
     return 0;

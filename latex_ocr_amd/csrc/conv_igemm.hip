@@ -11,6 +11,7 @@
 //   (Rounds 1-2 also carried a 256 x 128 x 64 im2col-tile kernel and a 256-channel-wide halo kernel: superseded, removed in round 4.)
 #include "gemm.h"
 #include "api_util.h"
+#include "lxo_debug.h"
 #include <stdlib.h>
 
 namespace {

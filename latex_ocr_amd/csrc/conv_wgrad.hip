@@ -12,6 +12,7 @@
 // ranges of the workgroups have unequal lengths so that those epilogues do not collide.
 #include "gemm.h"
 #include "api_util.h"
+#include "lxo_debug.h"
 #include <stdlib.h>
 
 namespace {

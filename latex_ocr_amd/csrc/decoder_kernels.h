@@ -46,5 +46,7 @@ int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, i
 int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, hipStream_t st);
 int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k, int cols, hipStream_t st);
 int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sumsq_tmp, float* out, hipStream_t st);
+int lxo_k_chain_guard(const unsigned* err_fwd, const unsigned* err_bwd, const float* probe, float* scale, int have_scale, unsigned* status, hipStream_t st);
+int lxo_k_chain_poison(const unsigned* err_fwd, const unsigned* err_bwd, float* probe, hipStream_t st);
 int lxo_k_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps, const float* scale, hipStream_t st);
 int lxo_k_simple_opt(float* p, const float* g, float* slot, long long n, float lr, int mode, const float* scale, hipStream_t st);

@@ -1493,10 +1493,28 @@ __global__ void clip_scale_kernel(const float* __restrict__ sumsq, int nparts, f
     out[1] = gn;
     out[0] = clip > 0.f ? clip / fmaxf(gn, clip) : 1.0f;
 }
+// lxo_chain_guard: fold the error words of the two persistent decoder chains (xdec.hip) into the optimizer's scale.  scale[0] = NaN when
+// either chain of this step did not assemble (its outputs are garbage) or when the probe element of the gradients is NaN (another rank's
+// chain failed: chain_poison_kernel below put a NaN into that element before the all-reduce), else the clip scale already there
+// (have_scale) or 1.  status = {forward word, backward word, step dropped}.
+__global__ void chain_guard_kernel(const unsigned* __restrict__ err_fwd, const unsigned* __restrict__ err_bwd, const float* __restrict__ probe,
+                                   float* __restrict__ scale, int have_scale, unsigned* __restrict__ status) {
+    const unsigned ef = err_fwd ? err_fwd[0] : 0u, eb = err_bwd ? err_bwd[0] : 0u;
+    const float pv = probe ? probe[0] : 0.f;
+    const bool drop = (ef | eb) != 0u || pv != pv;
+    if (status) { status[0] = ef; status[1] = eb; status[2] = drop ? 1u : 0u; }
+    scale[0] = drop ? __uint_as_float(0x7fc00000u) : (have_scale ? scale[0] : 1.0f);
+}
+// behind the decoder backward: a failed chain turns one gradient element into NaN, so that under data parallelism the gradient all-reduce
+// carries the failure to every rank and all of them drop the step (lxo_chain_guard reads the element back)
+__global__ void chain_poison_kernel(const unsigned* __restrict__ err_fwd, const unsigned* __restrict__ err_bwd, float* __restrict__ probe) {
+    if ((err_fwd && err_fwd[0]) || (err_bwd && err_bwd[0])) probe[0] = __uint_as_float(0x7fc00000u);
+}
 // TF AdamOptimizer: theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the host
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                   long long n, float lr_t, float b1, float b2, float eps, const float* __restrict__ scale) {
     const float sc = scale ? scale[0] : 1.0f;
+    if (sc != sc) return;                 // a NaN scale = a poisoned step (lxo_chain_guard: a decoder chain did not assemble): dropped, no slot is touched
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i] * sc;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -1513,6 +1531,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 __global__ __launch_bounds__(256) void simple_opt_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ slot,
                                                         long long n, float lr, int mode, const float* __restrict__ scale) {
     const float sc = scale ? scale[0] : 1.0f;
+    if (sc != sc) return;                 // as in adam_kernel: a poisoned step is dropped
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i] * sc;
         if (mode == 1) p[i] -= lr * gi;
@@ -1774,6 +1793,14 @@ int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sums
 int lxo_k_simple_opt(float* p, const float* g, float* slot, long long n, float lr, int mode, const float* scale, hipStream_t st) {
     if (mode < 1 || mode > 3 || (mode > 1 && !slot)) return -2;
     LAUNCH(simple_opt_kernel, grid1(n, 256 * 4, 4096), p, g, slot, n, lr, mode, scale);
+    DONE;
+}
+int lxo_k_chain_guard(const unsigned* err_fwd, const unsigned* err_bwd, const float* probe, float* scale, int have_scale, unsigned* status, hipStream_t st) {
+    hipLaunchKernelGGL(chain_guard_kernel, dim3(1), dim3(1), 0, st, err_fwd, err_bwd, probe, scale, have_scale, status);
+    DONE;
+}
+int lxo_k_chain_poison(const unsigned* err_fwd, const unsigned* err_bwd, float* probe, hipStream_t st) {
+    hipLaunchKernelGGL(chain_poison_kernel, dim3(1), dim3(1), 0, st, err_fwd, err_bwd, probe);
     DONE;
 }
 int lxo_k_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2, float eps, const float* scale, hipStream_t st) {

@@ -251,7 +251,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
         if (rc == 0) chain_done = true;
         else if (rc != -2) return rc < 0 ? rc : -rc;
     }
-    if (P.bf && !chain_done) HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC) + 8 * 64, 0, 4, st));      // no chain in this call: clear its error word (the loss kernel reads it)
+    if (P.bf && !chain_done) HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC), 0, kXDecSyncBytes, st));      // no chain in this call: clear its tickets and its error word (the loss kernel and lxo_chain_guard read it; a reused workspace may hold another shape's bytes here)
     if (fused && !chain_done) {
         bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         RC(mirror_oh(P, ws, 0, B, st));
@@ -319,6 +319,9 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         if (P.bf && fused) RC(tn(P, false, false, P.ws<bf16_t>(ws, W_RECB) + (size_t)B * P.RECB, P.RECB, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
         else RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
     }
+    // a failed forward chain poisons the last gradient element (y_W_o's, final after this part): under data parallelism its all-reduce
+    // carries the failure to every rank (lxo_chain_guard)
+    if ((parts & 1) && P.bf) RC(lxo_k_chain_poison(P.ws<unsigned>(ws, W_XSYNC) + 8 * 64, nullptr, grads + P.ptotal - 1, st));
     if (!(parts & 2)) return 0;
 
     // the launch-per-step kernels accumulate d_c in place and d_att_h with atomics; the backward chain writes both with plain stores
@@ -330,6 +333,9 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         return 0;
     };
     if (!want_chain) RC(zero_acc());
+    // no backward chain in this call: clear block 1's tickets and error word (lxo_chain_guard / Engine.chain_status read them; the workspace
+    // is reused across shapes and the region offsets move with the shape, so stale bytes there would read as a broken chain)
+    if (P.bf && !want_chain) HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4, 0, kXDecSyncBytes, st));
     if (active) {    // rows of skipped steps must read as zero in the deferred all-step GEMMs below
         HIPRC(hipMemsetAsync(gall, 0, (size_t)TB * O * 4, st));
         HIPRC(hipMemsetAsync(dhc, 0, (size_t)TB * P.HC * 4, st));
@@ -381,7 +387,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             const int rc = lxo_launch_xdec_bwd(x, U, O, C, E, st);
             if (rc == 0) chain_done = bwd_chain = true;
             else if (rc != -2) return rc < 0 ? rc : -rc;
-            else RC(zero_acc());
+            else { RC(zero_acc()); HIPRC(hipMemsetAsync(x.sync, 0, kXDecSyncBytes, st)); }      // the shape does not qualify: no tickets, no error
         }
         RStep a; memset(&a, 0, sizeof(a));
         a.U = U; a.O = O; a.zx_row = -1;
@@ -551,6 +557,9 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     }
     RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, st));
+    // the backward chain's error word -> the probe element (as for the forward chain above; y_W_o's bucket is reduced behind this call
+    // where the backward chain runs, Engine.backward)
+    if (bwd_chain) RC(lxo_k_chain_poison(nullptr, P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4 + 8 * 64, grads + P.ptotal - 1, st));
     return 0;
 }
 
@@ -667,6 +676,44 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
         return 0;
     }));
     return 0;
+}
+
+// lxo_chain_guard: scale[0] = NaN when a chain of this step left an error word, else the clip scale / 1 (decoder_kernels.hip)
+int lxo_impl_chain_guard(const Plan& P, void* ws, const float* grads, float* scale, int have_scale, unsigned* status, hipStream_t st) {
+    const unsigned* ef = P.bf ? P.ws<unsigned>(ws, W_XSYNC) + 8 * 64 : nullptr;
+    const unsigned* eb = P.bf ? P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4 + 8 * 64 : nullptr;
+    return lxo_k_chain_guard(ef, eb, grads ? grads + P.ptotal - 1 : nullptr, scale, have_scale, status, st);
+}
+
+// ---- AttentionState of the step-wise decode (attention_cell.py:8: cell_state = LSTMStateTuple(c, h), o): the state lxo_decode_step(time) /
+// lxo_decode_cell_step(time) steps FROM lives in record slot time & 1 ----
+static int state_rows(const Plan& P) { return P.s.B * (P.s.beam > 1 ? P.s.beam : 1); }
+int lxo_impl_decode_state_get(const Plan& P, void* ws, int time, float* c, float* h, float* o, hipStream_t st) {
+    const int nv = state_rows(P), U = P.s.U, O = P.s.O, slot = time & 1;
+    const float* rec = P.ws<float>(ws, W_REC) + (size_t)slot * nv * P.REC;
+    const float* cs = P.ws<float>(ws, W_CS) + (size_t)slot * nv * U;
+    if (c) HIPRC(hipMemcpyAsync(c, cs, (size_t)nv * U * 4, hipMemcpyDeviceToDevice, st));
+    if (h) HIPRC(hipMemcpy2DAsync(h, (size_t)U * 4, rec + O, (size_t)P.REC * 4, (size_t)U * 4, nv, hipMemcpyDeviceToDevice, st));
+    if (o) HIPRC(hipMemcpy2DAsync(o, (size_t)O * 4, rec, (size_t)P.REC * 4, (size_t)O * 4, nv, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+int lxo_impl_decode_state_set(const Plan& P, void* ws, int time, const float* c, const float* h, const float* o, const int* ids_prev, hipStream_t st) {
+    const int nv = state_rows(P), U = P.s.U, O = P.s.O, slot = time & 1;
+    float* rec = P.ws<float>(ws, W_REC) + (size_t)slot * nv * P.REC;
+    float* cs = P.ws<float>(ws, W_CS) + (size_t)slot * nv * U;
+    if (c) HIPRC(hipMemcpyAsync(cs, c, (size_t)nv * U * 4, hipMemcpyDeviceToDevice, st));
+    if (h) HIPRC(hipMemcpy2DAsync(rec + O, (size_t)P.REC * 4, h, (size_t)U * 4, (size_t)U * 4, nv, hipMemcpyDeviceToDevice, st));
+    if (o) HIPRC(hipMemcpy2DAsync(rec, (size_t)P.REC * 4, o, (size_t)O * 4, (size_t)O * 4, nv, hipMemcpyDeviceToDevice, st));
+    if ((h || o) && fused_steps(P)) RC(mirror_oh(P, ws, (size_t)slot * nv, nv, st));      // the step GEMMs read the bf16 mirror of [o | h]
+    if (ids_prev) HIPRC(hipMemcpyAsync(P.ws<int>(ws, W_DEC_IDS), ids_prev, (size_t)nv * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+// AttentionCell.step alone (attention_cell.py:58-89): state slot time & 1 -> slot (time + 1) & 1, logits in ws region "dec_logits";
+// no arg-max, no finished flags (those belong to the decoder cells: lxo_decode_step)
+int lxo_impl_decode_cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int time, int start_token, hipStream_t st) {
+    const int k = P.s.beam > 1 ? P.s.beam : 1;
+    if (time < 0) return -5;
+    return decode_common_step(P, prm, wp, ws, state_rows(P), k, (time + 1) & 1, start_token ? nullptr : P.ws<int>(ws, W_DEC_IDS), st);
 }
 
 // ---- the decode loop one step at a time: what the reference's cell protocol (dynamic_decode.py:34-61: initialize / step /

@@ -36,6 +36,6 @@ struct RStep {
 
 int lxo_launch_rstep(int dt, int a_bf16, const RStep& p, hipStream_t st);
 // measurement aid: the next launches whose epilogue is `epi` stamp their phases into buf (null = off); per host thread
-extern "C" int lxo_rstep_debug(unsigned long long* buf, int epi);
+#include "lxo_debug.h"      // lxo_rstep_debug
 // rows x cols of an f32 matrix -> bf16 copy (record mirrors of the initial state / after beam re-ordering)
 int lxo_k_mirror(const float* src, int lds, void* dst, int ldd, int rows, int cols, hipStream_t st);

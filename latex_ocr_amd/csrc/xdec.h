@@ -4,6 +4,7 @@
 #pragma once
 #include "lxo_common.h"
 #include "decoder_kernels.h"
+#include "lxo_debug.h"
 
 struct XDecFwd {
     // recurrent weights, bf16, K-contiguous ([out][in]) with the row pitches of the plan; each workgroup keeps its column slice of all
@@ -60,12 +61,7 @@ struct XDecBwd {
     unsigned long long* dbg;          // as in XDecFwd
 };
 int lxo_launch_xdec_bwd(const XDecBwd& p, int U, int O, int C, int E, hipStream_t st);
-extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf);
-// test aid: the next forward (bit 0) / backward (bit 1) chain launch of this host thread reports a broken chain (its error word is set
-// behind the kernel), so that the caller's fall-back to the launch-per-step chain can be exercised on hardware that never breaks one
-extern "C" int lxo_xdec_inject_error(int which);
-// measurement aid: the next launches of this host thread stamp their phases into buf (null = off)
-extern "C" int lxo_xdec_debug(unsigned long long* buf);
+// measurement aid (include/lxo_debug.h: lxo_xdec_debug / lxo_xdec_debug_bwd): the next launches of this host thread stamp their phases into a buffer
 // One block per chain in ws region "xdec_sync": [sync words, 4096 B: per-XCD flag line + ticket line, error word at [512]]
 // [hand-over words, 384 KB: 8-byte {value, tag} pairs for up to 64 samples]; the launcher zeroes the whole block (tags of an earlier
 // launch must not pass for this one's).  Forward chain: block 0, backward chain: block 1.

@@ -32,7 +32,6 @@ int lxo_launch_xdec_fwd(const XDecFwd&, int, int, int, int, hipStream_t) { retur
 int lxo_launch_xdec_bwd(const XDecBwd&, int, int, int, int, hipStream_t) { return -2; }
 extern "C" int lxo_xdec_debug(unsigned long long*) { return 0; }
 extern "C" int lxo_xdec_debug_bwd(unsigned long long*) { return 0; }
-extern "C" int lxo_xdec_inject_error(int) { return 0; }
 #else
 
 HIP_DYNAMIC_SHARED(char, xdec_dyn_lds)
@@ -1007,16 +1006,7 @@ int launch_bwd_nb(const XDecBwd& p, hipStream_t st) {
 }  // namespace
 
 static thread_local unsigned long long* g_xdbg = nullptr;
-static thread_local int g_xinject = 0;
 extern "C" int lxo_xdec_debug(unsigned long long* buf) { g_xdbg = buf; return 0; }
-extern "C" int lxo_xdec_inject_error(int which) { g_xinject = which; return 0; }
-// after a chain launch: the armed test error (word 512 of the chain's block = 7)
-static int inject_after_launch(int bit, unsigned* sync, hipStream_t st) {
-    if (!(g_xinject & bit)) return 0;
-    g_xinject &= ~bit;
-    HIPRC(hipMemsetD32Async((hipDeviceptr_t)(sync + 8 * 64), 7, 1, st));
-    return 0;
-}
 int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream_t st) {
     XDecFwd p = p0;
     p.dbg = g_xdbg;
@@ -1052,7 +1042,6 @@ int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream
     case 4: rc = launch_nb<4>(p, att_u, st); break;
     default: rc = launch_nb<8>(p, att_u, st); break;
     }
-    if (rc == 0) RC(inject_after_launch(1, p.sync, st));
     return rc;
 }
 static thread_local unsigned long long* g_xdbg_b = nullptr;
@@ -1082,7 +1071,6 @@ int lxo_launch_xdec_bwd(const XDecBwd& p0, int U, int O, int C, int E, hipStream
     case 4: rc = launch_bwd_nb<4>(p, st); break;
     default: rc = launch_bwd_nb<8>(p, st); break;
     }
-    if (rc == 0) RC(inject_after_launch(2, p.sync, st));
     return rc;
 }
 #endif

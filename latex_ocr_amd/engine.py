@@ -21,13 +21,14 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-# csrc/xdec.h: kXDecBlockBytes -- ws region "xdec_sync" holds one such block per chain (forward, then backward): 4 KB of flag lines, tickets
-# and the error word (word 512) + 384 KB of hand-over words (tests/test_abi.py keeps the two definitions together)
-XDEC_BLOCK_BYTES = 4096 + (384 << 10)
+# include/lxo.h: LXO_XDEC_BLOCK_BYTES (csrc/xdec.h: kXDecBlockBytes) -- ws region "xdec_sync" holds one such block per chain (forward, then
+# backward): 4 KB of flag lines, tickets and the error word (word LXO_XDEC_ERR_WORD) + 384 KB of hand-over words (tests/test_abi.py keeps
+# the definitions together)
+XDEC_BLOCK_BYTES = _abi.LXO_XDEC_BLOCK_BYTES
 
 
 class Engine(object):
-    def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None, skip_padded=None):
+    def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None, skip_padded=None, deterministic=None):
         self.lib = lib if lib is not None else _abi.load()
         self.device = torch.device(device)
         if self.device.type != "cuda" and lib is None:
@@ -43,9 +44,23 @@ class Engine(object):
         # decoder step decomposition (lxo_shape.step_kernels): 0 = automatic (the persistent XCD-local chain of csrc/xdec.hip where the shape
         # qualifies, else the fused step kernels), 2 = always the fused step kernels, 1 = round 1's split-K slab path
         self.step_kernels = int(os.environ.get("LXO_STEP_KERNELS", "0"))
+        if self.step_kernels not in (0, 1, 2):
+            raise ValueError("LXO_STEP_KERNELS must be 0, 1 or 2 (include/lxo.h: lxo_shape.step_kernels), got %d" % self.step_kernels)
+        # bf16 mode only: every reduction of a training step in a fixed order (lxo_shape.deterministic): bit-identical losses, gradients and
+        # weights from run to run, for a few per cent of a step.  The f32 parity mode is always deterministic.
+        self.deterministic = (os.environ.get("LXO_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
+        # health of the persistent decoder chains (csrc/xdec.hip): checked synchronously after the first launch that used one (forward and
+        # backward separately), then every step WITHOUT a host stall: lxo_chain_guard folds the two error words into the optimizer's scale on
+        # the device (a step whose chain did not assemble is dropped, not applied) and copies them into a pinned ring that the next
+        # train_step reads (_chain_health_poll); a failure switches this engine to the launch-per-step kernels for good.
         self._xdec_checked = False
         self._xdec_bwd_checked = False
+        self.chain_used = False
         self.chain_used_bwd = False
+        self.chain_failures = 0           # steps a chain failed in (each was dropped or redone)
+        self._nochain_shapes, self._nochain_shapes_bwd = set(), set()
+        self._health_ring = None
+        self._health_i = 0
         self.specs = PP.param_specs(self.n_tok, self.dims)
         self.n_params = PP.n_params(self.n_tok, self.dims)
         probe = self._shape(1, 32, 32, 1)
@@ -109,6 +124,7 @@ class Engine(object):
         sh.no_positional = 0 if d.get("positional", True) else 1  # positional_embeddings (encoder.py:60-65)
         sh.step_kernels = self.step_kernels
         sh.encoder_rnn = 1 if d.get("row_bilstm") else 0        # optional row-BiLSTM encoder (not in the reference; off by default)
+        sh.deterministic = 1 if self.deterministic else 0
         return sh
 
     def _stream(self):
@@ -232,7 +248,8 @@ class Engine(object):
         if self._active is None:
             self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
                      "decoder_train_fwd")
-            if not self._xdec_checked and self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda":
+            if (not self._xdec_checked and self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda"
+                    and (B, H, W) not in self._nochain_shapes):
                 self._check_chain(st)
         else:
             assert self._active.shape == (T,)
@@ -249,17 +266,76 @@ class Engine(object):
         return bool(w[32:512:64].any()), int(w[512])
 
     def _check_chain(self, st):
-        """Once per engine, after the first forward that may have run the persistent chain: it relies on how the hardware places a
-        256-workgroup grid (32 per XCD, one per CU).  If it reports an error, switch this engine to the launch-per-step chain for good
-        and redo the decoder forward."""
-        self._xdec_checked = True
+        """After the first forward that RAN the persistent chain (a shape that does not qualify leaves no tickets: checked again on the
+        next one): the chain relies on how the hardware places a 256-workgroup grid (32 per XCD, one per CU).  If it reports an error,
+        switch this engine to the launch-per-step chain for good and redo the decoder forward.  Later steps are watched without a host
+        synchronisation (_chain_health_post / _chain_health_poll)."""
         used, err = self.chain_status()
         self.chain_used = used and not err
+        if used or err:
+            self._xdec_checked = True
+        else:
+            self._nochain_shapes.add((self.shape.B, self.shape.H, self.shape.W))      # this shape takes the launch-per-step kernels: no need to look again
         if err:
-            self.step_kernels = 2
-            self.shape.step_kernels = 2
+            self._chain_fallback("forward", err)
             self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
                      "decoder_train_fwd")
+
+    def _chain_fallback(self, which, err):
+        import warnings
+        self.chain_failures += 1
+        self.step_kernels = 2
+        if self.shape is not None:
+            self.shape.step_kernels = 2
+        self.chain_used = self.chain_used_bwd = False
+        warnings.warn("latex_ocr_amd: the persistent %s decoder chain did not assemble (error word %d: a barrier / hand-over timed out or an "
+                      "XCD got the wrong number of workgroups -- CUs held by another kernel or process, a CU mask); this engine now runs the "
+                      "launch-per-step decoder kernels (lxo_shape.step_kernels = 2)" % (which, err), RuntimeWarning)
+
+    def _chains_possible(self):
+        return self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda" and not self.skip_padded
+
+    def _chain_health_post(self, have_scale):
+        """Behind backward(), before the optimizer: lxo_chain_guard (device: scale[0] = NaN when a chain of this step failed, so the optimizer
+        drops the step) + an asynchronous copy of the two error words into a pinned ring slot.  No host synchronisation."""
+        st = self._stream()
+        if self._health_ring is None:
+            self._health_dev = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self._health_ring = [{"host": torch.zeros(4, dtype=torch.int32).pin_memory(), "ev": None} for _ in range(4)]
+        self._ck(self.lib.lxo_chain_guard(self.sref(), _p(self.ws), _p(self.grads), _p(self.scale), 1 if have_scale else 0, _p(self._health_dev), st),
+                 "chain_guard")
+        slot = self._health_ring[self._health_i % len(self._health_ring)]
+        self._health_i += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()                 # four steps old: long done (and its words were looked at by _chain_health_poll)
+            self._chain_health_look(slot)
+        slot["host"].copy_(self._health_dev, non_blocking=True)
+        slot["seq"] = self._health_i
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record(torch.cuda.current_stream(self.device))
+
+    def _chain_health_look(self, slot):
+        ef, eb, dropped = int(slot["host"][0]), int(slot["host"][1]), int(slot["host"][2])
+        slot["ev"] = None
+        if dropped:
+            self.dropped_steps = getattr(self, "dropped_steps", 0) + 1
+            self._last_dropped_seq = slot["seq"]
+            if getattr(self, "method", 0) == 0 and self.adam_t > 0:
+                self.adam_t -= 1                      # the step was dropped on the device (NaN scale) on EVERY rank: its Adam time step did not happen
+        if (ef or eb) and self.step_kernels == 0:
+            self._chain_fallback("forward" if ef else "backward", ef or eb)
+        return bool(dropped)
+
+    def _chain_health_poll(self, wait=False):
+        """Look at the error words of finished steps (wait=True: of every posted step; the caller has synchronised or accepts to).
+        -> True when a failure was found (the engine has switched to the launch-per-step kernels; the failed step was dropped)."""
+        bad = False
+        for slot in self._health_ring or ():
+            if slot["ev"] is not None and (wait or slot["ev"].query()):
+                if wait:
+                    slot["ev"].synchronize()
+                bad = self._chain_health_look(slot) or bad
+        return bad
 
     def _bind_side(self):
         side = ctypes.c_void_p(self.side_stream.cuda_stream) if self.side_stream is not None else ctypes.c_void_p(0)
@@ -314,14 +390,17 @@ class Engine(object):
                                                                _p(self.grads), act, st), "decoder_train_bwd_active")
 
         decoder_bwd(chain)
-        if chain and not self._xdec_bwd_checked:
-            # once per engine, as for the forward chain: a chain that did not assemble leaves an error word -> launch chain from now on
-            self._xdec_bwd_checked = True
+        if chain and not self._xdec_bwd_checked and (self.shape.B, self.shape.H, self.shape.W) not in self._nochain_shapes_bwd:
+            # as for the forward chain, after the first backward that RAN it: a chain that did not assemble leaves an error word -> launch
+            # chain from now on.  (The words are cleared by every call, chain or not, so `err` is this call's.)
             used, err = self.chain_status(backward=True)
             self.chain_used_bwd = used and not err
+            if used or err:
+                self._xdec_bwd_checked = True
+            else:
+                self._nochain_shapes_bwd.add((self.shape.B, self.shape.H, self.shape.W))
             if err:
-                self.step_kernels = 2
-                self.shape.step_kernels = 2
+                self._chain_fallback("backward", err)
                 chain = False
                 decoder_bwd(False)
         if comm:
@@ -353,12 +432,17 @@ class Engine(object):
         elif self.method == 3:
             self.adam_v.fill_(1.0)        # RMSProp rms slot starts at ones
 
-    def optimizer_step(self, lr, clip=-1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    def optimizer_step(self, lr, clip=-1.0, beta1=0.9, beta2=0.999, eps=1e-8, guard=False):
+        """guard: fold the decoder chains' error words into the scale first (train_step does; a failed step is then dropped on the device)."""
         st = self._stream()
+        guard = guard and self._chains_possible() and self.ws is not None and self.shape is not None
         if getattr(self, "method", 0) != 0:
             scale = None
             if clip is not None and clip > 0:
                 self._ck(self.lib.lxo_global_norm_scale(self.n_params, _p(self.grads), ctypes.c_float(clip), _p(self.scale), st), "clip")
+                scale = self.scale
+            if guard:
+                self._chain_health_post(scale is not None)
                 scale = self.scale
             self._ck(self.lib.lxo_optimizer_step(self.method, self.n_params, _p(self.params), _p(self.grads), _p(self.adam_v),
                                                  ctypes.c_float(float(lr)), _p(scale), st), "optimizer_step")
@@ -369,6 +453,9 @@ class Engine(object):
         scale = None
         if clip is not None and clip > 0:
             self._ck(self.lib.lxo_global_norm_scale(self.n_params, _p(self.grads), ctypes.c_float(clip), _p(self.scale), st), "clip")
+            scale = self.scale
+        if guard:
+            self._chain_health_post(scale is not None)
             scale = self.scale
         self._ck(self.lib.lxo_adam_step(self.n_params, _p(self.params), _p(self.grads), _p(self.adam_m), _p(self.adam_v),
                                         ctypes.c_float(lr_t), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
@@ -388,6 +475,8 @@ class Engine(object):
         if self.skip_padded:
             img, formula, lengths, active = self.sort_by_length(img, formula, lengths)
         n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
+        if self._health_ring is not None:
+            self._chain_health_poll()                 # error words of the steps the device has finished meanwhile (no stall)
         if dist is not None:
             # the global token count travels rank -> device -> all-reduce -> loss kernel; no host sync inside the step
             ntok, ev = dist.sum_count_async(n_local)
@@ -399,7 +488,7 @@ class Engine(object):
         self.backward(comm=dist.reduce_range_fn(self.grads) if dist is not None else None)
         if dist is not None:
             dist.finish()
-        self.optimizer_step(lr, clip)
+        self.optimizer_step(lr, clip, guard=True)
         if not sync_loss:
             return None
         if dist is not None:
@@ -408,6 +497,16 @@ class Engine(object):
             s = s.cpu().numpy()
         else:
             s = stats.cpu().numpy()
+        if (self._health_ring is not None and self._chain_health_poll(wait=True) and getattr(self, "_last_dropped_seq", -1) == self._health_i
+                and dist is None and not getattr(self, "_redoing", False)):
+            # the host is synchronised here anyway: a chain failed in THIS step, the device dropped its update, the engine has switched to the
+            # launch-per-step kernels -- run the step again so that the caller gets the loss and the update it asked for
+            self._redoing = True
+            try:
+                return self.train_step(img, formula, lengths, lr, clip=clip, dist=None, sync_loss=True, dropout=dropout,
+                                       dropout_seed=drop[1] if drop is not None else None)
+            finally:
+                self._redoing = False
         return float(s[0]) / float(s[1])
 
     def sort_by_length(self, img, formula, lengths):
@@ -500,6 +599,42 @@ class Engine(object):
         Vp = (self.n_tok + 31) // 32 * 32
         logits = self.region("dec_logits", "f32", (ids.size, Vp))[:, :self.n_tok].cpu().numpy().reshape(ids.shape + (self.n_tok,))
         return ids, par, fin, logits
+
+    # the AttentionState as data, and AttentionCell.step alone (model/components/attention_cell.py drives these)
+    def _dec_rows(self):
+        return int(self.shape.B) * max(1, int(self.beam))
+
+    def decode_get_state(self, time):
+        """-> (c [rows, U], h [rows, U], o [rows, O]) float32 host arrays: the state that step `time` starts from."""
+        n, U, O = self._dec_rows(), self.dims["U"], self.dims["O"]
+        c = torch.empty(n, U, dtype=torch.float32, device=self.device)
+        h = torch.empty(n, U, dtype=torch.float32, device=self.device)
+        o = torch.empty(n, O, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.lxo_decode_state_get(self.sref(), _p(self.ws), int(time), _p(c), _p(h), _p(o), self._stream()), "decode_state_get")
+        return c.cpu().numpy(), h.cpu().numpy(), o.cpu().numpy()
+
+    def decode_set_state(self, time, c=None, h=None, o=None, ids=None):
+        """Overwrite (parts of) the state that step `time` starts from, and / or the token ids fed with it."""
+        n, U, O = self._dec_rows(), self.dims["U"], self.dims["O"]
+        dev = []
+        for a, shp, dt in ((c, (n, U), torch.float32), (h, (n, U), torch.float32), (o, (n, O), torch.float32), (ids, (n,), torch.int32)):
+            if a is None:
+                dev.append(None)
+                continue
+            a = np.ascontiguousarray(a)
+            if tuple(a.shape) != shp:
+                raise ValueError("decode_set_state: expected shape %s, got %s" % (shp, a.shape))
+            dev.append(self._to_dev(a, dt))
+        self._ck(self.lib.lxo_decode_state_set(self.sref(), _p(self.ws), int(time), _p(dev[0]), _p(dev[1]), _p(dev[2]), _p(dev[3]),
+                                               self._stream()), "decode_state_set")
+        torch.cuda.current_stream(self.device).synchronize() if self.device.type == "cuda" else None     # the staging tensors die with this frame
+
+    def decode_cell_step(self, time, start_token):
+        """AttentionCell.step alone: state of `time` -> state of time + 1; -> logits float32 [rows, V]."""
+        self._ck(self.lib.lxo_decode_cell_step(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(time), 1 if start_token else 0,
+                                               self._stream()), "decode_cell_step")
+        Vp = (self.n_tok + 31) // 32 * 32
+        return self.region("dec_logits", "f32", (self._dec_rows(), Vp))[:, :self.n_tok].cpu().numpy()
 
     def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False, div_gamma=1.0, div_prob=0.0, div_seed=0):
         """ids int32 [B, T', k] as pred_test.ids of the beam graph before the transpose at img2seq.py:241.

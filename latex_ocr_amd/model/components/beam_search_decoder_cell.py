@@ -41,16 +41,21 @@ class BeamSearchDecoderCell(object):
         return "start_token"
 
     def initialize(self, maximum_iterations=151):
-        c = self._cell
-        c._engine.decode_begin(c._img, self._beam_size, max_steps=int(maximum_iterations) + 1, div_gamma=self._div_gamma,
-                               div_prob=self._div_prob, div_seed=self._div_seed)
-        return self.initial_state(), self.initial_inputs(), np.zeros((self._batch_size, self._beam_size), dtype=bool)
+        state = self._cell.begin(self._beam_size, max_steps=int(maximum_iterations) + 1, div_gamma=self._div_gamma,
+                                 div_prob=self._div_prob, div_seed=self._div_seed)
+        return (BeamSearchDecoderCellState(state, "beam_lp"), self.initial_inputs(),
+                np.zeros((self._batch_size, self._beam_size), dtype=bool))
 
     def step(self, time, state, embedding, finished):
         """beam_search_decoder_cell.py:123-187: cell step on batch x beam rows, log-softmax, finished-beam masking, (diversity
-        penalty,) top-k over beam x vocabulary (beam 0 only at time 0), ids / parents, state and flags gathered by parents."""
+        penalty,) top-k over beam x vocabulary (beam 0 only at time 0), ids / parents, state and flags gathered by parents.
+        The running log-probs and finished flags stay on the device, so `state.cell_state` must be the cell's CURRENT tokens
+        (a stale or foreign token raises; a beam search cannot be re-entered from host arrays without its log-probs)."""
+        if self._cell.check_state(state.cell_state) != "current":
+            raise ValueError("BeamSearchDecoderCell.step: the beam state (log-probs, finished flags) lives on the device; pass the state "
+                             "the previous step returned")
         ids, par, fin, logits = self._cell._engine.decode_step(int(time), self._end_token)
-        new_state = BeamSearchDecoderCellState(self._cell.initial_state(int(time)), "beam_lp")
+        new_state = BeamSearchDecoderCellState(self._cell.advance(int(time)), "beam_lp")
         return BeamSearchDecoderOutput(logits, ids, par), new_state, ids, fin
 
     def finalize(self, final_outputs, final_state):

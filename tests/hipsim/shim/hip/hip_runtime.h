@@ -330,6 +330,10 @@ inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipsim"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < height; ++r) memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 typedef void* hipEvent_t;
 enum { hipEventDisableTiming = 2 };

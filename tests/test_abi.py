@@ -28,8 +28,21 @@ def test_exports_every_declared_symbol(lib):
     assert declared and set(declared) == set(_abi.ENTRY_POINTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.lxo_version() == _abi.ABI_VERSION == 4
+    assert lib.lxo_version() == _abi.ABI_VERSION == 5
     assert lib.lxo_shape_size() == ctypes.sizeof(_abi.LxoShape)
+
+
+def test_dynamic_symbol_table_is_exactly_the_two_headers(lib):
+    """-fvisibility=hidden + csrc/exports.map: `nm -D` of the production library lists the entry points of include/lxo.h, the five
+    measurement hooks of include/lxo_debug.h, and nothing else -- no C++ internals, no test hooks (there is no fault injector)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _abi.LIB_PATH]).decode()
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    declared = set()
+    for h in ("lxo.h", "lxo_debug.h"):
+        declared |= set(re.findall(r"\b(lxo_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", h)).read()))
+    assert set(exported) == declared, (sorted(set(exported) - declared), sorted(declared - set(exported)))
+    assert not [s for s in exported if "inject" in s]
 
 
 def test_param_table_matches_python(lib):

@@ -154,3 +154,58 @@ def test_cell_protocol_vs_reference_code_f32(V):
         for t in range(T - 1, -1, -1):
             assert np.array_equal(tb.ids[b, t], ids[b, t][cur])
             cur = par[b, t][cur]
+
+
+def test_attention_cell_step_from_a_state_of_the_callers_choosing_f32():
+    """AttentionCell.step(embedding, state) (attention_cell.py:58-89; called at greedy_decoder_cell.py:55) takes ANY state.  The device-side
+    cell hands out tokens for the state it holds and accepts (a) those, (b) an AttentionState of host arrays -- uploaded through
+    lxo_decode_state_set -- and refuses stale or foreign tokens instead of silently stepping from something else."""
+    from latex_ocr_amd.model.components import AttentionCell, GreedyDecoderCell
+    V = 50
+    tag = "v%d_toy_" % V
+    eng = Engine(V, dtype="f32", seed=0)
+    eng.load_params(_weights(V, "toy"))
+    img = REFDEC[tag + "img"]
+    cfg = {"dim_e": 256, "dim_o": 512, "num_units": 512, "dim_embeddings": 80}
+    cell = AttentionCell(eng, img, cfg, V)
+    g = GreedyDecoderCell(cell, V - 1)
+    state, inputs, fin = g.initialize(31)
+    first = state
+    outs, saved = [], None
+    for time in range(4):
+        out, state, inputs, fin = g.step(time, state, inputs, fin)
+        outs.append(out)
+        if time == 1:
+            saved, saved_ids, saved_tokens = cell.read_state(state), inputs.copy(), state
+    want = REFDEC[tag + "greedy_ids"]
+    assert np.array_equal(np.stack([o.ids for o in outs], 1), want[:, :4])
+    assert saved.cell_state.c.shape == (img.shape[0], 512) and saved.o.shape == (img.shape[0], 512)
+    with pytest.raises(ValueError, match="stale"):
+        cell.step(saved_ids, saved_tokens)                       # the device has moved on to step 3
+    with pytest.raises(ValueError, match="stale"):
+        g.step(4, first, inputs, fin)
+    other = AttentionCell(eng, img, cfg, V)
+    with pytest.raises(ValueError, match="foreign"):
+        cell.step("start_token", other.initial_state())
+    with pytest.raises(TypeError):
+        cell.step(np.zeros((img.shape[0], 80), np.float32), state)
+    # the cell alone, from the state saved after step 1, in a FRESH decode: the logits step 2 produced
+    cell.begin(1, max_steps=32)
+    logits, st = cell.step(saved_ids, saved)
+    assert logits.shape == outs[2].logits.shape
+    assert np.abs(logits - outs[2].logits).max() <= 2e-5 * max(1.0, np.abs(outs[2].logits).max())
+    assert np.array_equal(logits.argmax(1), outs[2].ids)
+    # current tokens keep working: one more cell step from `st` with the ids step 2 chose = step 3's logits
+    logits3, st3 = cell.step(outs[2].ids, st)
+    assert np.abs(logits3 - outs[3].logits).max() <= 2e-5 * max(1.0, np.abs(outs[3].logits).max())
+    # the greedy cell re-entered at time 2 from the host state continues the reference sequence
+    s0, i0, f0 = g.initialize(31)
+    out2, s2, i2, f2 = g.step(2, saved, saved_ids, f0)
+    assert np.array_equal(out2.ids, want[:, 2])
+    out3, _, _, _ = g.step(3, s2, i2, f2)
+    assert np.array_equal(out3.ids, want[:, 3])
+    # start-token form from the initial state = step 0
+    s0 = cell.begin(1, max_steps=32)
+    l0, _ = cell.step("start_token", s0)
+    assert np.abs(l0 - outs[0].logits).max() <= 2e-5 * max(1.0, np.abs(outs[0].logits).max())
+

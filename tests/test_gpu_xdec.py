@@ -112,12 +112,38 @@ def test_backward_chain_equals_launch_per_step_backward(B, H, W, drop):
         B, H, W, drop, {k: "%.1e" % v for k, v in worst.items()}, wc[0], wc[1]))
 
 
+class _FaultyEngine(Engine):
+    """Engine whose chains "break" on demand.  No MI355X here has ever broken one and the library carries no fault injector, so the test
+    plays the hardware: it writes the chain's ERROR WORD (include/lxo.h: LXO_XDEC_ERR_WORD of the chain's block in ws region "xdec_sync")
+    into device memory behind the launch, exactly where a timed-out barrier would have left it; everything that READS the word is the
+    product's own code (Engine.chain_status, lxo_chain_guard, the CE kernel's NaN backstop)."""
+    fault_fwd = fault_bwd = fault_guard = 0
+
+    def _poke(self, backward, value):
+        from latex_ocr_amd import _abi
+        w = self.region("xdec_sync", "i32")
+        w[(_abi.LXO_XDEC_BLOCK_BYTES // 4 if backward else 0) + _abi.LXO_XDEC_ERR_WORD] = value
+
+    def chain_status(self, backward=False):
+        if backward and self.fault_bwd:
+            self.fault_bwd -= 1
+            self._poke(True, 7)
+        if not backward and self.fault_fwd:
+            self.fault_fwd -= 1
+            self._poke(False, 7)
+        return Engine.chain_status(self, backward)
+
+    def _chain_health_post(self, have_scale):
+        if self.fault_guard:                                     # a later step's chain breaks: seen by the device-side guard only
+            self.fault_guard -= 1
+            self._poke(True, 7)
+        return Engine._chain_health_post(self, have_scale)
+
+
 def test_engine_falls_back_when_a_chain_reports_an_error():
     """The chains rely on how the hardware places a 256-workgroup grid; a chain that does not assemble sets an error word and the engine
-    switches to the launch-per-step kernels for good and repeats the call.  No MI355X here has ever broken one, so the error is injected
-    (`lxo_xdec_inject_error`: the word is set behind the kernel): the repeated forward must be the launch chain's bit for bit (no atomics
-    in the forward), the repeated backward its gradients."""
-    import ctypes
+    switches to the launch-per-step kernels for good and repeats the call: the repeated forward must be the launch chain's bit for bit
+    (no atomics in the forward), the repeated backward its gradients."""
     img, f, l = batch(16, 48, 160, V, 5, 24, seed=31)
     n = int(l.sum())
     ref = Engine(V, dtype="bf16", seed=4)
@@ -130,11 +156,11 @@ def test_engine_falls_back_when_a_chain_reports_an_error():
     torch.cuda.synchronize()
     gr = ref.grad_dict()
 
-    eng = Engine(V, dtype="bf16", seed=4)
-    eng.lib.lxo_xdec_inject_error.argtypes = [ctypes.c_int]
-    eng.lib.lxo_xdec_inject_error(1)                           # the next forward chain launch reports a broken chain
-    eng.forward(img, f)
-    assert eng.step_kernels == 2 and not eng.chain_used         # noticed, switched, repeated
+    eng = _FaultyEngine(V, dtype="bf16", seed=4)
+    eng.fault_fwd = 1                                           # the first forward chain launch "reports" a broken chain
+    with pytest.warns(RuntimeWarning, match="did not assemble"):
+        eng.forward(img, f)
+    assert eng.step_kernels == 2 and not eng.chain_used and eng.chain_failures == 1     # noticed, switched, repeated
     s = eng.loss(l, 1.0 / n).cpu().numpy().copy()
     assert np.array_equal(eng.region("logits", "f32", (T, 16, (V + 31) // 32 * 32)).cpu().numpy(), lr)
     assert s[1] == sr[1] and abs(s[0] - sr[0]) <= 1e-6 * abs(sr[0])
@@ -143,18 +169,58 @@ def test_engine_falls_back_when_a_chain_reports_an_error():
     for k, g in eng.grad_dict().items():
         assert cosine(g, gr[k]) > 0.999999, (k, cosine(g, gr[k]))
 
-    eng2 = Engine(V, dtype="bf16", seed=4)                      # forward chain fine, backward chain reports the error
+    eng2 = _FaultyEngine(V, dtype="bf16", seed=4)               # forward chain fine, backward chain reports the error
     eng2.forward(img, f)
     assert eng2.chain_used
     eng2.loss(l, 1.0 / n)
-    eng2.lib.lxo_xdec_inject_error(2)
-    eng2.backward()
+    eng2.fault_bwd = 1
+    with pytest.warns(RuntimeWarning, match="backward decoder chain"):
+        eng2.backward()
     torch.cuda.synchronize()
     assert eng2.step_kernels == 2 and not eng2.chain_used_bwd
     for k, g in eng2.grad_dict().items():
         assert np.isfinite(g).all() and cosine(g, gr[k]) > 0.9999, (k, cosine(g, gr[k]))
     eng2.forward(img, f)                                        # and the engine stays on the launch chain
     assert not eng2.chain_status()[0] or eng2.step_kernels == 2
+
+
+def test_a_chain_that_breaks_in_a_later_step_drops_that_step_and_falls_back():
+    """After the first use the chains are watched WITHOUT a host stall: lxo_chain_guard turns the optimizer's scale into NaN on the device when
+    a chain of the step left an error word (lxo_adam_step then touches nothing: garbage gradients are never applied) and the words reach the
+    host through a pinned ring that the next train_step looks at.  Non-syncing caller: the step is dropped (weights bit-identical to before it,
+    Adam's time step taken back) and the engine runs the launch-per-step kernels from then on; syncing caller (it reads the loss): the step is
+    repeated on those kernels, so loss and update are the ones asked for."""
+    img, f, l = batch(16, 48, 160, V, 5, 24, seed=33)
+    eng = _FaultyEngine(V, dtype="bf16", seed=6)
+    eng.train_step(img, f, l, 1e-3, sync_loss=False)            # first use: checked synchronously, fine
+    torch.cuda.synchronize()
+    assert eng.chain_used and eng.chain_used_bwd and eng.adam_t == 1
+    before = eng.params.clone()
+    m_before = eng.adam_m.clone()
+    eng.fault_guard = 1
+    eng.train_step(img, f, l, 1e-3, sync_loss=False)            # the backward chain of this step "breaks"
+    torch.cuda.synchronize()
+    assert torch.equal(eng.params, before) and torch.equal(eng.adam_m, m_before)        # dropped on the device
+    with pytest.warns(RuntimeWarning, match="did not assemble"):
+        eng.train_step(img, f, l, 1e-3, sync_loss=False)        # the host learns of it here (no stall) and falls back
+    torch.cuda.synchronize()
+    assert eng.step_kernels == 2 and eng.chain_failures == 1 and getattr(eng, "dropped_steps", 0) == 1
+    assert eng.adam_t == 2 and not torch.equal(eng.params, before)      # 3 calls, 2 applied updates
+    assert torch.isfinite(eng.params).all()
+
+    # syncing caller: the failed step is redone on the launch-per-step kernels
+    ref = Engine(V, dtype="bf16", seed=6)
+    ref.step_kernels = 2
+    l0 = ref.train_step(img, f, l, 1e-3)
+    l1 = ref.train_step(img, f, l, 1e-3)
+    e2 = _FaultyEngine(V, dtype="bf16", seed=6)
+    a0 = e2.train_step(img, f, l, 1e-3)
+    e2.fault_guard = 1
+    with pytest.warns(RuntimeWarning, match="did not assemble"):
+        a1 = e2.train_step(img, f, l, 1e-3)
+    assert e2.step_kernels == 2 and e2.adam_t == 2 and getattr(e2, "dropped_steps", 0) == 1
+    assert abs(a0 - l0) <= 2e-4 * abs(l0) and abs(a1 - l1) <= 2e-3 * abs(l1), (a0, l0, a1, l1)
+    assert cosine(e2.params.cpu().numpy(), ref.params.cpu().numpy()) > 0.999999
 
 
 def test_chain_with_dropout_equals_launch_per_step():
@@ -185,7 +251,7 @@ def test_chain_vs_oracle_loss_and_greedy_weights():
     torch.cuda.synchronize()
     got = eng.grad_dict()
     for k in G:
-        assert cosine(got[k], G[k].numpy()) > 0.999, (k, cosine(got[k], G[k].numpy()))
+        assert cosine(got[k], G[k].numpy()) > 0.9999, (k, cosine(got[k], G[k].numpy()))      # measured >= 0.99995 (B = 64: test_gpu_benchcfg)
 
 
 @pytest.mark.parametrize("step_kernels", [0, 2])

@@ -192,6 +192,88 @@ def test_decode_one_step_at_a_time_equals_the_loops():
             assert np.array_equal(par[:, :time], want_par)
 
 
+def test_cell_step_from_a_state_of_the_callers_choosing():
+    """AttentionCell.step(embedding, state) of the reference takes ANY state (attention_cell.py:58).  lxo_decode_state_get / _set move the
+    AttentionState (c, h, o) and the fed-back ids across the boundary and lxo_decode_cell_step runs the cell alone: a cell step from a
+    state read back after step 1 of one decode, re-installed into a FRESH decode, must give the logits the original step 2 produced,
+    bit for bit (f32 parity mode)."""
+    img = GOLD["img"]
+    S = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, max_steps=9)
+    U, O, Vp = S.dims["U"], S.dims["O"], 32
+    S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+    S.ck(S.L.lxo_decode_begin(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), None), "begin")
+    ids = np.zeros((2, 9), np.int32); fin = np.zeros(2, np.int32)
+    logits = []
+    for time in range(3):
+        S.ck(S.L.lxo_decode_step(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), 10, time, ptr(ids), None, ptr(fin), None, None), "step")
+        logits.append(S.region("dec_logits", np.float32, (2, Vp)).copy())
+        if time == 1:       # the state step 2 starts from, and the ids it is fed
+            c = np.zeros((2, U), np.float32); h = np.zeros((2, U), np.float32); o = np.zeros((2, O), np.float32)
+            S.ck(S.L.lxo_decode_state_get(S.sref(), ptr(S.ws), 2, ptr(c), ptr(h), ptr(o), None), "get")
+            fed = ids[:, 1].copy()
+    assert np.abs(c).max() > 0 and np.abs(h).max() > 0 and np.abs(o).max() > 0
+    S2 = Sim(2, 32, 48, 1, 11, dtype=0, seed=0, max_steps=9)
+    S2.ck(S2.L.lxo_encoder_fwd(S2.sref(), ptr(S2.params), ptr(S2.wpack), ptr(S2.ws), ptr(img), None), "enc")
+    S2.ck(S2.L.lxo_decode_begin(S2.sref(), ptr(S2.params), ptr(S2.wpack), ptr(S2.ws), None), "begin")
+    S2.ck(S2.L.lxo_decode_state_set(S2.sref(), ptr(S2.ws), 2, ptr(c), ptr(h), ptr(o), ptr(np.ascontiguousarray(fed)), None), "set")
+    S2.ck(S2.L.lxo_decode_cell_step(S2.sref(), ptr(S2.params), ptr(S2.wpack), ptr(S2.ws), 2, 0, None), "cell_step")
+    got = S2.region("dec_logits", np.float32, (2, Vp))
+    assert np.array_equal(got[:, :11], logits[2][:, :11])
+    # ... and the start-token form from the initial state gives step 0's logits
+    S2.ck(S2.L.lxo_decode_begin(S2.sref(), ptr(S2.params), ptr(S2.wpack), ptr(S2.ws), None), "begin")
+    S2.ck(S2.L.lxo_decode_cell_step(S2.sref(), ptr(S2.params), ptr(S2.wpack), ptr(S2.ws), 0, 1, None), "cell_step")
+    assert np.array_equal(S2.region("dec_logits", np.float32, (2, Vp))[:, :11], logits[0][:, :11])
+    # the state after that step, read back, is the one the first decode had after ITS step 0
+    c1 = np.zeros((2, U), np.float32)
+    S2.ck(S2.L.lxo_decode_state_get(S2.sref(), ptr(S2.ws), 1, ptr(c1), None, None, None), "get")
+    assert np.abs(c1).max() > 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_chain_guard_drops_a_poisoned_step(dtype):
+    """lxo_chain_guard folds the decoder chains' error words (ws region "xdec_sync", include/lxo.h) and the NaN probe element of the
+    gradients into the optimizer's scale; a NaN scale makes lxo_adam_step / lxo_optimizer_step leave every buffer untouched."""
+    S = Sim(2, 32, 48, 3, 11, dtype=dtype, dims=SMALL, seed=0)
+    L = S.L
+    n = S.params.size
+    rng = np.random.default_rng(1)
+    g = rng.standard_normal(n).astype(np.float32)
+    sc = np.zeros(2 + 1024, np.float32); st = np.full(4, 9, np.uint32)
+    # healthy: scale 1 without clip, the clip scale with it
+    S.ck(L.lxo_chain_guard(S.sref(), ptr(S.ws), ptr(g), ptr(sc), 0, ptr(st), None), "guard")
+    assert sc[0] == 1.0 and list(st[:3]) == [0, 0, 0]
+    sc[0] = 0.25
+    S.ck(L.lxo_chain_guard(S.sref(), ptr(S.ws), ptr(g), ptr(sc), 1, ptr(st), None), "guard")
+    assert sc[0] == 0.25
+    # another rank's failure arrives as a NaN in the last gradient element
+    g2 = g.copy(); g2[-1] = np.nan
+    S.ck(L.lxo_chain_guard(S.sref(), ptr(S.ws), ptr(g2), ptr(sc), 1, ptr(st), None), "guard")
+    assert np.isnan(sc[0]) and list(st[:3]) == [0, 0, 1]
+    p = rng.standard_normal(n).astype(np.float32); m = rng.standard_normal(n).astype(np.float32); v = np.abs(rng.standard_normal(n)).astype(np.float32)
+    p0, m0, v0 = p.copy(), m.copy(), v.copy()
+    assert L.lxo_adam_step(n, ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_float(1e-3), ctypes.c_float(0.9), ctypes.c_float(0.999),
+                           ctypes.c_float(1e-8), ptr(sc), None) == 0
+    assert np.array_equal(p, p0) and np.array_equal(m, m0) and np.array_equal(v, v0)
+    for mode in (1, 2, 3):
+        assert L.lxo_optimizer_step(mode, n, ptr(p), ptr(g), ptr(v), ctypes.c_float(0.01), ptr(sc), None) == 0
+        assert np.array_equal(p, p0) and np.array_equal(v, v0)
+    if dtype == 1:
+        # this rank's own chains: the error words (forward block 0, backward block 1)
+        w = S.region("xdec_sync", np.uint32)
+        for blk, want in ((0, [5, 0, 1]), (1, [0, 6, 1])):
+            w[:] = 0
+            w[blk * (_abi_consts()[0] // 4) + _abi_consts()[1]] = want[0] or want[1]
+            sc[0] = 0.5
+            S.ck(L.lxo_chain_guard(S.sref(), ptr(S.ws), ptr(g), ptr(sc), 1, ptr(st), None), "guard")
+            assert np.isnan(sc[0]) and list(st[:3]) == want
+        w[:] = 0
+
+
+def _abi_consts():
+    from latex_ocr_amd import _abi
+    return _abi.LXO_XDEC_BLOCK_BYTES, _abi.LXO_XDEC_ERR_WORD
+
+
 def test_adam_and_clip():
     L = lib()
     rng = np.random.default_rng(0)
