@@ -243,6 +243,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     // unrolled sweeps behind uniform predicates), which spreads the concurrent atomics over nine times as many lines
     // (stamps: 70 k -> 47 k cycles on conv6, 77 k -> 69 k on conv2 where all 256 workgroups share one tile; the launch time moved
     // within noise: what remains is the L2 atomic rate for 18.9 M lane-atomics per launch).
+    if (p.det_slab) {
+        // deterministic mode: the partial tile goes to this workgroup's slot [tap][ci 64][co 128] of the slab with plain stores;
+        // wgrad_slab_reduce_kernel adds the slots of a tile in pixel-range order
+        float* const sb = p.det_slab + ((long long)split * ntiles + tile) * (9 * WCI * WCO) + (wci * 32 + 4 * (lane >> 5)) * WCO + wco * 32 + (lane & 31);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sb[(t * WCI + (e & 3) + 8 * (e >> 2)) * WCO] = acc[t][e];
+        return;
+    }
     const int co = co0 + wco * 32 + (lane & 31);
     if (co < Cout) {
         const int rot = (int)(blockIdx.x % 9u);
@@ -259,6 +269,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
         for (int t = 0; t < 9; ++t) if (t < rot) emit(acc[t], t);
     }
     WSTAMP(62);
+}
+
+// deterministic mode: dW[(tap * Cin + ci0 + ci)][co0 + co] += sum over the pixel ranges s = 0 .. nsplit-1 (in that order) of slab[s][tile][tap][ci][co];
+// slots of empty ranges were zeroed by the launcher
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int ntiles, int tiles_co, int Cin, int Cout,
+                                                               float* __restrict__ dw, int ldc) {
+    const int tile = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;                 // element of the 9 x 64 x 128 tile
+    if (i >= 9 * WCI * WCO) return;
+    const int co = i % WCO, ci = (i / WCO) % WCI, tap = i / (WCO * WCI);
+    const int ci0 = (tile / tiles_co) * WCI, co0 = (tile % tiles_co) * WCO;
+    float s = 0.f;
+    for (int q = 0; q < nsplit; ++q) s += slab[((long long)q * ntiles + tile) * (9 * WCI * WCO) + i];
+    if (co0 + co < Cout) dw[(long long)(tap * Cin + ci0 + ci) * ldc + co0 + co] += s;
 }
 
 }  // namespace
@@ -301,6 +325,13 @@ int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     q.dbg = g_wgrad_dbg;
     // splits are dealt to the 8 XCDs in turn: round the split count up to a multiple of 8 (empty ranges return at once)
     const int nsplit8 = (nsplit + 7) / 8 * 8;
+    if (q.det_slab) {
+        const size_t need = (size_t)nsplit * tiles * 9 * WCI * WCO;
+        if (need > q.det_floats) return -6;
+        HIPRC(hipMemsetAsync(q.det_slab, 0, need * sizeof(float), s));          // a range that turns out empty leaves its slot untouched
+    }
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * nsplit8), dim3(WTHREADS), 2 * WSTAGE, s, q, tiles_co, tiles_x, tiles_y, nblocks, nsplit, stagger);
+    if (q.det_slab)
+        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(9 * WCI * WCO / 256, tiles), dim3(256), 0, s, q.det_slab, nsplit, tiles, tiles_co, p.Cin, p.J, p.C, p.ldc);
     return (int)hipGetLastError();
 }

@@ -35,6 +35,7 @@ int lxo_k_add_mean_grad(float* dimg, const float* dmean, int B, int R, int C, hi
 // ntok_dev (nullable): device scalar holding the global token count; when set the kernel uses 1 / *ntok_dev instead of inv_ntok
 int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* lengths, void* dlogits, float* loss_acc, float inv_ntok,
                   const float* ntok_dev, const unsigned* chain_err, int B, int T, int V, int Vp, DetScratch det, hipStream_t st);      // chain_err (nullable): error word of the persistent decoder chain; non-zero poisons the loss (NaN)
+int lxo_k_colsum_det(const void* a, int bf16, long long lda, float* out, long long M, int N, DetScratch det, hipStream_t st);      // ordered column sums of an f32 / bf16 matrix (no atomics)
 int lxo_k_colsum(const float* a, long long lda, float* out, long long M, int N, DetScratch det, hipStream_t st);
 int lxo_k_embed_scatter(const float* demb, const int* formula, float* dtable, float* dstart, int B, int T, int D, int V, int det, hipStream_t st);
 int lxo_k_init_bwd(const float* dcc, Slabs dxh, const float* c0, const float* rec0, int ldr, float* dpre, int B, int U, int O, hipStream_t st);

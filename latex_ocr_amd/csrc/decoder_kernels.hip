@@ -1180,7 +1180,8 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
 
 // ---- f32 parity mode: reductions without float atomics (the order of every sum is fixed, so two runs agree bit for bit) ----
 // part[rb][n] = sum of rows [rb * rows_per, ...) of column n, rows in ascending order
-__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ a, long long lda, float* __restrict__ part, long long M, int N, int rows_per) {
+template <typename AT>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const AT* __restrict__ a, long long lda, float* __restrict__ part, long long M, int N, int rows_per) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const long long m0 = (long long)blockIdx.y * rows_per, m1 = m0 + rows_per < M ? m0 + rows_per : M;
     if (n >= N) return;
@@ -1188,7 +1189,7 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     for (long long mb = m0; mb < m1; mb += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const long long m = mb + u < m1 ? mb + u : m1 - 1; v[u] = a[m * lda + n]; }
+        for (int u = 0; u < 8; ++u) { const long long m = mb + u < m1 ? mb + u : m1 - 1; v[u] = to_f32(a[m * lda + n]); }
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (mb + u < m1) s += v[u];
     }
@@ -1726,19 +1727,22 @@ int lxo_k_ce_loss(int dt, const float* logits, const int* formula, const int* le
     if (part) return lxo_k_det_reduce(part, g, 2, 2, loss_acc, st);
     DONE;
 }
+// ordered column sums (no atomics): per-row-block partial sums into the scratch, then the blocks in order; a = f32 or (bf16 != 0) bf16
+int lxo_k_colsum_det(const void* a, int bf16, long long lda, float* out, long long M, int N, DetScratch det, hipStream_t st) {
+    if (!det.p) return -6;
+    if (M <= 0 || N <= 0) return 0;
+    long long maxslots = (long long)(det.floats / (size_t)N);
+    if (maxslots < 1) return -6;
+    if (maxslots > 1024) maxslots = 1024;
+    long long rows_per = (M + maxslots - 1) / maxslots;
+    if (rows_per < 64) rows_per = 64;
+    const int nrb = (int)((M + rows_per - 1) / rows_per);
+    if (bf16) hipLaunchKernelGGL((colsum_part_kernel<bf16_t>), dim3(cdiv(N, 256), nrb), dim3(256), 0, st, (const bf16_t*)a, lda, det.p, M, N, (int)rows_per);
+    else hipLaunchKernelGGL((colsum_part_kernel<float>), dim3(cdiv(N, 256), nrb), dim3(256), 0, st, (const float*)a, lda, det.p, M, N, (int)rows_per);
+    return lxo_k_det_reduce(det.p, nrb, N, N, out, st);
+}
 int lxo_k_colsum(const float* a, long long lda, float* out, long long M, int N, DetScratch det, hipStream_t st) {
-    if (det.p) {
-        // f32 parity mode: per-row-block partial sums, then the blocks in order (two launches, no atomics)
-        if (M <= 0 || N <= 0) return 0;
-        long long maxslots = (long long)(det.floats / (size_t)N);
-        if (maxslots < 1) return -6;
-        if (maxslots > 1024) maxslots = 1024;
-        long long rows_per = (M + maxslots - 1) / maxslots;
-        if (rows_per < 64) rows_per = 64;
-        const int nrb = (int)((M + rows_per - 1) / rows_per);
-        hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 256), nrb), dim3(256), 0, st, a, lda, det.p, M, N, (int)rows_per);
-        return lxo_k_det_reduce(det.p, nrb, N, N, out, st);
-    }
+    if (det.p) return lxo_k_colsum_det(a, 0, lda, out, M, N, det, st);      // parity / deterministic mode: two launches, no atomics
     const int rpb = 64;
     if (N % 4 == 0 && lda % 4 == 0 && ((uintptr_t)a & 15) == 0 && M > 0)
         hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(N, 256), cdiv((int)M, rpb)), dim3(256), 0, st, a, (int)lda, out, (int)M, N, rpb);

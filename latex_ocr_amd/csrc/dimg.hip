@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void dimg_fused_kernel(DimgArgs p) {
             for (int e = 0; e < 8; ++e) atomicAdd(&dbs[wj * 64 + tc + e], cs[e]);
         }
         __syncthreads();
-        if (tid < 128 && j0 + tid < p.C) atomicAdd(&p.db[j0 + tid], dbs[tid]);
+        if (p.db && tid < 128 && j0 + tid < p.C) atomicAdd(&p.db[j0 + tid], dbs[tid]);       // (deterministic mode: db == null, the caller sums the columns of dy6 in a fixed order)
     }
 }
 

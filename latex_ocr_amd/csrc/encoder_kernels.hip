@@ -338,7 +338,7 @@ LXO_DEV void c1_route(const c1_v16f& a, int g4, float bias, float g, float (&d)[
 
 __global__ __launch_bounds__(256) void conv1_pool_bwd_mfma_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, const bf16_t* __restrict__ dout,
-                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 float* __restrict__ dw, float* __restrict__ db, float* __restrict__ part,
                                                                  int B, int H, int W, int Hp, int Wp) {
     __shared__ __attribute__((aligned(16))) C1Patch spb[2];
     __shared__ float red[4][10][64];                               // per wave: 9 taps + bias, 64 channels
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_mfma_kernel(const uint8_t*
     for (int i = threadIdx.x; i < 640; i += 256) {
         const int t = i >> 6, c = i & 63;
         const float v = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
-        if (t < 9) atomicAdd(&dw[t * 64 + c], v); else atomicAdd(&db[c], v);
+        if (part) part[(long long)blockIdx.x * 640 + i] = v;       // deterministic mode: this workgroup's slot [dw 576 | db 64]; lxo_k_det_reduce adds the slots in order
+        else if (t < 9) atomicAdd(&dw[t * 64 + c], v); else atomicAdd(&db[c], v);
     }
 }
 
@@ -840,8 +841,14 @@ int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float
     if (dt == LXO_BF16 && conv1_mfma()) {
         const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
         static int cap = -1; if (cap < 0) { const char* e = getenv("LXO_C1_CAP"); cap = e ? atoi(e) : 512; }
-        hipLaunchKernelGGL(conv1_pool_bwd_mfma_kernel, dim3(grid_for((long long)B * Hp * ((Wp + C1_SEG - 1) / C1_SEG), 4, cap)), dim3(256), 0, s,
-                           img, w, b, (const bf16_t*)dout, dw, db, B, H, W, Hp, Wp);
+        const int g = grid_for((long long)B * Hp * ((Wp + C1_SEG - 1) / C1_SEG), 4, cap);
+        float* part = nullptr;                  // deterministic mode: one slot [dw 576 | db 64] per workgroup, added in workgroup order
+        if (det.p) { if ((size_t)g * 640 > det.floats) return -6; part = det.p; }
+        hipLaunchKernelGGL(conv1_pool_bwd_mfma_kernel, dim3(g), dim3(256), 0, s, img, w, b, (const bf16_t*)dout, dw, db, part, B, H, W, Hp, Wp);
+        if (part) {
+            if (int rc = lxo_k_det_reduce(part, g, 640, 576, dw, s)) return rc;
+            return lxo_k_det_reduce(part + 576, g, 640, 64, db, s);
+        }
         return (int)hipGetLastError();
     }
     const int rc = dt == LXO_BF16 ? conv1_bwd_t<bf16_t>(img, w, b, dout, dw, db, B, H, W, det, s) : conv1_bwd_t<float>(img, w, b, dout, dw, db, B, H, W, det, s);

@@ -41,6 +41,9 @@ struct GemmTN {
     long long strideA, strideB, strideC;
     int atomic;                // 1: atomicAdd into C (C pre-initialised); 0: plain store (nsplit must be 1)
     unsigned long long* dbg;   // measurement aid (null = off): conv_wgrad_kernel stamps its pixel blocks here, [workgroup][64] (tools/conv_stamps.py)
+    // deterministic mode (bf16 kernels; the f32 kernels always take ONE row range per tile): det_slab != null = no float atomics --
+    // conv_wgrad_kernel stores its partial tiles to the slab and an ordered pass adds them; the dense kernels take one row range per tile
+    float* det_slab; size_t det_floats;
 };
 
 // dt: LXO_F32 / LXO_BF16 = compute type (type of Bp / conv tensors);

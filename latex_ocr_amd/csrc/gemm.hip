@@ -710,11 +710,16 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
         if (q.conv) return launch_tn<float, true, float, float>(q, s);
         return launch_tn<float, false, float, float>(q, s);
     }
+    if (p.det_slab && !p.conv) {           // deterministic bf16 mode, dense product: ONE row range per output tile (one writer per element)
+        GemmTN q = p; q.nsplit = 1; q.det_slab = nullptr;
+        return lxo_launch_gemm_tn(dt, a_f32, b_f32, q, s);
+    }
     if (p.conv) {
         if (a_f32 || b_f32) return -3;
         static int use_halo = -1;
         if (use_halo < 0) { const char* e = getenv("LXO_WGRAD_HALO"); use_halo = (e && e[0] == '0') ? 0 : 1; }
         if (use_halo && p.Cin % 64 == 0 && p.J % 8 == 0 && p.atomic && p.nbatch == 1) { const int rc = lxo_launch_conv_wgrad(p, s); if (rc != -2) return rc; }
+        if (p.det_slab) { GemmTN q = p; q.nsplit = 1; return launch_tn<bf16_t, true, bf16_t, bf16_t>(q, s); }
         return launch_tn<bf16_t, true, bf16_t, bf16_t>(p, s);
     }
     if (!a_f32 && !b_f32) {

@@ -31,6 +31,7 @@ int tn(const Plan& P, bool a_f32, bool b_f32, const void* A, int lda, const void
     const int maxs = M / 64 > 0 ? M / 64 : 1;
     if (ns > maxs) ns = maxs;
     g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
+    if (P.bf && P.det()) g.nsplit = 1;                    // bf16 deterministic mode: one row range per output tile = one writer per element
     if (P.s.dtype == LXO_F32) { a_f32 = true; b_f32 = true; }
     return lxo_launch_gemm_tn(P.s.dtype, a_f32, b_f32, g, st);
 }
@@ -541,7 +542,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         a.dctx = dhc + U; a.ld_dctx = (long long)B * P.HC; a.HC = P.HC;
         a.datt = P.ws<bf16_t>(ws, W_DATTIMG); a.W = (const bf16_t*)P.pk(wp, K_ATT_IMG); a.ldw = E;
         a.dmean = dmean; a.T = T; a.B = B; a.R = P.R; a.C = C; a.E = E;
-        a.y6 = P.ws<bf16_t>(ws, W_Y6); a.dy6 = P.ws<bf16_t>(ws, W_DIMG); a.db = gw(P_CONV6_B);
+        a.y6 = P.ws<bf16_t>(ws, W_Y6); a.dy6 = P.ws<bf16_t>(ws, W_DIMG); a.db = P.det() ? nullptr : gw(P_CONV6_B);      // deterministic mode: lxo_encoder_bwd sums the columns of d_y6 in order
         RC(lxo_launch_dimg_fused(a, st));
     } else {
         {

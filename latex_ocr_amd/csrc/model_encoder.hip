@@ -119,13 +119,13 @@ static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din
     // algorithmic FLOPs of a data gradient = those of the layer's forward, whatever grid the kernel pads to
     LxoTimed tm("conv_dgrad", conv_name(Cin, Cout, valid), 2.0 * P.s.B * Hout * Wout * 9.0 * Cin * Cout, st);
     RC(lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st));
-    // f32 parity mode: the bias gradient is an ordered column sum of the masked result (the fused sum uses float atomics)
-    if (P.det() && colsum) RC(lxo_k_colsum((const float*)din, Cin, colsum, g.M, Cin, det, st));
+    // parity / deterministic mode: the bias gradient is an ordered column sum of the masked result (the fused sum uses float atomics)
+    if (P.det() && colsum) RC(lxo_k_colsum_det(din, P.bf ? 1 : 0, Cin, colsum, g.M, Cin, det, st));
     return 0;
 }
 // wgrad: dW[(kh,kw,ci)][co] += sum_m in[m shifted][ci] * d_out[m][co]
 static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw, int H, int W, int Cin, int Cout,
-                      bool valid, hipStream_t st) {
+                      bool valid, DetScratch det, hipStream_t st) {
     GemmTN g; memset(&g, 0, sizeof(g));
     g.A = in; g.B = dout; g.C = dw;
     g.conv = 1; g.H = H; g.W = W; g.Cin = Cin;
@@ -137,6 +137,7 @@ static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw
     const int maxs = g.M / 256 > 0 ? g.M / 256 : 1;
     if (ns > maxs) ns = maxs;
     g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
+    if (P.bf && P.det()) { g.det_slab = det.p; g.det_floats = det.floats; }        // bf16 deterministic mode: partial tiles to the scratch, added in order
     LxoTimed tm("conv_wgrad", conv_name(Cin, Cout, valid), 2.0 * g.M * g.I * g.J, st);
     return lxo_launch_gemm_tn(P.s.dtype, 0, 0, g, st);
 }
@@ -215,7 +216,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
     auto dbp = [&](int pid) -> float* { return P.det() ? nullptr : gw(pid); };
     auto dbsum = [&](const void* x, long long rows, int Cc, int pid) -> int {
         if (!P.det()) return 0;
-        return lxo_k_colsum((const float*)x, Cc, gw(pid), rows, Cc, det, st);
+        return lxo_k_colsum_det(x, P.bf ? 1 : 0, Cc, gw(pid), rows, Cc, det, st);
     };
     hipStream_t side = g_enc_side;
     bool pending[3] = {false, false, false};
@@ -227,10 +228,10 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
     // weight gradient of a layer whose d_y sits in buffer xi (just produced on the main stream)
     auto wgrad = [&](const void* in, int xi, float* dw, int H, int W, int Cin, int Cout, bool valid, const void* dy_at = nullptr) -> int {
         const void* dy = dy_at ? dy_at : G[xi];
-        if (!side) return conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, st);
+        if (!side) return conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, det, st);
         HIPRC(hipEventRecord(g_ev_x, st));
         HIPRC(hipStreamWaitEvent(side, g_ev_x, 0));
-        RC(conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, side));
+        RC(conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, det, side));
         HIPRC(hipEventRecord(g_ev_free[xi], side));
         pending[xi] = true;
         return 0;
@@ -244,6 +245,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         case 6:   // d_y6 = d_img * (y6>0) -> X ; wgrad6 ; d_p5 = dgrad6 -> Y
             if (P.dimg_masked()) {        // the decoder left d_y6 (masked, compute dtype) in "d_img" and summed the bias gradient
                 const void* dy6 = P.ws<void>(ws, W_DIMG);
+                RC(dbsum(dy6, (long long)B * P.R, C, P_CONV6_B));          // deterministic mode: the decoder's GEMM left the bias sum to this ordered pass
                 RC(wgrad(P.ws<void>(ws, W_P5), XB[6], gw(P_CONV6_W), P.H6, P.W5, C, C, true, dy6));
                 RC(acquire(YB[6]));
                 RC(conv_dgrad(P, dy6, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, det, st));
@@ -268,6 +270,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
                 t.lda = 8 * C; t.ldb = C; t.ldc = C;
                 { int ns = M / 2048; if (ns < 1) ns = 1; if (ns > 16) ns = 16; t.nsplit = ns; }
                 t.nbatch = 1; t.atomic = 1;
+                if (P.bf && P.det()) { t.det_slab = det.p; t.det_floats = det.floats; }
                 RC(lxo_launch_gemm_tn(dt, 0, 0, t, st));
                 GemmNT g; memset(&g, 0, sizeof(g));
                 g.A = Yup; g.Bp = P.pk(wp, K_CONVS_D); g.C = P.ws<void>(ws, W_COLS);
@@ -281,7 +284,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
                 RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), det, st));
                 break;
             }
-            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M5), Yup, X, dbp(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
             else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), Yup, X, dbp(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
             RC(dbsum(X, (long long)B * P.H4 * P.W2, C, P_CONV5_B));
             RC(wgrad(P.ws<void>(ws, W_P4), XB[5], gw(P_CONV5_W), P.H4, P.W2, 256, C, false));
@@ -291,7 +294,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         case 4:   // d_y4 = route(d_p4) -> X (cnn: already there, masked) ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> Y (+ db3)
             if (!P.cnn) {
                 RC(acquire(XB[4]));
-                if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
+                if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M4), Yup, X, dbp(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
                 else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), Yup, X, dbp(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
                 RC(dbsum(X, (long long)B * P.H2 * P.W2, 256, P_CONV4_B));
             }
@@ -306,7 +309,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
             break;
         case 2:   // d_y2 = route(d_p2) -> X ; wgrad2 ; d_p1 = dgrad2 -> Y
             RC(acquire(XB[2]));
-            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M2), Yup, X, dbp(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
             else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), Yup, X, dbp(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
             RC(dbsum(X, (long long)B * P.H1 * P.W1, 128, P_CONV2_B));
             RC(wgrad(P.ws<void>(ws, W_P1), XB[2], gw(P_CONV2_W), P.H1, P.W1, 64, 128, false));

@@ -101,7 +101,8 @@ struct Plan {
     bool dimg_masked() const { return bf && s.E % 32 == 0 && !rnn; }
     // f32 mode is the PARITY mode: every reduction runs in a fixed order (no float atomics), so a step is reproducible bit for bit
     // (SURVEY.md Appendix D step 8); bf16 mode keeps the atomic epilogues
-    bool det() const { return !bf; }
+    // lxo_shape.deterministic extends that to the bf16 mode (opt-in: ordered partial slots instead of the atomic epilogues)
+    bool det() const { return !bf || s.deterministic != 0; }
     // bf16 training: the attention kernels of the recurrence read E_x = e^{2 att_img} (region att_exp) and form tanh from one reciprocal
     // per element; LXO_ATT_EXP=0 keeps the x form (A/B)
     bool att_exp() const;

@@ -141,10 +141,14 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
     wb[W_ATT_EXP] = bf ? BL * R * E * esz : 0;
     wb[W_XSYNC] = bf ? 2 * ((size_t)4096 + (384u << 10)) : 8192;     // one block per chain, forward then backward (xdec.h: kXDecBlockBytes)
-    if (!bf) {        // the largest user: d_beta, one E-vector per (sample, 16 regions) workgroup; column sums use at most 1024 row blocks x 4U columns
+    if (!bf || s.deterministic) {        // the largest user (f32): d_beta, one E-vector per (sample, 16 regions) workgroup; column sums use at most 1024 row blocks x 4U columns
         size_t need = BL * (size_t)((R + 15) / 16) * E * f4;
         const size_t floor_ = (size_t)1024 * (4 * U > 2048 ? 4 * U : 2048) * f4;
         wb[W_DET] = need > floor_ ? need : floor_;
+        // bf16 deterministic mode: conv_wgrad_kernel stores one (64 ci x 128 co x 9 taps) f32 partial per (pixel range, tile) workgroup
+        // -- at most 264 of them (256 rounded up to whole XCD rounds) -- and an ordered pass adds them (conv_wgrad.hip)
+        const size_t wg = (size_t)264 * 9 * 64 * 128 * f4;
+        if (bf && wb[W_DET] < wg) wb[W_DET] = wg;
     }
     const int nb = s.beam > 1 ? s.beam : 1;
     const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)

@@ -170,6 +170,12 @@ class DataParallel(object):
         if self._cnt_ev[slot] is not None:     # a non-syncing caller may run more than 4 steps ahead of the device
             self._cnt_ev[slot].synchronize()
         pin[0] = float(n_local)
+        # ONE communicator, two streams: the count of step N + 1 must not overtake the last gradient bucket of step N on the device.  The host
+        # order is already fixed (finish() joined the bucket queue before this call), RCCL orders the kernels of one communicator itself, and
+        # this wait makes the order explicit in the stream graph as well (the count stream waiting for the SIDE stream costs the compute
+        # stream nothing -- tools/queue_probe.py: only waits on compute-stream events do)
+        if self.side is not None:
+            self.cnt_stream.wait_stream(self.side)
         with torch.cuda.stream(self.cnt_stream):
             t = pin.to(self.device, non_blocking=True)
             copied = torch.cuda.Event()
