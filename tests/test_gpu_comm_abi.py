@@ -66,3 +66,47 @@ def test_dataparallel_uses_the_abi_comm_world1():
         dp.close()
     finally:
         td.destroy_process_group()
+
+
+@pytest.mark.parametrize("host_ordered", ["1", "0"])
+def test_dp_step_stress_world1_chains_beside_rccl(host_ordered):
+    """200 data-parallel steps at world size 1 with the persistent decoder chains (bf16, B = 8): ONE communicator driven from two host
+    threads (main: token count on its stream; helper: gradient buckets on the side stream) on three streams, the chains kept clear of
+    the collectives, lxo_chain_guard behind the exchange -- in both bucket-ordering modes.  Every step's chain error words are looked at
+    (Engine.chain_failures / dropped_steps stay 0), the run ends on the same weights as the same 200 steps without the exchange to
+    f32-atomic noise, and nothing hangs.  (The N-rank run itself is the driver's: no box here has a second GPU.)"""
+    import os
+    import torch.distributed as td
+    from gpu_common import Engine, batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29%03d" % (650 + int(host_ordered))
+    old = os.environ.get("LXO_DP_HOST_ORDERED")
+    os.environ["LXO_DP_HOST_ORDERED"] = host_ordered
+    td.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from latex_ocr_amd.dist import DataParallel
+        dp = DataParallel(device="cuda:0")
+        assert dp.lxo is not None and dp.lxo.ranks_seen == 1 and dp.host_ordered == (host_ordered == "1")
+        V = 50
+        batches = [batch(8, 32, 128, V, 3, 9, seed=40 + i) for i in range(4)]
+        a = Engine(V, dtype="bf16", seed=0); b = Engine(V, dtype="bf16", seed=0)
+        for i in range(200):
+            img, f, l = batches[i % 4]
+            la = a.train_step(img, f, l, 1e-3, dist=dp, sync_loss=(i % 50 == 49))
+        torch.cuda.synchronize()
+        a._chain_health_poll(wait=True)
+        assert a.chain_used and a.chain_used_bwd and a.chain_failures == 0 and getattr(a, "dropped_steps", 0) == 0 and a.adam_t == 200
+        for i in range(200):
+            img, f, l = batches[i % 4]
+            lb = b.train_step(img, f, l, 1e-3, sync_loss=(i % 50 == 49))
+        torch.cuda.synchronize()
+        print("host_ordered=%s: loss after 200 steps with / without the exchange: %.4f / %.4f" % (host_ordered, la, lb))
+        assert np.isfinite(la) and np.isfinite(lb) and abs(la - lb) <= 0.3 * abs(lb) + 0.05, (la, lb)       # two bf16 (atomic-order) trajectories of 200 steps
+        assert la < 3.9 and torch.isfinite(a.params).all()                                # below ln 50: it trained
+        dp.close()
+    finally:
+        td.destroy_process_group()
+        if old is None:
+            os.environ.pop("LXO_DP_HOST_ORDERED", None)
+        else:
+            os.environ["LXO_DP_HOST_ORDERED"] = old
+

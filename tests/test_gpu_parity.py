@@ -29,10 +29,14 @@ def _grads_check(dtype, tol_loss, min_cos, dropout=None, dims=None, hw=(32, 128)
     assert stats[1] == n
     assert abs(loss - float(loss_ref)) / float(loss_ref) < tol_loss, (loss, float(loss_ref))
     got = eng.grad_dict()
-    worst = 1.0
+    worst, wk = 1.0, None
     for k in G:
         c = cosine(got[k], G[k].numpy())
-        worst = min(worst, c)
+        if c < worst:
+            worst, wk = c, k
+    print("%s: loss rel %.2e; worst gradient cosine %.6f (%s), bar %.5f" % (dtype, abs(loss - float(loss_ref)) / float(loss_ref), worst, wk, min_cos))
+    for k in G:
+        c = cosine(got[k], G[k].numpy())
         assert c > min_cos, (k, c, rel(got[k], G[k].numpy()))
     return worst
 
