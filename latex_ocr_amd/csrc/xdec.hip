@@ -54,6 +54,18 @@ constexpr int kLL = LXO_XDEC_LLMASK;
 #endif
 constexpr int kLLB = LXO_XDEC_LLMASK_B;
 
+// Where the forward chain requests the first two row blocks of the NEXT step's attention stream (registers xiA / xiB):
+//   0  at the end of this step's chunk (round 4): they land before the XCD barrier behind P3 -- `vmcnt` counts in order, so the barrier's
+//      s_waitcnt vmcnt(0) (it must cover the partial stores) also waits for them: that IS the ~2 us wait behind P3
+//   1  in the NEXT step's P1, behind the workgroup barrier that follows the partial tiles (waves 2..7: they have no epilogue work) / behind
+//      the epilogue's stores (waves 0, 1): the requests fly during the P1 epilogue, the h~ hand-over and P2, whose own loads are younger
+//   2  at the end of P2 (behind the att_h stores): they fly during the att_h hand-over only
+//   3  in P4 behind the merge of the chunk partials (its loads are the last ones P4 waits for): they fly during the o projection, P1 and P2
+#ifndef LXO_XDEC_PF
+#define LXO_XDEC_PF 0
+#endif
+constexpr int kPF = LXO_XDEC_PF;
+
 constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
 constexpr int SCMAX = 2048;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB)
 
@@ -311,6 +323,12 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     const rsrc_t rll_o = make_rsrc(ll_o, (unsigned)B * 256u * 8u);
     unsigned long long* dbg = p.dbg ? p.dbg + ((long long)(xcc * 32 + rank) * T) * 16 : nullptr;
 #define XSTAMP(i) do { if (dbg && tid == 0) dbg[t * 16 + (i)] = wall_clock64(); } while (0)
+    // the first two row blocks of step `ts`'s walk (direction ts & 1) into the two buffers
+    auto prefetch = [&](int ts) {
+        const int rv = ts & 1;
+        att_load<ATT_U>(xiA, xaA, imq, aiq, wave + XW * ATT_U * (rv ? nblk - 1 : 0), anq, lane);
+        att_load<ATT_U>(xiB, xaB, imq, aiq, wave + XW * ATT_U * (rv ? nblk - 2 : 1), anq, lane);
+    };
     for (int t = 0; t < T; ++t) {
         dr.t = t;
         XSTAMP(0);
@@ -360,6 +378,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             XSTAMP(10);
             __syncthreads();
             XSTAMP(11);
+            if (kPF == 1 && t > 0 && wave >= 2) prefetch(t);      // (step 0's blocks were requested in the prologue)
             if (tid < NB * 16) {
                 // TF-1.12 LSTMCell, gate order i, j, f, o, forget_bias 1.0 (attention_cell.py:71)
                 float g[4];
@@ -388,6 +407,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 const unsigned mine = (unsigned)htb, other = (unsigned)__shfl_xor((int)mine, 1);
                 if (!(eu & 1)) { const u32x2 wv = {mine | (other << 16), (unsigned)(t + 1)}; *reinterpret_cast<u32x2*>(ll_ht + ((bb * 256 + (u >> 1)) * 2)) = wv; }
             }
+            if (kPF == 1 && t > 0 && wave < 2) prefetch(t);
         }
         XSTAMP(1);
         if (kLL & 1) __syncthreads();                       // (the partial tiles in LDS are rewritten by P2)
@@ -426,6 +446,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 const u32x2 wv = {__float_as_uint(v), (unsigned)(t + 1)};
                 *reinterpret_cast<u32x2*>(ll_ah + ((b0 + row) * XE + e0 + e) * 2) = wv;      // the attention workgroups poll these words: no barrier
             }
+            if (kPF == 2 && t > 0) prefetch(t);
         }
         XSTAMP(3);
         if (!(kLL & 2)) xbar(xsync, rank, ++ph, err, &s_dead);
@@ -456,6 +477,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             // entering: block 0 in A and block 1 in B (requested at the end of the previous step's P3).  Each buffer is refilled right
             // after its block is computed -- with the block two ahead, or, at the end of the chunk, with the NEXT STEP's first two blocks
             // (its direction is the other one): they land during P4 / P1 / P2
+            if constexpr (kPF == 0) {
             for (int it = 0; it < nblk; it += 2) {
                 att_block<ATT_U, EXPD>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, sc, lane);
                 __builtin_amdgcn_sched_barrier(0);
@@ -467,6 +489,26 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                     att_load<ATT_U>(xiB, xaB, imq, aiq, (it + 3 < nblk) ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            } else {
+            // the chunk ends with nothing in flight (the next step's first blocks are requested elsewhere: kPF).  Peeled so that every load is
+            // unconditional on its path (a load behind a branch makes hipcc wait vmcnt(0) at the join)
+            int it = 0;
+            for (; it + 3 < nblk; it += 2) {
+                att_block<ATT_U, EXPD>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, sc, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                att_load<ATT_U>(xiA, xaA, imq, aiq, XBASE(it + 2, rev), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                att_block<ATT_U, EXPD>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, sc, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                att_load<ATT_U>(xiB, xaB, imq, aiq, XBASE(it + 3, rev), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int rem = nblk - it;                           // 0 (empty chunk) .. 3
+            if (rem >= 1) att_block<ATT_U, EXPD>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, sc, lane);
+            if (rem == 3) { __builtin_amdgcn_sched_barrier(0); att_load<ATT_U>(xiA, xaA, imq, aiq, XBASE(it + 2, rev), anq, lane); __builtin_amdgcn_sched_barrier(0); }
+            if (rem >= 2) att_block<ATT_U, EXPD>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, sc, lane);
+            if (rem == 3) att_block<ATT_U, EXPD>(xiA, xaA, XBASE(it + 2, rev), an, ah, bt, m, l, acc, sc, lane);
             }
 #undef XBASE
             // merge the 8 waves
@@ -566,6 +608,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                     }
                 }
             }
+            if (kPF == 3) prefetch(t + 1);
             // alpha of this workgroup's chunk (what the reference hands to its visualisation hook, attention_mechanism.py:96-105)
             {
                 const float mm = smax[as], inv = sinv[as];

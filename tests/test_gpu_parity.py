@@ -12,6 +12,9 @@ pytestmark = pytest.mark.gpu
 from gpu_common import *  # noqa
 
 
+CONV1_BF16 = 0.998       # measured on MI355X at these toy shapes: 0.9986 .. 0.9994 (B = 64 at 128 x 512: 0.99995, tests/test_gpu_benchcfg.py)
+
+
 def _grads_check(dtype, tol_loss, min_cos, dropout=None, dims=None, hw=(32, 128), n=6):
     V = 50
     img, f, l = batch(n, hw[0], hw[1], V, 5, 12, seed=7)
@@ -29,15 +32,15 @@ def _grads_check(dtype, tol_loss, min_cos, dropout=None, dims=None, hw=(32, 128)
     assert stats[1] == n
     assert abs(loss - float(loss_ref)) / float(loss_ref) < tol_loss, (loss, float(loss_ref))
     got = eng.grad_dict()
-    worst, wk = 1.0, None
-    for k in G:
-        c = cosine(got[k], G[k].numpy())
-        if c < worst:
-            worst, wk = c, k
-    print("%s: loss rel %.2e; worst gradient cosine %.6f (%s), bar %.5f" % (dtype, abs(loss - float(loss_ref)) / float(loss_ref), worst, wk, min_cos))
-    for k in G:
-        c = cosine(got[k], G[k].numpy())
-        assert c > min_cos, (k, c, rel(got[k], G[k].numpy()))
+    cs = sorted((cosine(got[k], G[k].numpy()), k) for k in G)
+    worst = cs[0][0]
+    print("%s: loss rel %.2e; lowest gradient cosines %s; bar %.5f (conv1's kernel / bias in bf16: %.4f)" % (
+        dtype, abs(loss - float(loss_ref)) / float(loss_ref), ", ".join("%.6f %s" % (c, k.split("/", 1)[-1]) for c, k in cs[:3]), min_cos, CONV1_BF16))
+    for c, k in cs:
+        # bf16: conv1's kernel and bias gradients (576 + 64 numbers, each a sum over every pixel of bf16-rounded d_y1: the noisiest of the 28;
+        # measured 0.9986 .. 0.9994) have their own bar; the other 26 measure >= 0.99918 at these toy shapes
+        bar = CONV1_BF16 if (dtype == "bf16" and k.startswith("Encoder/convolutional_encoder/conv2d/")) else min_cos
+        assert c > bar, (k, c, rel(got[k], G[k].numpy()))
     return worst
 
 
@@ -46,7 +49,7 @@ def test_fwd_bwd_f32():
 
 
 def test_fwd_bwd_bf16():
-    _grads_check("bf16", 1e-3, 0.98)
+    _grads_check("bf16", 1e-3, 0.999)
 
 
 def test_fwd_bwd_odd_image_shape_f32():
@@ -55,7 +58,7 @@ def test_fwd_bwd_odd_image_shape_f32():
 
 
 def test_fwd_bwd_odd_image_shape_bf16():
-    _grads_check("bf16", 1e-3, 0.97, hw=(37, 141), n=3)
+    _grads_check("bf16", 1e-3, 0.999, hw=(37, 141), n=3)
 
 
 def test_fwd_bwd_encoder_cnn_f32():
@@ -64,10 +67,10 @@ def test_fwd_bwd_encoder_cnn_f32():
 
 
 def test_fwd_bwd_encoder_cnn_bf16():
-    _grads_check("bf16", 1e-3, 0.97, dims=dict(cnn=True))
+    _grads_check("bf16", 1e-3, 0.999, dims=dict(cnn=True))
 
 
-@pytest.mark.parametrize("dtype,tol,cos", [("f32", 2e-5, 0.9999), ("bf16", 1e-3, 0.97)])
+@pytest.mark.parametrize("dtype,tol,cos", [("f32", 2e-5, 0.9999), ("bf16", 1e-3, 0.999)])
 def test_fwd_bwd_mixed_widths(dtype, tol, cos):
     # model.json with unequal widths (attn_cell_config / att dims are free in the reference): U + C = 384 is a contraction the fused
     # step kernels cannot chunk, so the decoder runs on the split-K step kernels -- same results either way
@@ -114,7 +117,7 @@ def test_fwd_bwd_dropout_f32():
 
 
 def test_fwd_bwd_dropout_bf16():
-    _grads_check("bf16", 2e-3, 0.97, dropout=(0.8, 77))
+    _grads_check("bf16", 2e-3, 0.999, dropout=(0.8, 77))
 
 
 def test_encoder_features_f32():
