@@ -65,6 +65,13 @@ constexpr int kLLB = LXO_XDEC_LLMASK_B;
 #define LXO_XDEC_PF 0
 #endif
 constexpr int kPF = LXO_XDEC_PF;
+// the same for the backward chain: 0 at the end of the chunk (Q2); 1 in Q3 behind its first workgroup barrier (the chunk partials are in
+// LDS by then); 3 in Q4 behind the workgroup barrier that follows the partial tiles.  Bit 4 (+4): the forward values of the coming phases
+// (gates, c, d_o(logits), o, ctx, att_h: HBM loads, ~2 us) are requested at that site too, ONE STEP AHEAD, instead of at the end of Q2.
+#ifndef LXO_XDEC_PFB
+#define LXO_XDEC_PFB 0
+#endif
+constexpr int kPFB = LXO_XDEC_PFB & 3, kPFB_FV = (LXO_XDEC_PFB >> 2) & 1;
 
 constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
 constexpr int SCMAX = 2048;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB)
@@ -806,6 +813,30 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
     const rsrc_t rll_dc = make_rsrc(ll_dc, (unsigned)B * XC * 8u);
     unsigned long long* dbg = p.dbg ? p.dbg + ((long long)(xcc * 32 + rank) * T) * 16 : nullptr;
 #define XSTAMP(i) do { if (dbg && tid == 0) dbg[(T - 1 - t) * 16 + (i)] = wall_clock64(); } while (0)
+    // forward values the phases behind Q2 of step ts need (gates, c_ts, c_{ts-1}: Q3 of step ts; d_o(logits), o of step ts - 1: Q4) and the next
+    // Q2's ctx / att_h (step ts - 1)
+    auto fwd_values = [&](int ts) {
+        const long long sq = (long long)ts * B;
+        const int tq = max(ts - 1, 0);
+        const float* cp = p.rec + ((long long)(tq + 1) * B + ab) * p.REC + OFF_CTX + lane * 8;
+        cx0 = *reinterpret_cast<const f32x4*>(cp); cx1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        ahn = *reinterpret_cast<const f32x4*>(p.atth + ((long long)tq * B + ab) * XE + lane * 4);
+        const float* gr = p.gates + (sq + b0 + e3r) * 4 * XU + u0 + e3u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lg[q] = gr[q * XU];
+        lcc = p.cs[(sq + B + b0 + e3r) * XU + u0 + e3u];
+        lcp = p.cs[(sq + b0 + e3r) * XU + u0 + e3u];
+        const int nq4 = min(n0 + e4c, XO - 1);
+        qd = p.dolog[((long long)tq * B + b0 + e4r) * XO + nq4];
+        qo = p.rec[((long long)(tq + 1) * B + b0 + e4r) * p.REC + nq4];
+    };
+    // the first two row blocks of step ts's walk (direction ts & 1) and their alpha rows
+    auto prefetch_b = [&](int ts) {
+        const int rv = ts & 1;
+        const rsrc_t ralq = make_rsrc(p.alpha + (long long)ts * B * p.Rp + al_off, (unsigned)anq * 4u);
+        attb_load<ATT_U>(xiA, xaA, alA, imq, aiq, ralq, wave + XW * ATT_U * (rv ? nblk - 1 : 0), anq, lane);
+        attb_load<ATT_U>(xiB, xaB, alB, imq, aiq, ralq, wave + XW * ATT_U * (rv ? nblk - 2 : 1), anq, lane);
+    };
     for (int t = T - 1; t >= 0; --t) {
         dr.t = t;
         XSTAMP(0);
@@ -882,6 +913,7 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
             const int tn = max(t - 1, 0);
             const rsrc_t ral = make_rsrc(p.alpha + sp * p.Rp + al_off, (unsigned)anq * 4u);
             const rsrc_t raln = make_rsrc(p.alpha + (long long)tn * B * p.Rp + al_off, (unsigned)anq * 4u);
+            if constexpr (kPFB == 0) {
             for (int it = 0; it < nblk; it += 2) {
                 const bool moreA = it + 2 < nblk, moreB = it + 3 < nblk;
                 attb_block<ATT_U, EXPD>(xiA, xaA, alA, XBASE(it, rev), an, dc, ah, s, acc, de_row, lane);
@@ -895,20 +927,27 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // forward values of the coming phases (unconditional, clamped indices)
-            {
-                const float* cp = p.rec + ((long long)(tn + 1) * B + ab) * p.REC + OFF_CTX + lane * 8;
-                cx0 = *reinterpret_cast<const f32x4*>(cp); cx1 = *reinterpret_cast<const f32x4*>(cp + 4);
-                ahn = *reinterpret_cast<const f32x4*>(p.atth + ((long long)tn * B + ab) * XE + lane * 4);
-                const float* gr = p.gates + (sp + b0 + e3r) * 4 * XU + u0 + e3u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) lg[q] = gr[q * XU];
-                lcc = p.cs[(sp + B + b0 + e3r) * XU + u0 + e3u];
-                lcp = p.cs[(sp + b0 + e3r) * XU + u0 + e3u];
-                const int nq4 = min(n0 + e4c, XO - 1);
-                qd = p.dolog[((long long)tn * B + b0 + e4r) * XO + nq4];
-                qo = p.rec[((long long)(tn + 1) * B + b0 + e4r) * p.REC + nq4];
+            } else {
+            // the chunk ends with nothing in flight (kPFB: the next step's first blocks are requested in Q3 / Q4); peeled as in the forward chain
+            int it = 0;
+            for (; it + 3 < nblk; it += 2) {
+                attb_block<ATT_U, EXPD>(xiA, xaA, alA, XBASE(it, rev), an, dc, ah, s, acc, de_row, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                attb_load<ATT_U>(xiA, xaA, alA, imq, aiq, ral, XBASE(it + 2, rev), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                attb_block<ATT_U, EXPD>(xiB, xaB, alB, XBASE(it + 1, rev), an, dc, ah, s, acc, de_row, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                attb_load<ATT_U>(xiB, xaB, alB, imq, aiq, ral, XBASE(it + 3, rev), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const int rem = nblk - it;
+            if (rem >= 1) attb_block<ATT_U, EXPD>(xiA, xaA, alA, XBASE(it, rev), an, dc, ah, s, acc, de_row, lane);
+            if (rem == 3) { __builtin_amdgcn_sched_barrier(0); attb_load<ATT_U>(xiA, xaA, alA, imq, aiq, ral, XBASE(it + 2, rev), anq, lane); __builtin_amdgcn_sched_barrier(0); }
+            if (rem >= 2) attb_block<ATT_U, EXPD>(xiB, xaB, alB, XBASE(it + 1, rev), an, dc, ah, s, acc, de_row, lane);
+            if (rem == 3) attb_block<ATT_U, EXPD>(xiA, xaA, alA, XBASE(it + 2, rev), an, dc, ah, s, acc, de_row, lane);
+            }
+            // forward values of the coming phases (unconditional, clamped indices)
+            if constexpr (!kPFB_FV) fwd_values(t);
 #pragma unroll
             for (int j = 0; j < 4; ++j) redc[wave][lane * 4 + j] = acc[j] * bt[j];
             __syncthreads();
