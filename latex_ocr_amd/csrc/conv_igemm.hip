@@ -11,6 +11,7 @@
 //   (Rounds 1-2 also carried a 256 x 128 x 64 im2col-tile kernel and a 256-channel-wide halo kernel: superseded, removed in round 4.)
 #include "gemm.h"
 #include "api_util.h"
+#include "decoder_kernels.h"      // lxo_k_det_reduce
 #include "lxo_debug.h"
 #include <stdlib.h>
 
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
                 }
                 if (ok) *reinterpret_cast<u32x4*>(tile0 + (ty * p.Wo + tx) * p.ldc) = o;
             }
-            if (p.colsum) {
+            if (p.colsum || p.colsum_part) {
                 float* cs = reinterpret_cast<float*>(lxo_conv_lds);      // [RPQ][WBN] partial sums; the bf16 tile has been read
                 LXO_LDS_BARRIER();
 #pragma unroll
@@ -601,7 +602,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
                     float sres = 0.f;
 #pragma unroll
                     for (int r = 0; r < RPQ; ++r) sres += cs[r * WBN + tid];
-                    atomicAdd(&p.colsum[n0 + tid], sres);
+                    if (p.colsum_part) p.colsum_part[(long long)mt * p.N + n0 + tid] = sres;      // deterministic mode: this tile's slot
+                    else atomicAdd(&p.colsum[n0 + tid], sres);
                 }
             }
             CSTAMP(2 + nk);
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
         CSTAMP(42 + 3 * pass);
     }
     CSTAMP(2 + nk);
-    if (p.colsum) {
+    if (p.colsum || p.colsum_part) {
         LXO_LDS_BARRIER();
 #pragma unroll
         for (int e = 0; e < 8; ++e) ot[(tid / CH) * OP + c8 + e] = csum[e];
@@ -720,7 +722,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
             float sres = 0.f;
 #pragma unroll
             for (int r = 0; r < RPI; ++r) sres += ot[r * OP + tid];
-            atomicAdd(&p.colsum[n0 + tid], sres);
+            if (p.colsum_part) p.colsum_part[(long long)mt * p.N + n0 + tid] = sres;              // deterministic mode: this tile's slot
+            else atomicAdd(&p.colsum[n0 + tid], sres);
         }
     }
 }
@@ -769,13 +772,14 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
         }
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
-        const bool has_add = p.addend || p.out_pre, has_ref = p.relu_ref || p.colsum;
+        const bool has_add = p.addend || p.out_pre, has_ref = p.relu_ref || p.colsum || p.colsum_part;
         int epi = p.accumulate || (has_add && has_ref) ? 3 : (has_add ? 1 : (has_ref ? (p.relu_ref ? 2 : 3) : 0));      // 2 = the one-pass masked epilogue: needs the reference
         if (p.pool_out) {
             if (epi != 0 || p.N % 128 || !p.pool_mask || p.pool_h < 1 || p.pool_h > 2 || p.pool_w < 1 || p.pool_w > 2 || p.pool_h * p.pool_w == 1) return -2;
             epi = 4;
         } else if (!p.C) return -2;
         const dim3 g4(B * tiles_x * tiles_y * (p.N / 128)), g2(B * tiles_x * tiles_y * (p.N / 64));
+        if (p.colsum_part && (size_t)B * tiles_x * tiles_y * p.N > p.colsum_part_floats) return -6;
         if (p.N % 128 == 0) {
             if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 0>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
             else if (epi == 1) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
@@ -788,9 +792,11 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
             if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 0>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
             else hipLaunchKernelGGL((conv_halo2wg_kernel<2, 3>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
         }
+        if (p.colsum_part) return lxo_k_det_reduce(p.colsum_part, B * tiles_x * tiles_y, p.N, p.N, p.colsum, s);      // the tiles' sums in tile order
         return (int)hipGetLastError();
     }
     if (p.pool_out || !p.C) return -2;                    // the fused pool lives in conv_halo2wg_kernel only
+    if (p.colsum_part) return -7;                         // no slot form here: the caller runs it without the fused sum + an ordered pass
     // everything the two-workgroup kernel does not take (Cout % 64 != 0, tensors of 2 GB and more, tanh, alpha != 1): the general halo kernel
     {
         constexpr int LDSB = 2 * HPATCH + 3 * HB_STAGE, LDSB64 = 2 * HPATCH + 3 * (HB_STAGE / 2);

@@ -61,14 +61,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(GemmTN p, int tiles_co,
     // (stamps: 44-65 k cycles, 10-20 % of the launch).  Range length grows linearly with the split index (1 -/+ stagger at the ends),
     // so the workgroups finish spread over about the time the atomics take and the epilogues of the early ones run under the K
     // loops of the late ones.  boundary(s) = nblocks * (u + stagger * (u * u - u)), u = s / nsplit.
-    if (split >= nsplit) return;
+    if (split >= nsplit) return;                           // (slots >= nsplit do not exist)
     auto boundary = [&](int sidx) {
         const float u = (float)sidx / (float)nsplit;
         const int v = (int)((float)nblocks * (u + stagger * (u * u - u)) + 0.5f);
         return sidx >= nsplit ? nblocks : min(nblocks, max(0, v));
     };
     const int pb_beg = __builtin_amdgcn_readfirstlane(boundary(split)), pb_end = __builtin_amdgcn_readfirstlane(boundary(split + 1));
-    if (pb_beg >= pb_end) return;
+    if (pb_beg >= pb_end) {
+        if (p.det_slab) {                                      // deterministic mode: an empty range still owns a slot: zeros
+            float* const sb = p.det_slab + ((long long)split * ntiles + tile) * (9 * WCI * WCO);
+            for (int i = tid; i < 9 * WCI * WCO / 4; i += WTHREADS) reinterpret_cast<f32x4*>(sb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
 
     // ---- the LDS-DMA of one pixel block: 5 (wave 0) / 4 requests for the patch, 4 for d_out, through buffer resources.
     // The request addresses used to be rebuilt from the block index for every request (divisions, 64-bit multiplies, a select
@@ -328,7 +334,6 @@ int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     if (q.det_slab) {
         const size_t need = (size_t)nsplit * tiles * 9 * WCI * WCO;
         if (need > q.det_floats) return -6;
-        HIPRC(hipMemsetAsync(q.det_slab, 0, need * sizeof(float), s));          // a range that turns out empty leaves its slot untouched
     }
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * nsplit8), dim3(WTHREADS), 2 * WSTAGE, s, q, tiles_co, tiles_x, tiles_y, nblocks, nsplit, stagger);
     if (q.det_slab)

@@ -14,6 +14,7 @@ struct DimgArgs {
     const float* dmean;                                   // [B][C]
     float* out;
     const bf16_t* y6; bf16_t* dy6; float* db;
+    float* db_part; size_t db_part_floats;               // deterministic mode: per-workgroup slots of the bias sums (added in order into db by the launcher)
     int T, B, R, C, E;
 };
 int lxo_launch_dimg_fused(const DimgArgs& p, hipStream_t st);

@@ -9,6 +9,7 @@
 // once.  4 waves as 2 x 2, each 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 tiles; the next K-tile's loads are in flight
 // under the current tile's MFMAs; every load is unconditional (clamped address, masked value).
 #include "dimg.h"
+#include "decoder_kernels.h"      // lxo_k_det_reduce
 
 namespace {
 
@@ -207,7 +208,12 @@ __global__ __launch_bounds__(256) void dimg_fused_kernel(DimgArgs p) {
             for (int e = 0; e < 8; ++e) atomicAdd(&dbs[wj * 64 + tc + e], cs[e]);
         }
         __syncthreads();
-        if (p.db && tid < 128 && j0 + tid < p.C) atomicAdd(&p.db[j0 + tid], dbs[tid]);       // (deterministic mode: db == null, the caller sums the columns of dy6 in a fixed order)
+        // (inside the workgroup a column gets exactly two addends -- the two waves of its column half -- so the LDS sum does not depend on
+        // their order; deterministic mode: the workgroup's sums go to ITS slot and the launcher adds the slots in order)
+        if (tid < 128 && j0 + tid < p.C) {
+            if (p.db_part) p.db_part[((long long)b * gridDim.y + blockIdx.y) * p.C + j0 + tid] = dbs[tid];
+            else if (p.db) atomicAdd(&p.db[j0 + tid], dbs[tid]);
+        }
     }
 }
 
@@ -216,7 +222,9 @@ __global__ __launch_bounds__(256) void dimg_fused_kernel(DimgArgs p) {
 int lxo_launch_dimg_fused(const DimgArgs& p, hipStream_t st) {
     if (p.E % 32 || p.C % 8 || p.Rp % 8 || p.T < 1) return -2;
     dim3 grid((p.C + 127) / 128, (p.R + 127) / 128, p.B);
+    if (p.db_part && (size_t)grid.y * grid.z * p.C > p.db_part_floats) return -6;
     if (p.y6) hipLaunchKernelGGL((dimg_fused_kernel<1>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((dimg_fused_kernel<0>), grid, dim3(256), 0, st, p);
+    if (p.y6 && p.db_part && p.db) return lxo_k_det_reduce(p.db_part, (int)(grid.y * grid.z), p.C, p.C, p.db, st);
     return (int)hipGetLastError();
 }

@@ -11,7 +11,7 @@ int lxo_k_conv1_pool_fwd(int dt, const uint8_t* img, const float* w, const float
 int lxo_k_conv1_pool_bwd(int dt, const uint8_t* img, const float* w, const float* b, const void* dout, float* dw, float* db, int B, int H, int W, DetScratch det, hipStream_t s);
 int lxo_k_maxpool_fwd(int dt, const void* in, void* out, int B, int H, int W, int C, int ph, int pw, hipStream_t s);
 // bf16 mode, layers whose forward ran the fused conv + pool epilogue: routes by the one-byte-per-element mask instead of the activation
-int lxo_k_maxpool_mask_bwd(const unsigned char* mask, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s);
+int lxo_k_maxpool_mask_bwd(const unsigned char* mask, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, DetScratch det, hipStream_t s);      // det.p: the bias sums through ordered per-workgroup slots
 int lxo_k_maxpool_relu_bwd(int dt, const void* y, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s);
 int lxo_k_mask_convert(int dt, const float* d, const void* ref, void* out, float* db, long long rows, int C, hipStream_t s);
 int lxo_k_timing_signal(float* pos, int Hp, int Wp, int C, hipStream_t s);

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const CT* __restr
 // full-resolution activation (pool 2x2 on conv2: 369 MB instead of 603 MB); every load and store is unconditional in count.
 template <int PH, int PW>
 __global__ __launch_bounds__(256) void maxpool_mask_bwd_kernel(const unsigned char* __restrict__ mask, const bf16_t* __restrict__ dp,
-                                                              bf16_t* __restrict__ dyo, float* __restrict__ db,
+                                                              bf16_t* __restrict__ dyo, float* __restrict__ db, float* __restrict__ db_part,
                                                               int B, int H, int W, int C, int Ho, int Wo) {
     constexpr int ph = PH, pw = PW;           // compile-time window: the position loop unrolls into straight-line selects and stores
     __shared__ float dbs[512];
@@ -583,7 +583,21 @@ __global__ __launch_bounds__(256) void maxpool_mask_bwd_kernel(const unsigned ch
                 }
         }
     }
-    if (db) {
+    if (db_part) {
+        // deterministic mode: no atomics, neither in LDS nor in memory -- the threads' sums of a column meet in thread order, the workgroup's
+        // sums go to ITS slot [C] and lxo_k_det_reduce adds the slots in workgroup order
+        __shared__ float dbo[256 * 8];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dbo[threadIdx.x * 8 + e] = gb[e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) {
+            const int g = i >> 3, e = i & 7;
+            float s = 0.f;
+            for (int r = 0; r < ppb; ++r) s += dbo[(r * cgs + g) * 8 + e];
+            db_part[(long long)blockIdx.x * C + i] = s;
+        }
+    } else if (db) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(&dbs[cg * 8 + e], gb[e]);
         __syncthreads();
@@ -871,17 +885,20 @@ template <typename CT> static void pool_bwd_t(const void* y, const void* dp, voi
     hipLaunchKernelGGL((maxpool_relu_bwd_kernel<CT>), dim3(grid_for((long long)B * Ho * Wo, ppb * 8, 2048)), dim3(256), 0, s,
                        (const CT*)y, (const CT*)dp, (CT*)dy, db, B, H, W, C, ph, pw, Ho, Wo);
 }
-int lxo_k_maxpool_mask_bwd(const unsigned char* mask, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {
+int lxo_k_maxpool_mask_bwd(const unsigned char* mask, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, DetScratch det, hipStream_t s) {
     if (C % 8 || C > 512 || 256 % (C / 8)) return -2;
     const int Ho = (H + ph - 1) / ph, Wo = (W + pw - 1) / pw;
     const int ppb = 256 / (C / 8);
     const dim3 grid(grid_for((long long)B * Ho * Wo, ppb * 8, 2048));
-#define MB_ARGS mask, (const bf16_t*)dp, (bf16_t*)dy, db, B, H, W, C, Ho, Wo
+    float* db_part = nullptr;                 // deterministic mode: one slot [C] per workgroup
+    if (det.p && db) { if ((size_t)grid.x * C > det.floats) return -6; db_part = det.p; }
+#define MB_ARGS mask, (const bf16_t*)dp, (bf16_t*)dy, db, db_part, B, H, W, C, Ho, Wo
     if (ph == 2 && pw == 2) hipLaunchKernelGGL((maxpool_mask_bwd_kernel<2, 2>), grid, dim3(256), 0, s, MB_ARGS);
     else if (ph == 2 && pw == 1) hipLaunchKernelGGL((maxpool_mask_bwd_kernel<2, 1>), grid, dim3(256), 0, s, MB_ARGS);
     else if (ph == 1 && pw == 2) hipLaunchKernelGGL((maxpool_mask_bwd_kernel<1, 2>), grid, dim3(256), 0, s, MB_ARGS);
     else return -2;
 #undef MB_ARGS
+    if (db_part) return lxo_k_det_reduce(db_part, (int)grid.x, C, C, db, s);
     return (int)hipGetLastError();
 }
 int lxo_k_maxpool_relu_bwd(int dt, const void* y, const void* dp, void* dy, float* db, int B, int H, int W, int C, int ph, int pw, hipStream_t s) {

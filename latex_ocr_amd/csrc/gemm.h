@@ -20,6 +20,10 @@ struct GemmNT {
     void* out_pre;
     int accumulate;
     float* colsum;
+    // deterministic mode: colsum_part != null = no float atomics for the column sums -- conv_halo2wg_kernel stores its tile's sums to slot
+    // [tile index along M][N] of colsum_part and the launcher adds the slots in order into colsum; kernels without the slot form run
+    // without the fused sum and an ordered column-sum pass over C follows (lxo_launch_gemm_nt)
+    float* colsum_part; size_t colsum_part_floats;
     float alpha;
     unsigned long long* dbg;   // measurement aid (null = off): conv_halo2wg_kernel stamps its phases here, [workgroup][64] (tools/conv_stamps.py)
     // fused max pool (conv_halo2wg_kernel, plain epilogue only): pool_out[b][ceil(Ho/ph)][ceil(Wo/pw)][N] = max over the ph x pw window of

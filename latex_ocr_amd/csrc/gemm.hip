@@ -14,6 +14,7 @@
 // bf16 mode uses v_mfma_f32_32x32x16_bf16 (f32 accumulate); f32 mode (parity
 // mode) uses v_mfma_f32_32x32x2_f32, which is an exact fmaf chain.
 #include "gemm.h"
+#include "decoder_kernels.h"      // lxo_k_colsum_det (deterministic column sums)
 #include <stdlib.h>
 
 namespace {
@@ -666,7 +667,20 @@ int launch_tn(const GemmTN& p, hipStream_t s) {
 
 }  // namespace
 
-int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p, hipStream_t s) {
+int lxo_launch_gemm_nt(int dt, int a_f32, int c_f32, int small, const GemmNT& p0, hipStream_t s) {
+    if (p0.colsum_part) {
+        // deterministic column sums: the bf16 two-workgroup conv kernel has a slot form; everything else runs without the fused sum and the
+        // columns of the stored result are summed through ordered row-block slots (the same scratch)
+        if (dt == LXO_BF16 && p0.conv && !a_f32 && !c_f32 && p0.Cin % 64 == 0 && p0.Cin % 32 == 0 && p0.K % 32 == 0 && p0.K > 0 && p0.M > 0 && p0.N > 0) {
+            const int rc = lxo_launch_conv_igemm(p0, s);
+            if (rc != -7) return rc;
+        }
+        GemmNT q = p0; q.colsum = nullptr; q.colsum_part = nullptr;
+        if (int rc = lxo_launch_gemm_nt(dt, a_f32, c_f32, small, q, s)) return rc;
+        const DetScratch d = {p0.colsum_part, p0.colsum_part_floats};
+        return lxo_k_colsum_det(p0.C, (dt == LXO_BF16 && !c_f32) ? 1 : 0, p0.ldc, p0.colsum, p0.M, p0.N, d, s);
+    }
+    const GemmNT& p = p0;
     if (p.M <= 0 || p.N <= 0) return 0;
     if (p.K % 32 != 0 || p.K <= 0) return -2;
     if (p.conv && p.Cin % 32) return -2;
@@ -710,7 +724,11 @@ int lxo_launch_gemm_tn(int dt, int a_f32, int b_f32, const GemmTN& p, hipStream_
         if (q.conv) return launch_tn<float, true, float, float>(q, s);
         return launch_tn<float, false, float, float>(q, s);
     }
-    if (p.det_slab && !p.conv) {           // deterministic bf16 mode, dense product: ONE row range per output tile (one writer per element)
+    if (p.det_slab && !p.conv) {
+        // deterministic bf16 mode, dense product: the transposing-read kernel keeps its row ranges and stores one partial tile per (range,
+        // tile) to the slab, added in range order (gemm_tn_tr.hip); operands it does not take: ONE row range per output tile
+        if (!a_f32 && !b_f32 && p.atomic && p.nbatch == 1 && p.lda % 8 == 0 && p.ldb % 8 == 0 && (p.I + 7) / 8 * 8 <= p.lda && (p.J + 7) / 8 * 8 <= p.ldb &&
+            (((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0) { const int rc = lxo_launch_gemm_tn_tr(p, s); if (rc != -2) return rc; }
         GemmTN q = p; q.nsplit = 1; q.det_slab = nullptr;
         return lxo_launch_gemm_tn(dt, a_f32, b_f32, q, s);
     }

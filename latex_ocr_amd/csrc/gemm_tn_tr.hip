@@ -44,7 +44,13 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmTN p) {
     const int i0 = (tile / tj_n) * 128, j0 = (tile % tj_n) * 128;
     const int per = ((p.M + p.nsplit - 1) / p.nsplit + TBR - 1) / TBR * TBR;
     const int mbeg = split * per, mend = min(p.M, mbeg + per);
-    if (mbeg >= mend) return;
+    // deterministic mode: this (split, tile) unit's 128 x 128 partial goes to ITS slot of the slab with plain stores (an empty range stores
+    // zeros) and tn_slab_reduce_kernel adds the slots of a tile in split order
+    float* const slab = p.det_slab ? p.det_slab + ((long long)split * tiles + tile) * (128 * 128) : nullptr;
+    if (mbeg >= mend) {
+        if (slab) for (int i = tid; i < 128 * 128 / 4; i += 256) reinterpret_cast<f32x4*>(slab)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(p.B);
 
@@ -128,6 +134,16 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmTN p) {
         }
     }
     // acc[a][b][e]: row i = i0 + wi*64 + a*32 + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column j = j0 + wj*64 + b*32 + (lane & 31)
+    if (slab) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    slab[(wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 128 + wj * 64 + b * 32 + (lane & 31)] = acc[a][b][e];
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int jj = j0 + wj * 64 + b * 32 + (lane & 31);
@@ -139,6 +155,17 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(GemmTN p) {
                 if (ii < p.I && jj < p.J) atomicAdd(&p.C[(long long)ii * p.ldc + jj], acc[a][b][e]);
             }
     }
+}
+
+// deterministic mode: C[i0 + r][j0 + c] += sum over the splits s = 0 .. nsplit-1 (in that order) of slab[s][tile][r][c]
+__global__ __launch_bounds__(256) void tn_slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int tiles, int tj_n, int I, int J, float* __restrict__ C, int ldc) {
+    const int tile = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;                 // element of the 128 x 128 tile
+    const int r = i >> 7, c = i & 127;
+    const int ii = (tile / tj_n) * 128 + r, jj = (tile % tj_n) * 128 + c;
+    float s = 0.f;
+    for (int q = 0; q < nsplit; ++q) s += slab[((long long)q * tiles + tile) * (128 * 128) + i];
+    if (ii < I && jj < J) C[(long long)ii * ldc + jj] += s;
 }
 
 }  // namespace
@@ -158,8 +185,12 @@ int lxo_launch_gemm_tn_tr(const GemmTN& p, hipStream_t s) {
             if (known) done[dev] = true;
         }
     }
-    const int units = ((p.J + 127) / 128) * ((p.I + 127) / 128) * p.nsplit;
+    const int tiles = ((p.J + 127) / 128) * ((p.I + 127) / 128);
+    const int units = tiles * p.nsplit;
+    if (p.det_slab && (size_t)units * 128 * 128 > p.det_floats) return -2;      // (the caller falls back to one row range per tile)
     dim3 grid(8 * ((units + 7) / 8));
     hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), 2 * TSTAGE, s, p);
+    if (p.det_slab)
+        hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3(128 * 128 / 256, tiles), dim3(256), 0, s, p.det_slab, p.nsplit, tiles, (p.J + 127) / 128, p.I, p.J, p.C, p.ldc);
     return (int)hipGetLastError();
 }

@@ -23,7 +23,7 @@ int nt(const Plan& P, bool a_f32, bool c_f32, bool small, const void* A, int lda
 }
 // C[I][J] += A^T B over M rows
 int tn(const Plan& P, bool a_f32, bool b_f32, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
-       int M, int I, int J, hipStream_t st) {
+       int M, int I, int J, hipStream_t st, DetScratch det = DetScratch{nullptr, 0}) {
     GemmTN g; memset(&g, 0, sizeof(g));
     g.A = A; g.B = B; g.C = C; g.M = M; g.I = I; g.J = J; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     const int tiles = cdiv(I, 128) * cdiv(J, 128);
@@ -31,7 +31,8 @@ int tn(const Plan& P, bool a_f32, bool b_f32, const void* A, int lda, const void
     const int maxs = M / 64 > 0 ? M / 64 : 1;
     if (ns > maxs) ns = maxs;
     g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
-    if (P.bf && P.det()) g.nsplit = 1;                    // bf16 deterministic mode: one row range per output tile = one writer per element
+    // bf16 deterministic mode: partial tiles to the slab, added in range order (or, without a slab, one row range per output tile)
+    if (P.bf && P.det()) { if (det.p) { g.det_slab = det.p; g.det_floats = det.floats; } else g.nsplit = 1; }
     if (P.s.dtype == LXO_F32) { a_f32 = true; b_f32 = true; }
     return lxo_launch_gemm_tn(P.s.dtype, a_f32, b_f32, g, st);
 }
@@ -317,7 +318,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     // d_o (from logits) for every step, and dy_W_o
     if (parts & 1) {
         RC(nt(P, false, true, false, dlog, P.Vp, P.pk(wp, K_YWO), P.Vp, dolog, O, TB, O, P.Vp, nullptr, 0, false, st));
-        if (P.bf && fused) RC(tn(P, false, false, P.ws<bf16_t>(ws, W_RECB) + (size_t)B * P.RECB, P.RECB, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
+        if (P.bf && fused) RC(tn(P, false, false, P.ws<bf16_t>(ws, W_RECB) + (size_t)B * P.RECB, P.RECB, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st, det));
         else RC(tn(P, true, false, rec + (size_t)B * P.REC, P.REC, dlog, P.Vp, gw(P_YWO), V, TB, O, V, st));
     }
     // a failed forward chain poisons the last gradient element (y_W_o's, final after this part): under data parallelism its all-reduce
@@ -487,11 +488,11 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         // these reductions over T*B rows are bound by operand re-reads (every 128 x 128 tile walks all rows of both operands)
         const bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         const bf16_t* gb = P.ws<bf16_t>(ws, W_GB); const bf16_t* dzb = P.ws<bf16_t>(ws, W_DZB);
-        RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
-        if (bwd_chain) RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, P.ws<bf16_t>(ws, W_DATTHB), E, gw(P_ATT_H), E, TB, U, E, st));      // dW_att_h
+        RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, st, det));      // d[o_W_h; o_W_c]
+        if (bwd_chain) RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, P.ws<bf16_t>(ws, W_DATTHB), E, gw(P_ATT_H), E, TB, U, E, st, det));      // dW_att_h
         else RC(tn(P, false, true, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, datth, E, gw(P_ATT_H), E, TB, U, E, st));
-        RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st));           // dK rows 0..D
-        RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st));     // dK rows D..
+        RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st, det));           // dK rows 0..D
+        RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st, det));     // dK rows D..
     } else {
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, datth, E, gw(P_ATT_H), E, TB, U, E, st));      // dW_att_h
@@ -542,7 +543,8 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         a.dctx = dhc + U; a.ld_dctx = (long long)B * P.HC; a.HC = P.HC;
         a.datt = P.ws<bf16_t>(ws, W_DATTIMG); a.W = (const bf16_t*)P.pk(wp, K_ATT_IMG); a.ldw = E;
         a.dmean = dmean; a.T = T; a.B = B; a.R = P.R; a.C = C; a.E = E;
-        a.y6 = P.ws<bf16_t>(ws, W_Y6); a.dy6 = P.ws<bf16_t>(ws, W_DIMG); a.db = P.det() ? nullptr : gw(P_CONV6_B);      // deterministic mode: lxo_encoder_bwd sums the columns of d_y6 in order
+        a.y6 = P.ws<bf16_t>(ws, W_Y6); a.dy6 = P.ws<bf16_t>(ws, W_DIMG); a.db = gw(P_CONV6_B);
+        if (P.det()) { a.db_part = det.p; a.db_part_floats = det.floats; }      // deterministic mode: per-workgroup slots, added in order
         RC(lxo_launch_dimg_fused(a, st));
     } else {
         {
@@ -557,7 +559,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
                           T, B, P.R, P.Rp, E, det, st));
         RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     }
-    RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, st));
+    RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, st, det));
     // the backward chain's error word -> the probe element (as for the forward chain above; y_W_o's bucket is reduced behind this call
     // where the backward chain runs, Engine.backward)
     if (bwd_chain) RC(lxo_k_chain_poison(nullptr, P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4 + 8 * 64, grads + P.ptotal - 1, st));

@@ -115,13 +115,13 @@ static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din
     g.M = P.s.B * Hin * Win; g.N = Cin; g.K = 9 * Cout;
     g.lda = Cout; g.ldb = 9 * Cout; g.ldc = Cin;
     g.act = 0; g.alpha = 1.f; g.addend_rows = 1;
-    g.relu_ref = relu_ref; g.ldr = Cin; g.colsum = P.det() ? nullptr : colsum;
+    g.relu_ref = relu_ref; g.ldr = Cin; g.colsum = colsum;
+    // parity / deterministic mode: no float atomics for the bias gradient -- per-tile slots added in tile order where the kernel has that
+    // form (the bf16 two-workgroup kernel), else an ordered column-sum pass over the masked result (lxo_launch_gemm_nt)
+    if (P.det() && colsum) { g.colsum_part = det.p; g.colsum_part_floats = det.floats; }
     // algorithmic FLOPs of a data gradient = those of the layer's forward, whatever grid the kernel pads to
     LxoTimed tm("conv_dgrad", conv_name(Cin, Cout, valid), 2.0 * P.s.B * Hout * Wout * 9.0 * Cin * Cout, st);
-    RC(lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st));
-    // parity / deterministic mode: the bias gradient is an ordered column sum of the masked result (the fused sum uses float atomics)
-    if (P.det() && colsum) RC(lxo_k_colsum_det(din, P.bf ? 1 : 0, Cin, colsum, g.M, Cin, det, st));
-    return 0;
+    return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
 }
 // wgrad: dW[(kh,kw,ci)][co] += sum_m in[m shifted][ci] * d_out[m][co]
 static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw, int H, int W, int Cin, int Cout,
@@ -245,7 +245,6 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         case 6:   // d_y6 = d_img * (y6>0) -> X ; wgrad6 ; d_p5 = dgrad6 -> Y
             if (P.dimg_masked()) {        // the decoder left d_y6 (masked, compute dtype) in "d_img" and summed the bias gradient
                 const void* dy6 = P.ws<void>(ws, W_DIMG);
-                RC(dbsum(dy6, (long long)B * P.R, C, P_CONV6_B));          // deterministic mode: the decoder's GEMM left the bias sum to this ordered pass
                 RC(wgrad(P.ws<void>(ws, W_P5), XB[6], gw(P_CONV6_W), P.H6, P.W5, C, C, true, dy6));
                 RC(acquire(YB[6]));
                 RC(conv_dgrad(P, dy6, P.pk(wp, K_CONV6_D), Y, P.Hp, P.Wp, C, P.H6, P.W5, C, true, nullptr, nullptr, det, st));
@@ -284,9 +283,9 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
                 RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, P.ws<void>(ws, W_Y4), gw(P_CONV4_B), det, st));
                 break;
             }
-            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M5), Yup, X, dbp(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
+            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M5), Yup, X, gw(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, det, st));
             else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y5), Yup, X, dbp(P_CONV5_B), B, P.H4, P.W2, C, 1, 2, st));
-            RC(dbsum(X, (long long)B * P.H4 * P.W2, C, P_CONV5_B));
+            if (!P.pool_fused()) RC(dbsum(X, (long long)B * P.H4 * P.W2, C, P_CONV5_B));      // (the mask kernel summed it through its own ordered slots)
             RC(wgrad(P.ws<void>(ws, W_P4), XB[5], gw(P_CONV5_W), P.H4, P.W2, 256, C, false));
             RC(acquire(YB[5]));
             RC(conv_dgrad(P, X, P.pk(wp, K_CONV5_D), Y, P.H4, P.W2, C, P.H4, P.W2, 256, false, nullptr, nullptr, det, st));
@@ -294,9 +293,9 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         case 4:   // d_y4 = route(d_p4) -> X (cnn: already there, masked) ; wgrad4 ; d_y3 = dgrad4 * (y3>0) -> Y (+ db3)
             if (!P.cnn) {
                 RC(acquire(XB[4]));
-                if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M4), Yup, X, dbp(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
+                if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M4), Yup, X, gw(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, det, st));
                 else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y4), Yup, X, dbp(P_CONV4_B), B, P.H2, P.W2, 256, 2, 1, st));
-                RC(dbsum(X, (long long)B * P.H2 * P.W2, 256, P_CONV4_B));
+                if (!P.pool_fused()) RC(dbsum(X, (long long)B * P.H2 * P.W2, 256, P_CONV4_B));
             }
             RC(wgrad(P.ws<void>(ws, W_Y3), XB[4], gw(P_CONV4_W), P.H2, P.W2, 256, 256, false));
             RC(acquire(YB[4]));
@@ -309,9 +308,9 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
             break;
         case 2:   // d_y2 = route(d_p2) -> X ; wgrad2 ; d_p1 = dgrad2 -> Y
             RC(acquire(XB[2]));
-            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M2), Yup, X, dbp(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
+            if (P.pool_fused()) RC(lxo_k_maxpool_mask_bwd(P.ws<unsigned char>(ws, W_M2), Yup, X, gw(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, det, st));
             else RC(lxo_k_maxpool_relu_bwd(dt, P.ws<void>(ws, W_Y2), Yup, X, dbp(P_CONV2_B), B, P.H1, P.W1, 128, 2, 2, st));
-            RC(dbsum(X, (long long)B * P.H1 * P.W1, 128, P_CONV2_B));
+            if (!P.pool_fused()) RC(dbsum(X, (long long)B * P.H1 * P.W1, 128, P_CONV2_B));
             RC(wgrad(P.ws<void>(ws, W_P1), XB[2], gw(P_CONV2_W), P.H1, P.W1, 64, 128, false));
             RC(acquire(YB[2]));
             RC(conv_dgrad(P, X, P.pk(wp, K_CONV2_D), Y, P.H1, P.W1, 128, P.H1, P.W1, 64, false, nullptr, nullptr, det, st));

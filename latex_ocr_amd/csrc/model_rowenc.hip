@@ -72,7 +72,7 @@ int gemm_tn_acc(const Plan& P, const void* A, int lda, const void* B, int ldb, f
     const int maxs = M / 64 > 0 ? M / 64 : 1;
     if (ns > maxs) ns = maxs;
     g.nsplit = ns < 1 ? 1 : ns; g.nbatch = 1; g.atomic = 1;
-    if (P.bf && P.det()) g.nsplit = 1;                    // bf16 deterministic mode: one row range per output tile
+    if (P.bf && P.det()) g.nsplit = 1;                    // bf16 deterministic mode: one row range per output tile (these products are small)
     const bool f32 = P.s.dtype == LXO_F32;
     return lxo_launch_gemm_tn(P.s.dtype, f32, f32, g, st);     // bf16 mode: both operands are bf16 (X^T / h mirrors, d_z mirrors)
 }
