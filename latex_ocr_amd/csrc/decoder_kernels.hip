@@ -1195,13 +1195,34 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const AT* __restrict__
     }
     part[(long long)blockIdx.y * N + n] = s;
 }
-// out[n] += part[0][n] + part[1][n] + ... (slot order)
+// out[n] += sum of part[q][n] over the slots q, in a FIXED order: the slots are cut into 16 contiguous groups, a thread adds one group
+// left to right (eight loads in flight), thread 0 of a column adds the 16 group sums left to right.  The association is a function of
+// (nslot) only, so two runs agree bit for bit -- and 2048 slots cost 16 batches of loads instead of a 2048-long chain of dependent
+// load -> add round trips on 128 threads (round 5: that chain was 1.5 ms of the bf16 deterministic mode's step).
 __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int nslot, long long stride, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float gs[16][16];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
+    const int per = (nslot + 15) / 16;
+    const int q0 = g * per, q1 = min(nslot, q0 + per);
     float s = 0.f;
-    for (int q = 0; q < nslot; ++q) s += part[(long long)q * stride + n];
-    out[n] += s;
+    if (n < N) {
+        for (int q = q0; q < q1; q += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long long)min(q + u, q1 - 1) * stride + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (q + u < q1) s += v[u];
+        }
+    }
+    gs[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float tsum = gs[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) tsum += gs[k][c];
+        out[n] += tsum;
+    }
 }
 
 // d_emb rows -> embedding_table / start_token gradients (decoder.py:90-93 backward)
@@ -1684,7 +1705,7 @@ int lxo_k_attn_bwd(int dt, const void* att_img, const void* att_exp, const void*
 }
 int lxo_k_det_reduce(const float* part, int nslot, long long stride, int N, float* out, hipStream_t st) {
     if (nslot <= 0 || N <= 0) return 0;
-    hipLaunchKernelGGL(det_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, part, nslot, stride, N, out);
+    hipLaunchKernelGGL(det_reduce_kernel, dim3(cdiv(N, 16)), dim3(256), 0, st, part, nslot, stride, N, out);      // 16 columns x 16 slot groups per workgroup
     DONE;
 }
 int lxo_k_datt_img(int dt, const void* att_img, const float* att_h, const float* beta, const float* de, void* dout, float* dbeta,
