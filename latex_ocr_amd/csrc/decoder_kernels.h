@@ -44,7 +44,7 @@ int lxo_k_argmax(const float* logits, int Vp, int V, int n, int id_end, int* ids
 int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, int time, float div_gamma, float div_prob, int div_seed,
                     float* scratch, float* logp, int* finished,
                     int* ids_step, int* parents_step, int* ids_out, int* par_out, int max_steps, int* n_unfinished, hipStream_t st);
-int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, hipStream_t st);
+int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, void* recb, int ldrb, hipStream_t st);      // recb (nullable): bf16 mirror of the re-ordered [o | h] rows
 int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k, int cols, hipStream_t st);
 int lxo_k_global_norm_scale(long long n, const float* g, float clip, float* sumsq_tmp, float* out, hipStream_t st);
 int lxo_k_chain_guard(const unsigned* err_fwd, const unsigned* err_bwd, const float* probe, float* scale, int have_scale, unsigned* status, hipStream_t st);

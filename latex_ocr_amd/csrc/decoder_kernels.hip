@@ -405,6 +405,126 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
 }
 
 
+// The same pass for BEAM SEARCH (beam_search_decoder_cell.py:98-109 tiles the image features over the beam; here they are not tiled):
+// the NBM hypotheses of an image read the SAME att_img / img rows, so one workgroup = (chunk, IMAGE) loads every row once and runs the
+// scores / online softmax / context of all NBM decoder rows v = image * NBM + b on it.  attn_fwd_part_kernel with its (chunk, decoder row)
+// grid streamed the image's rows once per hypothesis: 427 MB per beam-5 step at B = 64 instead of 85 MB, 67 us of a 161 us step
+// (profiles/r05_beam_kernels_before.csv).  The arithmetic of a (row, hypothesis) pair is the per-row kernel's, in the same order (same
+// butterfly, same online-softmax updates), so the partials -- and with them the ids of the f32 parity mode -- are bit-identical to the
+// per-row kernel's for the same chunking.
+template <typename CT, int ATT_U, int NBM>
+__global__ __launch_bounds__(512) void attn_fwd_part_beam_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+                                                                const float* __restrict__ att_h, const float* __restrict__ beta,
+                                                                float* __restrict__ alpha, float* __restrict__ part,
+                                                                int R, int Rp, int E, int C, int nch, int rows_per, int rev) {
+    __shared__ float redc[ATT_W][512];
+    __shared__ float red[2 * ATT_W];
+    const int ch = blockIdx.x, bi = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = ch * rows_per;
+    const int n = min(R, r0 + rows_per) - r0;          // may be <= 0 for a trailing chunk
+    const CT* ai = att_img + ((long long)bi * R + r0) * E;
+    const CT* im = img + ((long long)bi * R + r0) * C;
+    const int k0 = lane * 4;
+    const bool kok = k0 < E;
+    float ah[NBM][4], bt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bt[j] = 0.f;
+    if (kok) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + k0); for (int j = 0; j < 4; ++j) bt[j] = b4[j]; }
+#pragma unroll
+    for (int b = 0; b < NBM; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ah[b][j] = 0.f;
+        if (kok) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(att_h + (long long)(bi * NBM + b) * E + k0); for (int j = 0; j < 4; ++j) ah[b][j] = a4[j]; }
+    }
+    const int c0 = lane * 8;
+    const bool cok = c0 < C;
+    const int c0l = cok ? c0 : 0, k0l = kok ? k0 : 0;
+    float m[NBM], l[NBM], acc[NBM][8];
+#pragma unroll
+    for (int b = 0; b < NBM; ++b) {
+        m[b] = -3.0e38f; l[b] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[b][e] = 0.f;
+    }
+    const int nit = n > wave ? (n - wave + ATT_W * ATT_U - 1) / (ATT_W * ATT_U) : 0;
+    for (int it = 0; it < nit; ++it) {
+        const int base = wave + ATT_W * ATT_U * (rev ? nit - 1 - it : it);
+        float xi[ATT_U][8], x[ATT_U][4];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {                 // unconditional, clamped (see attn_fwd_part_kernel)
+            const int r = min(base + ATT_W * u, n - 1);
+            load8(im + (long long)r * C + c0l, xi[u]);
+            load4(ai + (long long)r * E + k0l, x[u]);
+        }
+#pragma unroll
+        for (int b = 0; b < NBM; ++b) {
+            float pt[ATT_U];
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a = fmaf(tanh_ct<CT>(x[u][j] + ah[b][j]), bt[j], a);
+                pt[u] = kok ? a : 0.f;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+            }
+            float mn = m[b];
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) if (base + ATT_W * u < n) mn = fmaxf(mn, pt[u]);
+            const float sc = expf(m[b] - mn);
+            l[b] *= sc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[b][e] *= sc;
+            m[b] = mn;
+#pragma unroll
+            for (int u = 0; u < ATT_U; ++u) {
+                const int r = base + ATT_W * u;
+                if (r < n) {
+                    const float pw = expf(pt[u] - mn);
+                    l[b] += pw;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[b][e] = fmaf(pw, xi[u][e], acc[b][e]);
+                    if (lane == 0) alpha[(long long)(bi * NBM + b) * Rp + r0 + r] = pt[u];       // raw score
+                }
+            }
+        }
+    }
+    // merge the 8 waves, one hypothesis after the other (the LDS tile is shared)
+#pragma unroll
+    for (int b = 0; b < NBM; ++b) {
+        float* pout = part + ((long long)(bi * NBM + b) * nch + ch) * (C + 2);
+        if (b) __syncthreads();
+        if (lane == 0) red[wave] = m[b];
+        __syncthreads();
+        float mc = red[0];
+#pragma unroll
+        for (int w = 1; w < ATT_W; ++w) mc = fmaxf(mc, red[w]);
+        const float sw = (l[b] > 0.f) ? expf(m[b] - mc) : 0.f;
+        if (lane == 0) red[ATT_W + wave] = l[b] * sw;
+        if (cok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[b][e] * sw;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float lt = 0.f;
+#pragma unroll
+            for (int w = 0; w < ATT_W; ++w) lt += red[ATT_W + w];
+            pout[0] = mc; pout[1] = lt;
+        }
+        for (int c = tid; c < C; c += 512) {
+            float tt = 0.f;
+#pragma unroll
+            for (int w = 0; w < ATT_W; ++w) tt += redc[w][c];
+            pout[2 + c] = tt;
+        }
+    }
+}
+
 // merge the chunk partials: alpha = exp(e - m) / l ; ctx = sum_c ctx_c exp(m_c - m) / l.
 // grid (4, nv): every workgroup recomputes the (tiny) chunk scales in registers, then handles a
 // quarter of the channels and a quarter of the regions -- no serial phase, no barrier.
@@ -1467,6 +1587,103 @@ __global__ __launch_bounds__(256) void beam_step_kernel(float* __restrict__ logi
     }
 }
 
+// The same step with every candidate score held in REGISTERS (k * V <= 256 * BS_NPT, no diversity penalty): beam_step_kernel re-reads and
+// re-forms all k * V scores (an integer division each) for every one of its k selections and makes two passes over a row for its
+// log-sum-exp -- 31 us of a 161 us beam-5 step at B = 64, on 64 workgroups.  Here a lane loads its share of a row ONCE (max, then the
+// exponentials, from registers), a thread forms its <= BS_NPT scores ONCE, and a selection is a register scan + the block-wide arg-max.
+// Same expressions, same summation order inside a wave, same tie rule (lower flat index first): the ids and parents are the slow kernel's.
+constexpr int BS_NPT = 16;
+__global__ __launch_bounds__(256) void beam_step_fast_kernel(const float* __restrict__ logits, int Vp, int V, int k, int id_end, int time,
+                                                            float* __restrict__ logp, int* __restrict__ finished,
+                                                            int* __restrict__ ids_step, int* __restrict__ parents_step,
+                                                            int* __restrict__ ids_out, int* __restrict__ par_out, int max_steps,
+                                                            int* __restrict__ n_unfinished) {
+    __shared__ float lse[16];
+    __shared__ float cand_v[4]; __shared__ int cand_i[4];
+    __shared__ float sel_v[16]; __shared__ int sel_i[16];
+    __shared__ int fin_old[16];
+    __shared__ float lp_old[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float FMIN = -3.40282347e38f;
+    for (int j = wave; j < k; j += 4) {                       // log-sum-exp per hypothesis: one wave each, the row in registers when it fits
+        const float* lg = logits + ((long long)b * k + j) * Vp;
+        float m = -3.0e38f;
+        if (V <= 64 * 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int c = lane + 64 * u; x[u] = lg[c < V ? c : V - 1]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (lane + 64 * u < V) m = fmaxf(m, x[u]);
+            m = wave_max(m);
+            float l = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (lane + 64 * u < V) l += expf(x[u] - m);
+            l = wave_sum(l);
+            if (lane == 0) lse[j] = m + logf(l);
+        } else {
+            for (int c = lane; c < V; c += 64) m = fmaxf(m, lg[c]);
+            m = wave_max(m);
+            float l = 0.f;
+            for (int c = lane; c < V; c += 64) l += expf(lg[c] - m);
+            l = wave_sum(l);
+            if (lane == 0) lse[j] = m + logf(l);
+        }
+    }
+    if (tid < k) { fin_old[tid] = finished[b * k + tid]; lp_old[tid] = logp[b * k + tid]; }
+    __syncthreads();
+    const int nb = time > 0 ? k : 1;
+    const int total = nb * V;
+    float val[BS_NPT];
+#pragma unroll
+    for (int u = 0; u < BS_NPT; ++u) {
+        const int i = tid + 256 * u;
+        val[u] = -INFINITY;
+        if (i < total) {
+            const int j = i / V, c = i - j * V;
+            float sl = logits[((long long)b * k + j) * Vp + c] - lse[j];
+            const float f = fin_old[j] ? 1.f : 0.f;
+            sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
+            val[u] = lp_old[j] + sl;
+        }
+    }
+    unsigned taken = 0u;                                       // bit u: this thread's candidate u has been selected
+    for (int sel = 0; sel < k; ++sel) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < BS_NPT; ++u) {                      // ascending flat index: the first of equal values wins, as in the slow kernel
+            const int i = tid + 256 * u;
+            if (i < total && !((taken >> u) & 1u) && (val[u] > best || (val[u] == best && i < bi))) { best = val[u]; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { cand_v[wave] = best; cand_i[wave] = bi; }
+        __syncthreads();
+        float bv = cand_v[0]; int bx = cand_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (cand_v[w] > bv || (cand_v[w] == bv && cand_i[w] < bx)) { bv = cand_v[w]; bx = cand_i[w]; }
+        if (tid == 0) { sel_v[sel] = bv; sel_i[sel] = bx; }
+#pragma unroll
+        for (int u = 0; u < BS_NPT; ++u) if (tid + 256 * u == bx) taken |= 1u << u;
+        __syncthreads();
+    }
+    if (tid < k) {
+        const int idx = sel_i[tid];
+        const int id = idx % V, par = idx / V;
+        const int f = fin_old[par] | (id == id_end ? 1 : 0);
+        ids_step[b * k + tid] = id;
+        parents_step[b * k + tid] = par;
+        ids_out[((long long)b * max_steps + time) * k + tid] = id;
+        if (par_out) par_out[((long long)b * max_steps + time) * k + tid] = par;
+        logp[b * k + tid] = sel_v[tid];
+        finished[b * k + tid] = f;
+        if (!f) atomicAdd(n_unfinished, 1);
+    }
+}
+
 // new[v] = old[b*k + parents[v]] for the carried state (o | h of rec, and c)   (beam_search_decoder_cell.py:176-178)
 __global__ __launch_bounds__(256) void beam_gather_kernel(const float* __restrict__ rec, int ldr, int XH, const float* __restrict__ cs, int U,
                                                          const int* __restrict__ parents, int k, float* __restrict__ tmp_rec, float* __restrict__ tmp_cs, int n) {
@@ -1480,12 +1697,18 @@ __global__ __launch_bounds__(256) void beam_gather_kernel(const float* __restric
     }
 }
 __global__ __launch_bounds__(256) void beam_scatter_kernel(float* __restrict__ rec, int ldr, int XH, float* __restrict__ cs, int U,
-                                                          const float* __restrict__ tmp_rec, const float* __restrict__ tmp_cs, int n) {
+                                                          const float* __restrict__ tmp_rec, const float* __restrict__ tmp_cs, int n,
+                                                          bf16_t* __restrict__ recb, int ldrb) {
+    // recb (nullable): the bf16 mirror of the re-ordered [o | h] rows, written in the same pass (it was a launch of its own: mirror_kernel)
     const int W = XH + U;
     const long long total = (long long)n * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int v = (int)(i / W), c = (int)(i - (long long)v * W);
-        if (c < XH) rec[(long long)v * ldr + c] = tmp_rec[(long long)v * XH + c];
+        if (c < XH) {
+            const float x = tmp_rec[(long long)v * XH + c];
+            rec[(long long)v * ldr + c] = x;
+            if (recb) recb[(long long)v * ldrb + c] = f2bf(x);
+        }
         else cs[(long long)v * U + (c - XH)] = tmp_cs[(long long)v * U + (c - XH)];
     }
 }
@@ -1652,6 +1875,26 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
         }
         DONE;
     }
+    // beam search: one pass over an image's rows for all its hypotheses (attn_fwd_part_beam_kernel); the chunk count is chosen per IMAGE
+    static int beam_shared = -1;                          // LXO_ATT_BEAM_SHARED=0: the per-row kernel for beam search too (A/B)
+    if (beam_shared < 0) { const char* e = getenv("LXO_ATT_BEAM_SHARED"); beam_shared = (e && e[0] == '0') ? 0 : 1; }
+    if (beam_shared && (beam == 2 || beam == 3 || beam == 5) && ahs.n == 0 && att_h && E <= 256 && C <= 512 && nv % beam == 0) {
+        const int nimg = nv / beam;
+        int nb = cdiv(512, nimg);
+        if (nb > 16) nb = 16;
+        const int by_rows = R / 32 > 0 ? R / 32 : 1;
+        if (nb > by_rows) nb = by_rows;
+        const int need = cdiv(R, 1024);
+        if (nb < need) nb = need;
+        const int rpb = cdiv(R, nb);
+        const dim3 gb(nb, nimg);
+#define ABM(CT_, NB_) hipLaunchKernelGGL((attn_fwd_part_beam_kernel<CT_, 4, NB_>), gb, dim3(512), 0, st, (const CT_*)att_img, (const CT_*)img, att_h, beta, alpha, part, R, Rp, E, C, nb, rpb, rev)
+        if (dt == LXO_BF16) { if (beam == 2) ABM(bf16_t, 2); else if (beam == 3) ABM(bf16_t, 3); else ABM(bf16_t, 5); }
+        else { if (beam == 2) ABM(float, 2); else if (beam == 3) ABM(float, 3); else ABM(float, 5); }
+#undef ABM
+        hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, nb, rpb);
+        DONE;
+    }
 #define AF_ARGS att_h, ahs, att_h_out, beta, alpha, part, R, Rp, E, C, beam, nch, rows_per, rev
     if (dt == LXO_BF16) {
         if (E <= 256) { if (att_u(rows_per) == 8) hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 8>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); else hipLaunchKernelGGL((attn_fwd_part_kernel<bf16_t, 1, 7>), grid, dim3(512), 0, st, (const bf16_t*)att_img, (const bf16_t*)img, AF_ARGS); }
@@ -1796,12 +2039,17 @@ int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, i
         dp.log_gamma = logf(div_gamma);
         dp.thr = div_prob >= 1.f ? 16777216u : (unsigned)(div_prob * 16777216.0f);
     }
+    static int fast = -1;                                      // LXO_BEAM_FAST=0: the general kernel always (A/B)
+    if (fast < 0) { const char* e = getenv("LXO_BEAM_FAST"); fast = (e && e[0] == '0') ? 0 : 1; }
+    if (fast && dp.log_gamma == 0.f && (long long)k * V <= 256 * BS_NPT)
+        LAUNCH(beam_step_fast_kernel, nimg, logits, Vp, V, k, id_end, time, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
+    else
     LAUNCH(beam_step_kernel, nimg, logits, Vp, V, k, id_end, time, dp, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
     DONE;
 }
-int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, hipStream_t st) {
+int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, void* recb, int ldrb, hipStream_t st) {
     LAUNCH(beam_gather_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, parents, k, tmp_rec, tmp_cs, n);
-    LAUNCH(beam_scatter_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, tmp_rec, tmp_cs, n);
+    LAUNCH(beam_scatter_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, tmp_rec, tmp_cs, n, (bf16_t*)recb, ldrb);
     DONE;
 }
 int lxo_k_tile_rows(const float* src, int lds, float* dst, int ldd, int n, int k, int cols, hipStream_t st) {

@@ -295,7 +295,8 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
 int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, const float* ntok_dev, hipStream_t st) {
     HIPRC(hipMemsetAsync(P.ws<float>(ws, W_LOSS), 0, 64, st));
     RC(lxo_k_ce_loss(P.s.dtype, P.ws<float>(ws, W_LOGITS), formula, lengths, P.ws<void>(ws, W_DLOGITS), P.ws<float>(ws, W_LOSS),
-                     inv_ntok, ntok_dev, P.bf ? P.ws<unsigned>(ws, W_XSYNC) + 8 * 64 : nullptr, P.s.B, P.s.T, P.s.V, P.Vp, P.det_scratch(ws), st));
+                     inv_ntok, ntok_dev, P.bf ? P.ws<unsigned>(ws, W_XSYNC) + 8 * 64 : nullptr, P.s.B, P.s.T, P.s.V, P.Vp,
+                     DetScratch{P.ws<float>(ws, W_DET), P.wbytes[W_DET] / 4}, st));      // every mode: per-workgroup partial statistics added in order (25 us; the atomic form measured 53)
     return 0;
 }
 
@@ -597,6 +598,17 @@ static int decode_common_step(const Plan& P, const float* prm, const void* wp, v
                      rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U, nullptr,
                      P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, 0, 0, 0}, st));
     }
+    // logits = o y_W_o (attention_cell.py:84).  On the step kernel where it runs: one workgroup per 16 vocabulary columns and 16 / 64 rows
+    // (128 .. 160 workgroups); the dense-GEMM tiles gave 8 (greedy, 64 rows) or 12 (beam 5, 320 rows) workgroups -- 19 us of a beam step
+    if (fused_steps(P) && V % 4 == 0) {
+        RStep e; memset(&e, 0, sizeof(e));
+        e.M = nv; e.N = V; e.K = O; e.U = U; e.O = O; e.zx_row = -1; e.epi = RS_PLAIN; e.dr.inv_keep = 1.f;
+        e.A = P.bf ? (const void*)(P.ws<bf16_t>(ws, W_RECB) + (size_t)cur * nv * P.RECB) : (const void*)(rec + (size_t)cur * nv * P.REC);
+        e.lda = P.bf ? P.RECB : P.REC;
+        e.W = P.pk(wp, K_YWO_T); e.ldw = O; e.out = P.ws<float>(ws, W_DEC_LOGITS); e.ldo = P.Vp;
+        const int rc = lxo_launch_rstep(P.s.dtype, P.bf, e, st);
+        if (rc != -2) return rc < 0 ? rc : -rc;
+    }
     RC(nt(P, true, true, nv <= 64, rec + (size_t)cur * nv * P.REC, P.REC, P.pk(wp, K_YWO_T), O, P.ws<float>(ws, W_DEC_LOGITS), P.Vp,
           nv, V, O, nullptr, 0, false, st));
     return 0;
@@ -751,8 +763,8 @@ int lxo_impl_decode_step(const Plan& P, const float* prm, const void* wp, void* 
         RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, P.s.div_gamma, P.s.div_prob, P.s.div_seed, tmp,
                            P.ws<float>(ws, W_BEAM_LP), finished, ids_step, par_step, ids_out, parents_out, ms, flags, st));
         RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
-                             tmp, tmp + (size_t)nv * P.XH, nv, st));
-        if (fused_steps(P)) RC(mirror_oh(P, ws, (size_t)cur * nv, nv, st));
+                             tmp, tmp + (size_t)nv * P.XH, nv,
+                             (fused_steps(P) && P.bf) ? P.ws<bf16_t>(ws, W_RECB) + (size_t)cur * nv * P.RECB : nullptr, P.RECB, st));      // + the bf16 mirror of the re-ordered [o | h] rows
     }
     if (finished_out) HIPRC(hipMemcpyAsync(finished_out, finished, (size_t)nv * 4, hipMemcpyDeviceToHost, st));
     if (unfinished_host) {
@@ -785,8 +797,8 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
                            logp, finished, ids_step, par_step,
                            ids_out, parents_out, ms, unfinished, st));
         RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
-                             tmp, tmp + (size_t)nv * P.XH, nv, st));
-        if (fused_steps(P)) RC(mirror_oh(P, ws, (size_t)cur * nv, nv, st));    // the re-ordered [o | h] rows feed the next LSTM GEMM
+                             tmp, tmp + (size_t)nv * P.XH, nv,
+                             (fused_steps(P) && P.bf) ? P.ws<bf16_t>(ws, W_RECB) + (size_t)cur * nv * P.RECB : nullptr, P.RECB, st));    // the re-ordered [o | h] rows (+ their bf16 mirror) feed the next LSTM GEMM
         return 0;
     }));
     return 0;

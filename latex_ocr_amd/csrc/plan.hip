@@ -141,6 +141,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_M5] = (bf && !cnn) ? BL * H6 * W5 * C : 0;
     wb[W_ATT_EXP] = bf ? BL * R * E * esz : 0;
     wb[W_XSYNC] = bf ? 2 * ((size_t)4096 + (384u << 10)) : 8192;     // one block per chain, forward then backward (xdec.h: kXDecBlockBytes)
+    wb[W_DET] = 8192;                    // every mode: the 512 x 2 per-workgroup partial loss statistics (lxo_impl_ce_loss: ordered AND faster than 2048 workgroups' atomics on two words)
     if (!bf || s.deterministic) {        // the largest user (f32): d_beta, one E-vector per (sample, 16 regions) workgroup; column sums use at most 1024 row blocks x 4U columns
         size_t need = BL * (size_t)((R + 15) / 16) * E * f4;
         const size_t floor_ = (size_t)1024 * (4 * U > 2048 ? 4 * U : 2048) * f4;
