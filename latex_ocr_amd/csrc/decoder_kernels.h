@@ -24,7 +24,7 @@ int lxo_k_tanh_bwd(const float* a, int lda, Slabs carry, const float* o, int ldo
 int lxo_k_slab_reduce(Slabs sl, float* o, int ldo, int rows, int cols, hipStream_t st);
 int lxo_k_tanh_finalize(Slabs sl, float* o, int ldo, Drop dr, int rows, int cols, hipStream_t st);
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
-                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, int rev, hipStream_t st);   // ctxb (nullable): bf16 copy of ctx, pitch ldcb
+                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, int rev, hipStream_t st, const void* att_exp = nullptr);   // ctxb (nullable): bf16 copy of ctx, pitch ldcb; att_exp (nullable, bf16 beam decode): e^{2 att_img}
 int lxo_k_att_exp(const void* att_img, void* att_exp, long long n, hipStream_t st);       // bf16: att_exp = e^{2 att_img}, n elements (n % 8 == 0)
 int lxo_k_attn_bwd(int dt, const void* att_img, const void* att_exp, const void* img, const float* att_h, const float* beta, const float* alpha,
                    Slabs dcs, int dcoff, float* dctx_out, int lddc, const float* ctx, int ldctx, float* de, float* datth,

@@ -412,7 +412,21 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
 // (profiles/r05_beam_kernels_before.csv).  The arithmetic of a (row, hypothesis) pair is the per-row kernel's, in the same order (same
 // butterfly, same online-softmax updates), so the partials -- and with them the ids of the f32 parity mode -- are bit-identical to the
 // per-row kernel's for the same chunking.
-template <typename CT, int ATT_U, int NBM>
+// wave-wide sum without the LDS crossbar (v_add_f32_dpp inside a row of 16 lanes, v_permlane16 / 32_swap across rows: 69 ns per
+// dependent 64-lane reduction against 197 through ds_bpermute, tools/dpp_probe.hip): the forms of csrc/xdec.hip, for the bf16 instantiation
+template <int CTRL> LXO_DEV float bm_dpp_add(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+LXO_DEV float bm_wave_sum_dpp(float v) {
+    v = bm_dpp_add<0xB1>(v); v = bm_dpp_add<0x4E>(v); v = bm_dpp_add<0x141>(v); v = bm_dpp_add<0x140>(v);
+    { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    return v;
+}
+// EXPD (bf16 decode): att_img holds E_x = e^{2 att_img} (ws region att_exp, written once per decode call); with E_a = e^{2 att_h} and
+// r = 1 / (1 + E_x E_a), tanh = 1 - 2 r and the score is sum_k beta_k - 2 sum_k beta_k r_k: the constant is the same for every region of a
+// hypothesis, the softmax does not see it, it is dropped -- ONE transcendental per element instead of two (as in the training chains);
+// the softmax exponentials on v_exp_f32, the 64-lane sums on DPP.  ~400 -> ~200 issue cycles per (row, hypothesis): the kernel is bound
+// by that arithmetic (5 hypotheses per loaded row), not by the stream.
+template <typename CT, int ATT_U, int NBM, bool EXPD>
 __global__ __launch_bounds__(512) void attn_fwd_part_beam_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                                 const float* __restrict__ att_h, const float* __restrict__ beta,
                                                                 float* __restrict__ alpha, float* __restrict__ part,
@@ -430,12 +444,16 @@ __global__ __launch_bounds__(512) void attn_fwd_part_beam_kernel(const CT* __res
     float ah[NBM][4], bt[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bt[j] = 0.f;
-    if (kok) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + k0); for (int j = 0; j < 4; ++j) bt[j] = b4[j]; }
+    if (kok) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + k0); for (int j = 0; j < 4; ++j) bt[j] = EXPD ? -2.f * b4[j] : b4[j]; }
 #pragma unroll
     for (int b = 0; b < NBM; ++b) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) ah[b][j] = 0.f;
-        if (kok) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(att_h + (long long)(bi * NBM + b) * E + k0); for (int j = 0; j < 4; ++j) ah[b][j] = a4[j]; }
+        if (kok) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(att_h + (long long)(bi * NBM + b) * E + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ah[b][j] = EXPD ? __builtin_amdgcn_exp2f(fminf(fmaxf(a4[j] * 2.8853900817779268f, -60.f), 60.f)) : a4[j];
+        }
     }
     const int c0 = lane * 8;
     const bool cok = c0 < C;
@@ -463,19 +481,29 @@ __global__ __launch_bounds__(512) void attn_fwd_part_beam_kernel(const CT* __res
 #pragma unroll
             for (int u = 0; u < ATT_U; ++u) {
                 float a = 0.f;
+                if constexpr (EXPD) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a = fmaf(tanh_ct<CT>(x[u][j] + ah[b][j]), bt[j], a);
+                    for (int j = 0; j < 4; ++j) a = fmaf(__builtin_amdgcn_rcpf(fmaf(x[u][j], ah[b][j], 1.f)), bt[j], a);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a = fmaf(tanh_ct<CT>(x[u][j] + ah[b][j]), bt[j], a);
+                }
                 pt[u] = kok ? a : 0.f;
             }
+            if constexpr (EXPD) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
+                for (int u = 0; u < ATT_U; ++u) pt[u] = bm_wave_sum_dpp(pt[u]);
+            } else {
 #pragma unroll
-                for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+                for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                    for (int u = 0; u < ATT_U; ++u) pt[u] += __shfl_xor(pt[u], o);
+                }
             }
             float mn = m[b];
 #pragma unroll
             for (int u = 0; u < ATT_U; ++u) if (base + ATT_W * u < n) mn = fmaxf(mn, pt[u]);
-            const float sc = expf(m[b] - mn);
+            const float sc = EXPD ? __expf(m[b] - mn) : expf(m[b] - mn);
             l[b] *= sc;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[b][e] *= sc;
@@ -484,11 +512,11 @@ __global__ __launch_bounds__(512) void attn_fwd_part_beam_kernel(const CT* __res
             for (int u = 0; u < ATT_U; ++u) {
                 const int r = base + ATT_W * u;
                 if (r < n) {
-                    const float pw = expf(pt[u] - mn);
+                    const float pw = EXPD ? __expf(pt[u] - mn) : expf(pt[u] - mn);
                     l[b] += pw;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) acc[b][e] = fmaf(pw, xi[u][e], acc[b][e]);
-                    if (lane == 0) alpha[(long long)(bi * NBM + b) * Rp + r0 + r] = pt[u];       // raw score
+                    if (lane == 0) alpha[(long long)(bi * NBM + b) * Rp + r0 + r] = pt[u];       // raw score (EXPD: up to the constant sum of beta, which the softmax does not see)
                 }
             }
         }
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(512) void attn_fwd_part_beam_kernel(const CT* __res
         float mc = red[0];
 #pragma unroll
         for (int w = 1; w < ATT_W; ++w) mc = fmaxf(mc, red[w]);
-        const float sw = (l[b] > 0.f) ? expf(m[b] - mc) : 0.f;
+        const float sw = (l[b] > 0.f) ? (EXPD ? __expf(m[b] - mc) : expf(m[b] - mc)) : 0.f;
         if (lane == 0) red[ATT_W + wave] = l[b] * sw;
         if (cok) {
 #pragma unroll
@@ -1857,7 +1885,7 @@ static int att_u(int rows_per) {
     return (rows_per + 55) / 56 <= (rows_per + 63) / 64 ? 7 : 8;
 }
 int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* att_h, Slabs ahs, float* att_h_out, const float* beta, float* alpha, float* part,
-                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, int rev, hipStream_t st) {
+                   float* ctx, int ldctx, void* ctxb, int ldcb, int nv, int R, int Rp, int E, int C, int beam, int nch, int rev, hipStream_t st, const void* att_exp) {
     if (E > 1024 || C > 512 || nch < 1 || nch > 32) return -2;
     const int rows_per = cdiv(R, nch);
     dim3 grid(nch, nv);
@@ -1888,9 +1916,10 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
         if (nb < need) nb = need;
         const int rpb = cdiv(R, nb);
         const dim3 gb(nb, nimg);
-#define ABM(CT_, NB_) hipLaunchKernelGGL((attn_fwd_part_beam_kernel<CT_, 4, NB_>), gb, dim3(512), 0, st, (const CT_*)att_img, (const CT_*)img, att_h, beta, alpha, part, R, Rp, E, C, nb, rpb, rev)
-        if (dt == LXO_BF16) { if (beam == 2) ABM(bf16_t, 2); else if (beam == 3) ABM(bf16_t, 3); else ABM(bf16_t, 5); }
-        else { if (beam == 2) ABM(float, 2); else if (beam == 3) ABM(float, 3); else ABM(float, 5); }
+#define ABM(CT_, NB_, X_, AI_) hipLaunchKernelGGL((attn_fwd_part_beam_kernel<CT_, 4, NB_, X_>), gb, dim3(512), 0, st, (const CT_*)(AI_), (const CT_*)img, att_h, beta, alpha, part, R, Rp, E, C, nb, rpb, rev)
+        if (dt == LXO_BF16 && att_exp) { if (beam == 2) ABM(bf16_t, 2, true, att_exp); else if (beam == 3) ABM(bf16_t, 3, true, att_exp); else ABM(bf16_t, 5, true, att_exp); }
+        else if (dt == LXO_BF16) { if (beam == 2) ABM(bf16_t, 2, false, att_img); else if (beam == 3) ABM(bf16_t, 3, false, att_img); else ABM(bf16_t, 5, false, att_img); }
+        else { if (beam == 2) ABM(float, 2, false, att_img); else if (beam == 3) ABM(float, 3, false, att_img); else ABM(float, 5, false, att_img); }
 #undef ABM
         hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, nb, rpb);
         DONE;
