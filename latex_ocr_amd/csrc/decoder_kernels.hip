@@ -414,6 +414,14 @@ __global__ __launch_bounds__(512) void attn_fwd_part_kernel(const CT* __restrict
 // per-row kernel's for the same chunking.
 // wave-wide sum without the LDS crossbar (v_add_f32_dpp inside a row of 16 lanes, v_permlane16 / 32_swap across rows: 69 ns per
 // dependent 64-lane reduction against 197 through ds_bpermute, tools/dpp_probe.hip): the forms of csrc/xdec.hip, for the bf16 instantiation
+#ifdef LXO_HIPSIM
+// (tests/hipsim has no DPP / permlane-swap model: the interpreter build sums through the shuffles it does model)
+LXO_DEV float bm_wave_sum_dpp(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+#else
 template <int CTRL> LXO_DEV float bm_dpp_add(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
 LXO_DEV float bm_wave_sum_dpp(float v) {
     v = bm_dpp_add<0xB1>(v); v = bm_dpp_add<0x4E>(v); v = bm_dpp_add<0x141>(v); v = bm_dpp_add<0x140>(v);
@@ -421,13 +429,17 @@ LXO_DEV float bm_wave_sum_dpp(float v) {
     { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
     return v;
 }
+#endif
 // EXPD (bf16 decode): att_img holds E_x = e^{2 att_img} (ws region att_exp, written once per decode call); with E_a = e^{2 att_h} and
 // r = 1 / (1 + E_x E_a), tanh = 1 - 2 r and the score is sum_k beta_k - 2 sum_k beta_k r_k: the constant is the same for every region of a
 // hypothesis, the softmax does not see it, it is dropped -- ONE transcendental per element instead of two (as in the training chains);
 // the softmax exponentials on v_exp_f32, the 64-lane sums on DPP.  ~400 -> ~200 issue cycles per (row, hypothesis): the kernel is bound
 // by that arithmetic (5 hypotheses per loaded row), not by the stream.
-template <typename CT, int ATT_U, int NBM, bool EXPD>
-__global__ __launch_bounds__(512) void attn_fwd_part_beam_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
+// OCC = waves per SIMD the register allocation must admit: 4 = two 8-wave workgroups per CU (the grid of 512 workgroups in ONE round, and
+// twice the waves to cover the loads) -- the 5-hypothesis instantiation gets there with 2 rows per wave in flight instead of 4 (118 VGPRs;
+// with 4 rows it needs 142 and forcing it into 128 spills 16 dwords)
+template <typename CT, int ATT_U, int NBM, bool EXPD, int OCC>
+__global__ __launch_bounds__(512, OCC) void attn_fwd_part_beam_kernel(const CT* __restrict__ att_img, const CT* __restrict__ img,
                                                                 const float* __restrict__ att_h, const float* __restrict__ beta,
                                                                 float* __restrict__ alpha, float* __restrict__ part,
                                                                 int R, int Rp, int E, int C, int nch, int rows_per, int rev) {
@@ -1662,12 +1674,15 @@ __global__ __launch_bounds__(256) void beam_step_fast_kernel(const float* __rest
     const int nb = time > 0 ? k : 1;
     const int total = nb * V;
     float val[BS_NPT];
+    int jq = tid / V, cq = tid - jq * V;                         // (hypothesis, id) of candidate i = tid + 256 u, walked instead of divided
 #pragma unroll
     for (int u = 0; u < BS_NPT; ++u) {
         const int i = tid + 256 * u;
         val[u] = -INFINITY;
+        const int j = jq, c = cq;
+        cq += 256;
+        while (cq >= V) { cq -= V; ++jq; }
         if (i < total) {
-            const int j = i / V, c = i - j * V;
             float sl = logits[((long long)b * k + j) * Vp + c] - lse[j];
             const float f = fin_old[j] ? 1.f : 0.f;
             sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
@@ -1738,6 +1753,49 @@ __global__ __launch_bounds__(256) void beam_scatter_kernel(float* __restrict__ r
             if (recb) recb[(long long)v * ldrb + c] = f2bf(x);
         }
         else cs[(long long)v * U + (c - XH)] = tmp_cs[(long long)v * U + (c - XH)];
+    }
+}
+// The same re-ordering in ONE launch and in place: the permutation stays inside an image's k rows, so one workgroup per image reads its
+// k x (XH + U) state values into registers, meets at a barrier, and writes them back permuted (+ the bf16 mirror of [o | h]).  (The
+// gather / scatter pair above went through a scratch copy: two launches of ~5 us each in a 110 us beam step.)  Up to BP_NPT values per thread.
+constexpr int BP_NPT = 32;
+__global__ __launch_bounds__(256) void beam_permute_kernel(float* __restrict__ rec, int ldr, int XH, float* __restrict__ cs, int U,
+                                                          const int* __restrict__ parents, int k, bf16_t* __restrict__ recb, int ldrb) {
+    const int b = blockIdx.x, W = XH + U, total = k * W;
+    float v[BP_NPT];
+    const int r0 = threadIdx.x / W, c0 = threadIdx.x - r0 * W;  // (row, column) of value i = tid + 256 u: walked, not divided
+    int rq = r0, cq = c0;
+#pragma unroll
+    for (int u = 0; u < BP_NPT; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        v[u] = 0.f;
+        const int r = rq, c = cq;
+        cq += 256;
+        while (cq >= W) { cq -= W; ++rq; }
+        if (i < total) {
+            const int src = b * k + parents[b * k + r];
+            v[u] = c < XH ? rec[(long long)src * ldr + c] : cs[(long long)src * U + (c - XH)];
+        }
+    }
+    // every read of this image's rows must have completed before the first write: the loaded values are COPIED (a use makes the
+    // compiler wait for the loads) in front of the barrier
+    float keep = 0.f;
+#pragma unroll
+    for (int u = 0; u < BP_NPT; ++u) keep += v[u];
+    if (keep != keep && total < 0) rec[0] = keep;               // (never true: only forces the loads to land here)
+    __syncthreads();
+    rq = r0; cq = c0;
+#pragma unroll
+    for (int u = 0; u < BP_NPT; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int r = rq, c = cq;
+        cq += 256;
+        while (cq >= W) { cq -= W; ++rq; }
+        if (i < total) {
+            const int dst = b * k + r;
+            if (c < XH) { rec[(long long)dst * ldr + c] = v[u]; if (recb) recb[(long long)dst * ldrb + c] = f2bf(v[u]); }
+            else cs[(long long)dst * U + (c - XH)] = v[u];
+        }
     }
 }
 // row v of dst = row v / k of src (tile the initial state over the beam, beam_search_decoder_cell.py:98-109)
@@ -1916,10 +1974,10 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
         if (nb < need) nb = need;
         const int rpb = cdiv(R, nb);
         const dim3 gb(nb, nimg);
-#define ABM(CT_, NB_, X_, AI_) hipLaunchKernelGGL((attn_fwd_part_beam_kernel<CT_, 4, NB_, X_>), gb, dim3(512), 0, st, (const CT_*)(AI_), (const CT_*)img, att_h, beta, alpha, part, R, Rp, E, C, nb, rpb, rev)
-        if (dt == LXO_BF16 && att_exp) { if (beam == 2) ABM(bf16_t, 2, true, att_exp); else if (beam == 3) ABM(bf16_t, 3, true, att_exp); else ABM(bf16_t, 5, true, att_exp); }
-        else if (dt == LXO_BF16) { if (beam == 2) ABM(bf16_t, 2, false, att_img); else if (beam == 3) ABM(bf16_t, 3, false, att_img); else ABM(bf16_t, 5, false, att_img); }
-        else { if (beam == 2) ABM(float, 2, false, att_img); else if (beam == 3) ABM(float, 3, false, att_img); else ABM(float, 5, false, att_img); }
+#define ABM(CT_, U_, NB_, X_, OCC_, AI_) hipLaunchKernelGGL((attn_fwd_part_beam_kernel<CT_, U_, NB_, X_, OCC_>), gb, dim3(512), 0, st, (const CT_*)(AI_), (const CT_*)img, att_h, beta, alpha, part, R, Rp, E, C, nb, rpb, rev)
+        if (dt == LXO_BF16 && att_exp) { if (beam == 2) ABM(bf16_t, 4, 2, true, 4, att_exp); else if (beam == 3) ABM(bf16_t, 4, 3, true, 4, att_exp); else ABM(bf16_t, 2, 5, true, 4, att_exp); }
+        else if (dt == LXO_BF16) { if (beam == 2) ABM(bf16_t, 4, 2, false, 2, att_img); else if (beam == 3) ABM(bf16_t, 4, 3, false, 2, att_img); else ABM(bf16_t, 4, 5, false, 2, att_img); }
+        else { if (beam == 2) ABM(float, 4, 2, false, 2, att_img); else if (beam == 3) ABM(float, 4, 3, false, 2, att_img); else ABM(float, 4, 5, false, 2, att_img); }
 #undef ABM
         hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(4, nv), dim3(256), 0, st, part, alpha, ctx, ldctx, (bf16_t*)ctxb, ldcb, R, Rp, C, nb, rpb);
         DONE;
@@ -2077,6 +2135,10 @@ int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, i
     DONE;
 }
 int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, void* recb, int ldrb, hipStream_t st) {
+    if (k >= 1 && n % k == 0 && (long long)k * (XH + U) <= 256 * BP_NPT) {
+        LAUNCH(beam_permute_kernel, n / k, rec, ldr, XH, cs, U, parents, k, (bf16_t*)recb, ldrb);
+        DONE;
+    }
     LAUNCH(beam_gather_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, parents, k, tmp_rec, tmp_cs, n);
     LAUNCH(beam_scatter_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, tmp_rec, tmp_cs, n, (bf16_t*)recb, ldrb);
     DONE;
