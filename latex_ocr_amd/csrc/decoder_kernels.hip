@@ -1645,7 +1645,32 @@ __global__ __launch_bounds__(256) void beam_step_fast_kernel(const float* __rest
     __shared__ float lp_old[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float FMIN = -3.40282347e38f;
-    for (int j = wave; j < k; j += 4) {                       // log-sum-exp per hypothesis: one wave each, the row in registers when it fits
+    if (V <= 64 * 8 && k <= 8) {
+        // log-sum-exp per hypothesis: a wave takes hypotheses `wave` and `wave + 4`, BOTH rows requested before either is reduced (one
+        // memory round trip instead of two), each row in registers for its two passes
+        float x[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = min(wave + 4 * q, k - 1);
+            const float* lg = logits + ((long long)b * k + j) * Vp;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = lane + 64 * u; x[q][u] = lg[c < V ? c : V - 1]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = wave + 4 * q;
+            float m = -3.0e38f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (lane + 64 * u < V) m = fmaxf(m, x[q][u]);
+            m = wave_max(m);
+            float l = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (lane + 64 * u < V) l += expf(x[q][u] - m);
+            l = wave_sum(l);
+            if (lane == 0 && j < k) lse[j] = m + logf(l);
+        }
+    } else
+    for (int j = wave; j < k; j += 4) {                       // the general form: one wave per hypothesis, round-robin
         const float* lg = logits + ((long long)b * k + j) * Vp;
         float m = -3.0e38f;
         if (V <= 64 * 16) {
@@ -1755,46 +1780,30 @@ __global__ __launch_bounds__(256) void beam_scatter_kernel(float* __restrict__ r
         else cs[(long long)v * U + (c - XH)] = tmp_cs[(long long)v * U + (c - XH)];
     }
 }
-// The same re-ordering in ONE launch and in place: the permutation stays inside an image's k rows, so one workgroup per image reads its
-// k x (XH + U) state values into registers, meets at a barrier, and writes them back permuted (+ the bf16 mirror of [o | h]).  (The
-// gather / scatter pair above went through a scratch copy: two launches of ~5 us each in a 110 us beam step.)  Up to BP_NPT values per thread.
-constexpr int BP_NPT = 32;
+// The same re-ordering in ONE launch and in place: the permutation moves whole ROWS inside an image's k rows, so column c of the state is
+// permuted independently of every other column -- a thread takes one column of one image, reads its k values through `parents`, then
+// writes them back in order (+ the bf16 mirror of [o | h]).  No scratch copy, no barrier; grid = images x ceil((XH + U) / 256) workgroups.
+// (The gather / scatter pair above went through a scratch copy: two launches of ~5 us each in a 110 us beam step.)
+constexpr int BP_KMAX = 16;
 __global__ __launch_bounds__(256) void beam_permute_kernel(float* __restrict__ rec, int ldr, int XH, float* __restrict__ cs, int U,
                                                           const int* __restrict__ parents, int k, bf16_t* __restrict__ recb, int ldrb) {
-    const int b = blockIdx.x, W = XH + U, total = k * W;
-    float v[BP_NPT];
-    const int r0 = threadIdx.x / W, c0 = threadIdx.x - r0 * W;  // (row, column) of value i = tid + 256 u: walked, not divided
-    int rq = r0, cq = c0;
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= XH + U) return;
+    float v[BP_KMAX];
 #pragma unroll
-    for (int u = 0; u < BP_NPT; ++u) {
-        const int i = threadIdx.x + 256 * u;
-        v[u] = 0.f;
-        const int r = rq, c = cq;
-        cq += 256;
-        while (cq >= W) { cq -= W; ++rq; }
-        if (i < total) {
+    for (int r = 0; r < BP_KMAX; ++r) {
+        v[r] = 0.f;
+        if (r < k) {
             const int src = b * k + parents[b * k + r];
-            v[u] = c < XH ? rec[(long long)src * ldr + c] : cs[(long long)src * U + (c - XH)];
+            v[r] = c < XH ? rec[(long long)src * ldr + c] : cs[(long long)src * U + (c - XH)];
         }
     }
-    // every read of this image's rows must have completed before the first write: the loaded values are COPIED (a use makes the
-    // compiler wait for the loads) in front of the barrier
-    float keep = 0.f;
 #pragma unroll
-    for (int u = 0; u < BP_NPT; ++u) keep += v[u];
-    if (keep != keep && total < 0) rec[0] = keep;               // (never true: only forces the loads to land here)
-    __syncthreads();
-    rq = r0; cq = c0;
-#pragma unroll
-    for (int u = 0; u < BP_NPT; ++u) {
-        const int i = threadIdx.x + 256 * u;
-        const int r = rq, c = cq;
-        cq += 256;
-        while (cq >= W) { cq -= W; ++rq; }
-        if (i < total) {
+    for (int r = 0; r < BP_KMAX; ++r) {
+        if (r < k) {
             const int dst = b * k + r;
-            if (c < XH) { rec[(long long)dst * ldr + c] = v[u]; if (recb) recb[(long long)dst * ldrb + c] = f2bf(v[u]); }
-            else cs[(long long)dst * U + (c - XH)] = v[u];
+            if (c < XH) { rec[(long long)dst * ldr + c] = v[r]; if (recb) recb[(long long)dst * ldrb + c] = f2bf(v[r]); }
+            else cs[(long long)dst * U + (c - XH)] = v[r];
         }
     }
 }
@@ -2135,8 +2144,8 @@ int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, i
     DONE;
 }
 int lxo_k_beam_gather(float* rec, int ldr, int XH, float* cs, int U, const int* parents, int k, float* tmp_rec, float* tmp_cs, int n, void* recb, int ldrb, hipStream_t st) {
-    if (k >= 1 && n % k == 0 && (long long)k * (XH + U) <= 256 * BP_NPT) {
-        LAUNCH(beam_permute_kernel, n / k, rec, ldr, XH, cs, U, parents, k, (bf16_t*)recb, ldrb);
+    if (k >= 1 && k <= BP_KMAX && n % k == 0) {
+        LAUNCH(beam_permute_kernel, dim3(n / k, cdiv(XH + U, 256)), rec, ldr, XH, cs, U, parents, k, (bf16_t*)recb, ldrb);
         DONE;
     }
     LAUNCH(beam_gather_kernel, grid1((long long)n * (XH + U)), rec, ldr, XH, cs, U, parents, k, tmp_rec, tmp_cs, n);
