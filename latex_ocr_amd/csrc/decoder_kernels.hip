@@ -1973,7 +1973,8 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
     // beam search: one pass over an image's rows for all its hypotheses (attn_fwd_part_beam_kernel); the chunk count is chosen per IMAGE
     static int beam_shared = -1;                          // LXO_ATT_BEAM_SHARED=0: the per-row kernel for beam search too (A/B)
     if (beam_shared < 0) { const char* e = getenv("LXO_ATT_BEAM_SHARED"); beam_shared = (e && e[0] == '0') ? 0 : 1; }
-    if (beam_shared && (beam == 2 || beam == 3 || beam == 5) && ahs.n == 0 && att_h && E <= 256 && C <= 512 && nv % beam == 0) {
+    // (beam == 1 with att_exp: greedy decode in bf16 -- the same kernel with one hypothesis per image, for its E-domain arithmetic)
+    if (beam_shared && (beam == 2 || beam == 3 || beam == 5 || (beam == 1 && att_exp && dt == LXO_BF16)) && ahs.n == 0 && att_h && E <= 256 && C <= 512 && nv % beam == 0) {
         const int nimg = nv / beam;
         int nb = cdiv(512, nimg);
         if (nb > 16) nb = 16;
@@ -1984,7 +1985,7 @@ int lxo_k_attn_fwd(int dt, const void* att_img, const void* img, const float* at
         const int rpb = cdiv(R, nb);
         const dim3 gb(nb, nimg);
 #define ABM(CT_, U_, NB_, X_, OCC_, AI_) hipLaunchKernelGGL((attn_fwd_part_beam_kernel<CT_, U_, NB_, X_, OCC_>), gb, dim3(512), 0, st, (const CT_*)(AI_), (const CT_*)img, att_h, beta, alpha, part, R, Rp, E, C, nb, rpb, rev)
-        if (dt == LXO_BF16 && att_exp) { if (beam == 2) ABM(bf16_t, 4, 2, true, 4, att_exp); else if (beam == 3) ABM(bf16_t, 4, 3, true, 4, att_exp); else ABM(bf16_t, 2, 5, true, 4, att_exp); }
+        if (dt == LXO_BF16 && att_exp) { if (beam == 1) ABM(bf16_t, 4, 1, true, 4, att_exp); else if (beam == 2) ABM(bf16_t, 4, 2, true, 4, att_exp); else if (beam == 3) ABM(bf16_t, 4, 3, true, 4, att_exp); else ABM(bf16_t, 2, 5, true, 4, att_exp); }
         else if (dt == LXO_BF16) { if (beam == 2) ABM(bf16_t, 4, 2, false, 2, att_img); else if (beam == 3) ABM(bf16_t, 4, 3, false, 2, att_img); else ABM(bf16_t, 4, 5, false, 2, att_img); }
         else { if (beam == 2) ABM(float, 4, 2, false, 2, att_img); else if (beam == 3) ABM(float, 4, 3, false, 2, att_img); else ABM(float, 4, 5, false, 2, att_img); }
 #undef ABM

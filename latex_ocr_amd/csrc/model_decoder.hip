@@ -184,7 +184,7 @@ static int cell_step_fused(const Plan& P, const float* prm, const void* wp, void
     RC(lxo_k_attn_fwd(P.s.dtype, att_img, img, atth_t, kNoSlabs, nullptr,
                       prm + P.poff[P_BETA], alpha_t, part, rec_cur + P.OFF_CTX, P.REC, bf ? recb_cur + P.OFF_CTX : nullptr, P.RECB, nr, P.R, P.Rp, E, C, beam,
                       P.attn_chunks(nr), att_alternate() ? (dr.t & 1) : 0, st,
-                      (beam > 1 && P.att_exp()) ? P.ws<void>(ws, W_ATT_EXP) : nullptr));      // beam decode, bf16: the E-domain copy the decode set-up wrote
+                      (!gates_t && P.att_exp()) ? P.ws<void>(ws, W_ATT_EXP) : nullptr));      // decode (no gates kept), bf16: the E-domain copy the decode set-up wrote
     }
     // o = dropout(tanh([h~, ctx] [o_W_h; o_W_c]))                  (attention_cell.py:82-83)
     RStep k4 = a;
@@ -676,6 +676,7 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
     const int B = P.s.B, ms = P.s.max_steps;
     if (ms < max_iter + 1) return -5;
     RC(attention_prepare(P, prm, wp, ws, 1, st));
+    if (P.att_exp()) RC(lxo_k_att_exp(P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_ATT_EXP), (long long)B * P.R * P.s.E, st));      // bf16: E_x = e^{2 att_img}, once per call
     if (fused_steps(P)) RC(mirror_oh(P, ws, 0, B, st));
     int* flags = P.ws<int>(ws, W_DEC_FLAGS);          // [0..63]: per-step unfinished counters ; [64..]: finished[B]
     int* finished = flags + 64;
@@ -738,7 +739,7 @@ int lxo_impl_decode_begin(const Plan& P, const float* prm, const void* wp, void*
     const int B = P.s.B, k = P.s.beam > 1 ? P.s.beam : 1, nv = B * k;
     if (P.s.max_steps < 1 || k > 16) return -5;
     RC(attention_prepare(P, prm, wp, ws, k, st));
-    if (k > 1 && P.att_exp()) RC(lxo_k_att_exp(P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_ATT_EXP), (long long)B * P.R * P.s.E, st));      // beam decode, bf16: E_x = e^{2 att_img}, once per call
+    if (P.att_exp()) RC(lxo_k_att_exp(P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_ATT_EXP), (long long)B * P.R * P.s.E, st));      // bf16 decode: E_x = e^{2 att_img}, once per call
     if (fused_steps(P)) RC(mirror_oh(P, ws, 0, nv, st));
     HIPRC(hipMemsetAsync(P.ws<int>(ws, W_DEC_FLAGS), 0, 256 + (size_t)nv * 4, st));
     if (k > 1) HIPRC(hipMemsetAsync(P.ws<float>(ws, W_BEAM_LP), 0, (size_t)nv * 4, st));
@@ -781,7 +782,7 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
     const int B = P.s.B, k = P.s.beam, ms = P.s.max_steps, nv = B * k, U = P.s.U;
     if (ms < max_iter + 1 || k < 1 || k > 16) return -5;
     RC(attention_prepare(P, prm, wp, ws, k, st));
-    if (k > 1 && P.att_exp()) RC(lxo_k_att_exp(P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_ATT_EXP), (long long)B * P.R * P.s.E, st));      // bf16: E_x = e^{2 att_img}, once per call
+    if (P.att_exp()) RC(lxo_k_att_exp(P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_ATT_EXP), (long long)B * P.R * P.s.E, st));      // bf16: E_x = e^{2 att_img}, once per call
     if (fused_steps(P)) RC(mirror_oh(P, ws, 0, nv, st));
     int* flags = P.ws<int>(ws, W_DEC_FLAGS);
     int* finished = flags + 64;
