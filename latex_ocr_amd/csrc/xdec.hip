@@ -66,12 +66,13 @@ constexpr int kLLB = LXO_XDEC_LLMASK_B;
 #endif
 constexpr int kPF = LXO_XDEC_PF;
 // the same for the backward chain: 0 at the end of the chunk (Q2); 1 in Q3 behind its first workgroup barrier (the chunk partials are in
-// LDS by then); 3 in Q4 behind the workgroup barrier that follows the partial tiles.  Bit 4 (+4): the forward values of the coming phases
-// (gates, c, d_o(logits), o, ctx, att_h: HBM loads, ~2 us) are requested at that site too, ONE STEP AHEAD, instead of at the end of Q2.
+// LDS by then); 3 in Q4 behind the workgroup barrier that follows the partial tiles.  (The forward values of the coming phases -- gates, c,
+// d_o(logits), o, ctx, att_h: HBM loads, ~2 us -- stay at the end of Q2 in every variant: they are consumed within the step, so they cannot
+// be requested a step ahead without a second register set, and in front of the stream they measured slower in round 4.)
 #ifndef LXO_XDEC_PFB
 #define LXO_XDEC_PFB 0
 #endif
-constexpr int kPFB = LXO_XDEC_PFB & 3, kPFB_FV = (LXO_XDEC_PFB >> 2) & 1;
+constexpr int kPFB = LXO_XDEC_PFB;
 
 constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
 constexpr int SCMAX = 2048;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB)
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
             if (rem == 3) attb_block<ATT_U, EXPD>(xiA, xaA, alA, XBASE(it + 2, rev), an, dc, ah, s, acc, de_row, lane);
             }
             // forward values of the coming phases (unconditional, clamped indices)
-            if constexpr (!kPFB_FV) fwd_values(t);
+            fwd_values(t);
 #pragma unroll
             for (int j = 0; j < 4; ++j) redc[wave][lane * 4 + j] = acc[j] * bt[j];
             __syncthreads();
@@ -979,6 +980,7 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
                 *reinterpret_cast<f32x4*>(&redc[wave][lane * 4]) = v;
             }
             __syncthreads();
+            if (kPFB == 1 && t > 0) prefetch_b(t - 1);
             if (tid < NB * 64) {
                 const int row = tid >> 6, k4 = (tid & 63) * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(&redc[row * QS][k4]);
@@ -1042,6 +1044,7 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
                     for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][nt * 16 + r16] = acc[nt][i];
             }
             __syncthreads();
+            if (kPFB == 3 && t > 0) prefetch_b(t - 1);
             if (tid < NB * 32) {
                 float v = 0.f;
 #pragma unroll
