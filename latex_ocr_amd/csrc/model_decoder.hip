@@ -671,6 +671,44 @@ static int decode_loop(int max_iter, int* flags, hipStream_t st, int* steps_out,
     return 0;
 }
 
+// The same host loop at CHUNK granularity: one call of `chunk(first_step, n_steps, device counters)` enqueues n_steps steps (the persistent
+// greedy-decode chain runs a chunk as ONE launch).
+template <typename ChunkFn>
+static int decode_loop_chunked(int max_iter, int CHUNK, int* flags, hipStream_t st, int* steps_out, ChunkFn chunk) {
+    RC(poll_init());
+    if (CHUNK > 32) CHUNK = 32;
+    int enq = 0, nchunks = 0, steps = -1;
+    auto enqueue_chunk = [&]() -> int {
+        const int slot = nchunks & 1;
+        int* dflags = flags + slot * 32;
+        HIPRC(hipMemsetAsync(dflags, 0, 32 * sizeof(int), st));
+        int n = max_iter + 1 - enq; if (n > CHUNK) n = CHUNK;
+        RC(chunk(enq, n, dflags));
+        enq += n;
+        HIPRC(hipMemcpyAsync(g_poll.host + slot * 64, dflags, 32 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPRC(hipEventRecord(g_poll.ev[slot], st));
+        g_poll.host[slot * 64 + 32] = n;
+        g_poll.host[slot * 64 + 33] = enq - n;
+        ++nchunks;
+        return 0;
+    };
+    RC(enqueue_chunk());
+    int checked = 0;
+    while (steps < 0) {
+        if (enq <= max_iter) RC(enqueue_chunk());
+        const int slot = checked & 1;
+        HIPRC(hipEventSynchronize(g_poll.ev[slot]));
+        const int n = g_poll.host[slot * 64 + 32], first = g_poll.host[slot * 64 + 33];
+        for (int c = 0; c < n; ++c)
+            if (g_poll.host[slot * 64 + c] == 0 || first + c >= max_iter) { steps = first + c + 1; break; }
+        ++checked;
+        if (steps < 0 && checked == nchunks && enq > max_iter) steps = enq;
+    }
+    if (nchunks > checked) HIPRC(hipEventSynchronize(g_poll.ev[(nchunks - 1) & 1]));
+    if (steps_out) *steps_out = steps;
+    return 0;
+}
+
 int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter,
                            int* ids_out, float* alpha_out, int* steps_out, hipStream_t st) {
     const int B = P.s.B, ms = P.s.max_steps;
@@ -684,6 +722,34 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
     HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st));
     // rec/cs slot 0 holds the initial state; slots alternate
     if (fused_steps(P)) RC(decode_token_table(P, prm, wp, ws, st));
+    if (fused_steps(P) && P.bf && P.att_exp() && !alpha_out && P.s.step_kernels == 0) {
+        // the persistent greedy-decode chain (xdec.hip: xdec_dec_kernel): 16 steps per launch; -2 = the shape does not qualify
+        XDecDec x; memset(&x, 0, sizeof(x));
+        x.Wrt = (const bf16_t*)P.pk(wp, K_LSTM_RT); x.ldrt = P.ldRT;
+        x.Wah = (const bf16_t*)P.pk(wp, K_ATT_H_T); x.ldah = P.ldAHT;
+        x.Wow = (const bf16_t*)P.pk(wp, K_OW_T); x.ldow = P.ldOWT;
+        x.Wyo = (const bf16_t*)P.pk(wp, K_YWO_T); x.ldyo = P.s.O;
+        x.beta = prm + P.poff[P_BETA];
+        x.att_exp = P.ws<bf16_t>(ws, W_ATT_EXP); x.img = P.ws<bf16_t>(ws, W_IMG);
+        x.tx = P.ws<float>(ws, W_DEC_TX);
+        x.rec = P.ws<float>(ws, W_REC); x.recb = P.ws<bf16_t>(ws, W_RECB); x.cs = P.ws<float>(ws, W_CS);
+        x.part = P.ws<float>(ws, W_APART); x.sync = P.ws<unsigned>(ws, W_XSYNC);
+        x.ids_step = ids_step; x.ids_out = ids_out; x.finished = finished;
+        x.B = B; x.R = P.R; x.REC = P.REC; x.RECB = P.RECB; x.V = P.s.V; x.id_end = id_end; x.max_steps = ms;
+        x.t0 = 0; x.nsteps = 1; x.unfinished = flags;
+        static int chunk_steps = -1;
+        if (chunk_steps < 0) { const char* e = getenv("LXO_XDEC_DEC_CHUNK"); chunk_steps = (e && atoi(e) > 0) ? atoi(e) : 16; }
+        bool took = true;
+        const int rc = decode_loop_chunked(max_iter, chunk_steps, flags, st, steps_out, [&](int first, int n, int* unfinished) -> int {
+            XDecDec y = x; y.t0 = first; y.nsteps = n; y.unfinished = unfinished;
+            const int r = lxo_launch_xdec_dec(y, P.s.U, P.s.O, P.s.C, P.s.E, st);
+            if (r == -2 && first == 0) { took = false; return -2; }
+            return r;
+        });
+        if (took) return rc;
+        HIPRC(hipStreamSynchronize(st));                  // (nothing was enqueued by the refused first chunk but its counter memset)
+        HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st));
+    }
     RC(decode_loop(max_iter, flags, st, steps_out, [&](int time, int* unfinished) -> int {
         const int cur = (time + 1) & 1;
         RC(decode_common_step(P, prm, wp, ws, B, 1, cur, time == 0 ? nullptr : ids_step, st));

@@ -32,6 +32,31 @@ struct XDecFwd {
 // 0 = launched; -2 = the shape does not qualify (the caller runs the launch-per-step chain instead)
 int lxo_launch_xdec_fwd(const XDecFwd& p, int U, int O, int C, int E, hipStream_t st);
 
+// The same chain for GREEDY DECODE (dynamic_decode.py:17-74 over greedy_decoder_cell.py:53-66): steps t0 .. t0 + nsteps - 1 of the decode in
+// one launch.  What differs from the teacher-forced chain: the x-part of the LSTM pre-activation of a row is the row of the per-token table
+// its previous arg-max picks (row V: the start token), and every step ends with logits = o y_W_o, ids = arg-max -- computed at the START of
+// the next step's LSTM phase from the very o fragments that phase polls (the chain's last step is followed by one more such boundary).
+// The arg-max crosses the 32 workgroups of a chain as hand-over words {max, step tag << 16 | index}.  State lives in two alternating record
+// slots (slot t & 1 holds the state step t starts from), as in the launch-per-step decode.
+struct XDecDec {
+    const bf16_t* Wrt; int ldrt; const bf16_t* Wah; int ldah; const bf16_t* Wow; int ldow;      // as in XDecFwd
+    const bf16_t* Wyo; int ldyo;      // K_YWO_T [V][O]
+    const float* beta;
+    const bf16_t* att_exp;            // [B][R][E] e^{2 att_img}
+    const bf16_t* img;                // [B][R][C]
+    const float* tx;                  // [V + 1][4U] f32: emb(id) K[0:D] + b per input token; row V = the start token
+    float* rec; bf16_t* recb;         // [2][B][REC] / [2][B][RECB]
+    float* cs;                        // [2][B][U]
+    float* part;                      // [B][nq][C + 4] chunk partials
+    unsigned* sync;                   // block 0 of ws region "xdec_sync" (zeroed by the launcher); the arg-max words live in block 1's hand-over area
+    int* ids_step;                    // [B] in: the ids fed at step t0 (t0 > 0); out: the ids of the launch's last step
+    int* ids_out;                     // [B][max_steps]
+    int* finished;                    // [B] (0 / 1, sticky)
+    int* unfinished;                  // [nsteps] rows still unfinished after each step of this launch (zeroed by the caller)
+    int B, R, REC, RECB, V, id_end, t0, nsteps, max_steps;
+};
+int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_t st);
+
 // The same chain for BPTT (attention_cell.py:58-89 backwards, steps T-1 .. 0): per step [d_h~ | d_ctx] = g o_W^T, the attention stream
 // (d_e, d_att_h), d_h -> LSTM cell backward (d_z, d_c), the carries [d_o | d_h] = d_z K[D:]^T and g_{t-1}.  Everything a step hands to
 // the deferred all-step weight-gradient GEMMs (g, d_z and their bf16 mirrors, [d_h~ | d_ctx], d_e, d_att_h) is left in the same arrays

@@ -30,6 +30,7 @@
 // tests/hipsim interprets one workgroup after the other: a kernel whose workgroups wait for each other cannot run there
 int lxo_launch_xdec_fwd(const XDecFwd&, int, int, int, int, hipStream_t) { return -2; }
 int lxo_launch_xdec_bwd(const XDecBwd&, int, int, int, int, hipStream_t) { return -2; }
+int lxo_launch_xdec_dec(const XDecDec&, int, int, int, int, hipStream_t) { return -2; }
 extern "C" int lxo_xdec_debug(unsigned long long*) { return 0; }
 extern "C" int lxo_xdec_debug_bwd(unsigned long long*) { return 0; }
 #else
@@ -216,7 +217,7 @@ LXO_DEV void att_block(const u32x4 (&xi)[ATT_U], const u32x2 (&xa)[ATT_U], int b
             acc[2 * e] = fmaf(pw, __uint_as_float(xi[u][e] << 16), acc[2 * e]);
             acc[2 * e + 1] = fmaf(pw, __uint_as_float(xi[u][e] & 0xffff0000u), acc[2 * e + 1]);
         }
-        if (ok && lane == 0) sc[r] = pt[u];
+        if (ok && sc && lane == 0) sc[r] = pt[u];                   // (sc == null: the decode chain keeps no raw scores)
     }
 }
 // the loads of one block: UNCONDITIONAL (a row index beyond the chunk is clamped to its last row), so that the compiler counts them
@@ -668,6 +669,405 @@ int launch_nb(const XDecFwd& p, int att_u, hipStream_t st) {
     (void)att_u;
     if (p.att_exp) XLAUNCH(4, true); else XLAUNCH(4, false);
 #undef XLAUNCH
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ greedy-decode chain ----
+// xdec_fwd_kernel's phases with the decode's feedback (XDecDec in xdec.h).  Iteration s of the loop = [boundary: logits and arg-max of step
+// s - 1, from the o fragments P1 polls anyway] + [step s: P1 .. P4]; iteration nsteps is the boundary alone.  LDS: the y_W_o fragments take
+// the place of the raw scores (no alpha is kept), the o projection's A tile has 8 rows instead of 16.
+template <int NB>
+__global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
+    // 2 rows per wave and block in flight (the training chain: 4): the decode form carries more loop-invariant addresses (token table, ids,
+    // arg-max words) and with 4 rows the allocator spills 55 dwords of them into the serial phases; with 2 it spills 9
+    constexpr int NQ = 32 / NB, ATT_U = 2;
+    __shared__ __attribute__((aligned(16))) float redbuf[XW * 8 * 64];
+    float (*red)[8][64] = reinterpret_cast<float (*)[8][64]>(redbuf);
+    float (*redc)[XC] = reinterpret_cast<float (*)[XC]>(redbuf);
+    __shared__ u32x4 wahs[XW][2][64];
+    __shared__ u32x4 wyos[XW][2][64];                            // y_W_o B fragments: this workgroup's 16 vocabulary columns x its wave's 64 k   16 KB
+    __shared__ __attribute__((aligned(16))) bf16_t actx[8][XC + 8];
+    __shared__ float redl[XW][8][16];                            // logits partial tiles [wave][row][column]   4 KB
+    __shared__ float cst[8][16];
+    __shared__ float stm[NB][NQ], stl[NB][NQ], wgt[NB][NQ];
+    __shared__ float wred[2 * XW];
+    __shared__ int ids_l[8];
+    __shared__ int s_rank, s_dead;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g4 = lane >> 4;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    unsigned* xsync = p.sync + xcc * 64;
+    unsigned* err = p.sync + 8 * 64;
+    if (tid == 0) { s_dead = 0; s_rank = (int)atomicAdd(xsync + 32, 1u); }
+    for (int i = tid; i < 8 * (XC + 8); i += 512) (&actx[0][0])[i] = 0;
+    __syncthreads();
+    const int rank = s_rank;
+    if (rank >= 32) { if (tid == 0) *reinterpret_cast<volatile unsigned*>(err) = 2u; return; }
+    const int B = p.B, T = p.nsteps;
+    const int b0 = (int)xcc * NB;
+    const int u0 = rank * 16, e0 = rank * 8, o0 = rank * 16, v0 = rank * 16;
+
+#define P1K(ks) ((ks) < 2 ? wave * 64 + (ks) * 32 : XO + wave * 64 + ((ks) - 2) * 32)
+    u32x4 wrt0[4], wow[4];
+    u32x4* wl = reinterpret_cast<u32x4*>(xdec_dyn_lds) + (wave * 12) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wrt + (long long)(q * XU + u0 + r16) * p.ldrt + P1K(ks) + g4 * 8);
+            if (q == 0) wrt0[ks] = w; else wl[((q - 1) * 4 + ks) * 64] = w;
+        }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(p.Wah + (long long)(e0 + (r16 & 7)) * p.ldah + wave * 64 + ks * 32 + g4 * 8);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        wahs[wave][ks][lane] = r16 < 8 ? w : z;
+        // y_W_o rows v0 .. v0 + 15 (rows >= V: zeros, their logits are masked anyway), this wave's k range = P1's first two k-steps (o)
+        const int vr = v0 + r16;
+        const u32x4 y = *reinterpret_cast<const u32x4*>(p.Wyo + (long long)min(vr, p.V - 1) * p.ldyo + wave * 64 + ks * 32 + g4 * 8);
+        wyos[wave][ks][lane] = vr < p.V ? y : z;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        wow[ks] = *reinterpret_cast<const u32x4*>(p.Wow + (long long)(o0 + r16) * p.ldow + wave * 128 + ks * 32 + g4 * 8);
+    float bt[4];
+    { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + lane * 4); bt[0] = -2.f * b4[0]; bt[1] = -2.f * b4[1]; bt[2] = -2.f * b4[2]; bt[3] = -2.f * b4[3]; }
+    if (tid < NB * 16) cst[tid >> 4][tid & 15] = p.cs[((long long)(p.t0 & 1) * B + b0 + (tid >> 4)) * XU + u0 + (tid & 15)];
+
+    const int as = rank / NQ, aq = rank - as * NQ;
+    const int ab = b0 + as;
+    const int rows_per = (p.R + NQ - 1) / NQ;
+    const int ar0 = aq * rows_per;
+    const int an = min(p.R, ar0 + rows_per) - ar0;
+    const bf16_t* ai = p.att_exp + ((long long)ab * p.R + ar0) * XE;
+    const bf16_t* im = p.img + ((long long)ab * p.R + ar0) * XC;
+    float* pout = p.part + ((long long)ab * NQ + aq) * PST;
+    const int arow = min(r16, NB - 1);
+    const int nblk = an > 0 ? (an + XW * ATT_U - 1) / (XW * ATT_U) : 0;
+    const int anq = an > 0 ? an : 1;
+    const rsrc_t imq = make_rsrc(an > 0 ? im : p.img, (unsigned)anq * XC * 2u);
+    const rsrc_t aiq = make_rsrc(an > 0 ? ai : p.att_exp, (unsigned)anq * XE * 2u);
+    u32x4 xiA[ATT_U], xiB[ATT_U]; u32x2 xaA[ATT_U], xaB[ATT_U];
+    att_load<ATT_U>(xiA, xaA, imq, aiq, wave + XW * ATT_U * ((p.t0 & 1) ? nblk - 1 : 0), anq, lane);
+    att_load<ATT_U>(xiB, xaB, imq, aiq, wave + XW * ATT_U * ((p.t0 & 1) ? nblk - 2 : 1), anq, lane);
+
+    unsigned* ll_ah = p.sync + kXDecSyncBytes / 4 + kLLFwdAh / 4;
+    unsigned* ll_ht = p.sync + kXDecSyncBytes / 4 + kLLFwdHt / 4;
+    unsigned* ll_o = p.sync + kXDecSyncBytes / 4 + kLLFwdO / 4;
+    unsigned* ll_am = p.sync + kXDecBlockBytes / 4 + kXDecSyncBytes / 4;      // arg-max words [B][32 workgroups]: block 1's hand-over area (zeroed by the launcher)
+    const rsrc_t rll_ah = make_rsrc(ll_ah, (unsigned)B * XE * 8u);
+    const rsrc_t rll_ht = make_rsrc(ll_ht, (unsigned)B * 256u * 8u);
+    const rsrc_t rll_o = make_rsrc(ll_o, (unsigned)B * 256u * 8u);
+    const rsrc_t rll_am = make_rsrc(ll_am, (unsigned)B * 32u * 8u);
+    unsigned ph = 0;
+    for (int t = 0; t <= T; ++t) {
+        const int tg = p.t0 + t;                                 // global step index of the step this iteration runs
+        const long long sp = (long long)(tg & 1) * B, sn = (long long)((tg + 1) & 1) * B;
+        // =========================== boundary (logits, arg-max of step t - 1) + P1: LSTM cell ===========================
+        {
+            const rsrc_t rp = make_rsrc(p.recb + sp * p.RECB, (unsigned)B * p.RECB * 2u);
+            u32x4 a[4];
+            if (t > 0) {
+#pragma unroll
+                for (int ks = 2; ks < 4; ++ks) a[ks] = l2_load16(rp, (unsigned)(((b0 + arow) * p.RECB + P1K(ks) + g4 * 8) * 2));
+                u32x4 w[4];
+                unsigned off[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((b0 + arow) * 256 + ((P1K(j >> 1) + g4 * 8) >> 1)) * 8 + (j & 1) * 16);
+                ll_wait<4>(w, rll_o, off, (unsigned)t, err, &s_dead);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[ks] = u32x4{w[2 * ks][0], w[2 * ks][2], w[2 * ks + 1][0], w[2 * ks + 1][2]};
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rp, (unsigned)(((b0 + arow) * p.RECB + P1K(ks) + g4 * 8) * 2));
+            }
+            v4f acc[4], accl = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (t > 0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) accl = mfma16(a[ks], wyos[wave][ks][lane], accl);
+            }
+            if (t < T) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc[0] = mfma16(a[ks], wrt0[ks], acc[0]);
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) acc[q] = mfma16(a[ks], wl[((q - 1) * 4 + ks) * 64], acc[q]);
+                }
+            }
+            if (g4 * 4 < NB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[wave][g4 * 4 + i][q * 16 + r16] = acc[q][i];
+                    redl[wave][g4 * 4 + i][r16] = accl[i];
+                }
+            }
+            __syncthreads();
+            const int erow = tid >> 4, eu = tid & 15;
+            if (t > 0) {
+                // logits of this workgroup's 16 vocabulary columns, rows 0 .. NB-1; arg-max inside the 16 lanes of a row (ties: the lower index)
+                if (tid < NB * 16) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < XW; ++w) v += redl[w][erow][eu];
+                    int vi = v0 + eu;
+                    if (vi >= p.V) v = -3.0e38f;
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(vi, o);
+                        if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+                    }
+                    if (eu == 0) { const u32x2 wv = {__float_as_uint(v), ((unsigned)t << 16) | (unsigned)vi}; *reinterpret_cast<u32x2*>(ll_am + ((b0 + erow) * 32 + rank) * 2) = wv; }
+                }
+                // every workgroup gathers the 32 candidates of each of its chain's rows (thread = (row, candidate)) and reduces them
+                if (tid < NB * 32) {
+                    const int row = tid >> 5, cr = tid & 31;
+                    const unsigned off = (unsigned)(((b0 + row) * 32 + cr) * 8);
+                    float v = -3.0e38f; int vi = 0x7fffffff;
+                    const unsigned long long c0 = wall_clock64();
+                    for (;;) {
+                        const u32x2 wv = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rll_am, (int)off, 0, 16));
+                        const bool ok = (wv[1] >> 16) == (unsigned)t;
+                        if (ok) { v = __uint_as_float(wv[0]); vi = (int)(wv[1] & 0xffffu); }
+                        if (__ballot(!ok) == 0ull) break;
+                        if (s_dead || wall_clock64() - c0 > 20000000ull) {
+                            if ((tid & 63) == 0) { s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 4u; }
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(vi, o);
+                        if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+                    }
+                    if (cr == 0) {
+                        if (vi >= p.V) vi = 0;
+                        ids_l[row] = vi;
+                        if (rank == 0) {                          // one workgroup per chain publishes: ids, finished flags, the unfinished count of the step
+                            const int bb = b0 + row;
+                            p.ids_out[(long long)bb * p.max_steps + (tg - 1)] = vi;
+                            p.ids_step[bb] = vi;
+                            const int fo = p.finished[bb] | (vi == p.id_end ? 1 : 0);
+                            p.finished[bb] = fo;
+                            if (!fo) atomicAdd(p.unfinished + (t - 1), 1);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (t == T) break;
+            if (tid < NB * 16) {
+                // x-part of the pre-activation: the table row of the token fed at this step (the start token at step 0 of the decode)
+                const int bb = b0 + erow, u = u0 + eu;
+                const int id = tg == 0 ? p.V : (t == 0 ? p.ids_step[bb] : ids_l[erow]);
+                const float* zr = p.tx + (long long)id * 4 * XU + u;
+                float g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = zr[q * XU];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float z = g[q];
+#pragma unroll
+                    for (int w = 0; w < XW; ++w) z += red[w][erow][q * 16 + eu];
+                    g[q] = (q == 1) ? tanh_x(z) : sigm_x(q == 2 ? z + 1.0f : z);
+                }
+                const float c = g[2] * cst[erow][eu] + g[0] * g[1];
+                const float h = g[3] * tanh_x(c);
+                cst[erow][eu] = c;
+                p.cs[(sn + bb) * XU + u] = c;
+                float* rr = p.rec + (sn + bb) * p.REC;
+                bf16_t* rb = p.recb + (sn + bb) * p.RECB;
+                rr[OFF_H + u] = h; rr[OFF_HT + u] = h;
+                const bf16_t htb = f2bf(h);
+                rb[OFF_H + u] = htb; rb[OFF_HT + u] = htb;
+                const unsigned mine = (unsigned)htb, other = (unsigned)__shfl_xor((int)mine, 1);
+                if (!(eu & 1)) { const u32x2 wv = {mine | (other << 16), (unsigned)(t + 1)}; *reinterpret_cast<u32x2*>(ll_ht + ((bb * 256 + (u >> 1)) * 2)) = wv; }
+            }
+        }
+        __syncthreads();
+        // =========================== P2: att_h = h~ W ===========================
+        const rsrc_t rn = make_rsrc(p.recb + sn * p.RECB, (unsigned)B * p.RECB * 2u);
+        {
+            u32x4 a[2];
+            u32x4 w[4];
+            unsigned off[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((b0 + arow) * 256 + ((wave * 64 + (j >> 1) * 32 + g4 * 8) >> 1)) * 8 + (j & 1) * 16);
+            ll_wait<4>(w, rll_ht, off, (unsigned)(t + 1), err, &s_dead);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[ks] = u32x4{w[2 * ks][0], w[2 * ks][2], w[2 * ks + 1][0], w[2 * ks + 1][2]};
+            v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc = mfma16(a[ks], wahs[wave][ks][lane], acc);
+            if (g4 * 4 < NB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+            }
+            __syncthreads();
+            if (tid < NB * 8) {
+                const int row = tid >> 3, e = tid & 7;
+                float v = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < XW; ++w2) v += red[w2][row][e];
+                const u32x2 wv = {__float_as_uint(v), (unsigned)(t + 1)};
+                *reinterpret_cast<u32x2*>(ll_ah + ((b0 + row) * XE + e0 + e) * 2) = wv;
+            }
+        }
+        // =========================== P3: attention chunk ===========================
+        {
+            u32x4 aw[2];
+            { const unsigned off[2] = {(unsigned)((ab * XE + lane * 4) * 8), (unsigned)((ab * XE + lane * 4) * 8 + 16)}; ll_wait<2>(aw, rll_ah, off, (unsigned)(t + 1), err, &s_dead); }
+            float ah[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ah[j] = __builtin_amdgcn_exp2f(fminf(fmaxf(__uint_as_float(aw[j >> 1][(j & 1) * 2]) * 2.8853900817779268f, -60.f), 60.f));
+            const int c0 = lane * 8;
+            float m = -3.0e38f, l = 0.f, acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            const int rev = tg & 1;
+#define XBASE(i, rv) (wave + XW * ATT_U * ((rv) ? nblk - 1 - (i) : (i)))
+            for (int it = 0; it < nblk; it += 2) {
+                att_block<ATT_U, true>(xiA, xaA, XBASE(it, rev), an, ah, bt, m, l, acc, nullptr, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                att_load<ATT_U>(xiA, xaA, imq, aiq, (it + 2 < nblk) ? XBASE(it + 2, rev) : XBASE(0, rev ^ 1), anq, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < nblk) {
+                    att_block<ATT_U, true>(xiB, xaB, XBASE(it + 1, rev), an, ah, bt, m, l, acc, nullptr, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    att_load<ATT_U>(xiB, xaB, imq, aiq, (it + 3 < nblk) ? XBASE(it + 3, rev) : XBASE(1, rev ^ 1), anq, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#undef XBASE
+            if (lane == 0) wred[wave] = m;
+            __syncthreads();
+            float mc = wred[0];
+#pragma unroll
+            for (int w = 1; w < XW; ++w) mc = fmaxf(mc, wred[w]);
+            const float sw = (l > 0.f) ? __expf(m - mc) : 0.f;
+            if (lane == 0) wred[XW + wave] = l * sw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e] * sw;
+            __syncthreads();
+            if (tid == 0) {
+                float lt = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) lt += wred[XW + w];
+                pout[XC] = mc; pout[XC + 1] = lt;
+            }
+            {
+                float tsum = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) tsum += redc[w][tid];
+                pout[tid] = tsum;
+            }
+        }
+        xbar(xsync, rank, ++ph, err, &s_dead);
+        // =========================== P4: merge the chunks; ctx; o projection ===========================
+        {
+            const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * PST, (unsigned)(NB * NQ * PST) * 4u);
+            u32x4 a[4];
+            if (wave < 4) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rn, (unsigned)(((b0 + arow) * p.RECB + OFF_HT + wave * 128 + ks * 32 + g4 * 8) * 2));
+            }
+            constexpr int SPG = NB >= 4 ? NB / 4 : 1, NG = NB / SPG;
+            const int tg4 = tid >> 7, c4 = (tid & 127) * 4;
+            constexpr int QG = NB >= 4 ? 2 : 4;
+            u32x4 pc[SPG][QG];
+            if (tg4 < NG) {
+#pragma unroll
+                for (int si = 0; si < SPG; ++si)
+#pragma unroll
+                    for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)((((tg4 * SPG + si) * NQ + q) * PST + c4) * 4));
+            }
+            if (tid < NB * NQ) {
+                const unsigned o = (unsigned)((tid * PST + XC) * 4);
+                (&stm[0][0])[tid] = l2_load4(rpart, o); (&stl[0][0])[tid] = l2_load4(rpart, o + 4);
+            }
+            __syncthreads();
+            if (tid < NB) {
+                float mm = -3.0e38f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) if (stl[tid][q] > 0.f) mm = fmaxf(mm, stm[tid][q]);
+                float ll = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { const float w = stl[tid][q] > 0.f ? __expf(stm[tid][q] - mm) : 0.f; wgt[tid][q] = w; ll += stl[tid][q] * w; }
+                const float inv = 1.0f / ll;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) wgt[tid][q] *= inv;
+            }
+            __syncthreads();
+            if (tg4 < NG) {
+#pragma unroll
+                for (int si = 0; si < SPG; ++si) {
+                    const int sidx = tg4 * SPG + si;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q0 = 0; q0 < NQ; q0 += QG) {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) {
+                            const float w = wgt[sidx][q0 + q];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(__uint_as_float(pc[si][q][e]), w, v[e]);
+                        }
+                        if (q0 + QG < NQ) {
+#pragma unroll
+                            for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + q0 + QG + q) * PST + c4) * 4));
+                        }
+                    }
+                    const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(&actx[sidx][c4]) = vb;
+                    if ((c4 >> 4) == rank) {
+                        const f32x4 vf = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(p.rec + (sn + b0 + sidx) * p.REC + OFF_CTX + c4) = vf;
+                        *reinterpret_cast<u32x2*>(p.recb + (sn + b0 + sidx) * p.RECB + OFF_CTX + c4) = vb;
+                    }
+                }
+            }
+            __syncthreads();
+            if (wave >= 4) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const u32x4*>(&actx[arow][(wave - 4) * 128 + ks * 32 + g4 * 8]);
+            }
+            v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = mfma16(a[ks], wow[ks], acc);
+            if (g4 * 4 < NB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (NB >= 4 || i < NB) red[wave][g4 * 4 + i][r16] = acc[i];
+            }
+            __syncthreads();
+            if (tid < NB * 16) {
+                const int row = tid >> 4, cc = tid & 15;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) v += red[w][row][cc];
+                const int bb = b0 + row, n = o0 + cc;
+                v = tanh_x(v);
+                p.rec[(sn + bb) * p.REC + n] = v;
+                const bf16_t vb = f2bf(v);
+                p.recb[(sn + bb) * p.RECB + n] = vb;
+                const unsigned mine = (unsigned)vb, other = (unsigned)__shfl_xor((int)mine, 1);
+                if (!(cc & 1)) { const u32x2 wv = {mine | (other << 16), (unsigned)(t + 1)}; *reinterpret_cast<u32x2*>(ll_o + ((bb * 256 + (n >> 1)) * 2)) = wv; }
+            }
+        }
+        __syncthreads();
+    }
+#undef P1K
+}
+
+template <int NB>
+int launch_dec_nb(const XDecDec& p, hipStream_t st) {
+    constexpr int DYN = XW * 12 * 64 * 16;
+    static bool attr_done = false;
+    if (!attr_done) { HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(xdec_dec_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, DYN)); attr_done = true; }
+    hipLaunchKernelGGL((xdec_dec_kernel<NB>), dim3(256), dim3(512), DYN, st, p);
     return (int)hipGetLastError();
 }
 
@@ -1128,6 +1528,32 @@ int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream
     default: rc = launch_nb<8>(p, att_u, st); break;
     }
     return rc;
+}
+int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_t st) {
+    static int on = -1;                                          // LXO_XDEC_DEC=0: greedy decode on the launch-per-step kernels (A/B); LXO_XDEC=0 switches every chain off
+    if (on < 0) { const char* e = getenv("LXO_XDEC_DEC"); const char* f = getenv("LXO_XDEC"); on = ((e && e[0] == '0') || (f && f[0] == '0')) ? 0 : 1; }
+    if (!on) return -2;
+    if (U != XU || O != XO || C != XC || E != XE) return -2;
+    if (p.B % 8 != 0 || p.B > 64 || p.nsteps < 1 || p.V < 1 || p.V > 512 || p.V >= 65536) return -2;      // 32 workgroups x 16 vocabulary columns
+    const int nb = p.B / 8;
+    if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return -2;
+    const int nq = 32 / nb, rows_per = (p.R + nq - 1) / nq;
+    if (rows_per < 1) return -2;
+    if ((long long)p.B * p.RECB * 2 >= (1LL << 31) || p.ldrt % 8 || p.ldah % 8 || p.ldow % 8 || p.ldyo % 8 || p.RECB % 8 || !p.att_exp) return -2;
+    static int dev_ok = -1;
+    if (dev_ok < 0) {
+        int dev = 0; hipDeviceProp_t pr;
+        dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
+    }
+    if (!dev_ok) return -2;
+    HIPRC(hipMemsetAsync(p.sync, 0, kXDecBlockBytes, st));
+    HIPRC(hipMemsetAsync(p.sync + kXDecBlockBytes / 4 + kXDecSyncBytes / 4, 0, (size_t)p.B * 32 * 8, st));      // the arg-max words (block 1's hand-over area)
+    switch (nb) {
+    case 1: return launch_dec_nb<1>(p, st);
+    case 2: return launch_dec_nb<2>(p, st);
+    case 4: return launch_dec_nb<4>(p, st);
+    default: return launch_dec_nb<8>(p, st);
+    }
 }
 static thread_local unsigned long long* g_xdbg_b = nullptr;
 extern "C" int lxo_xdec_debug_bwd(unsigned long long* buf) { g_xdbg_b = buf; return 0; }
