@@ -737,8 +737,11 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
         x.ids_step = ids_step; x.ids_out = ids_out; x.finished = finished;
         x.B = B; x.R = P.R; x.REC = P.REC; x.RECB = P.RECB; x.V = P.s.V; x.id_end = id_end; x.max_steps = ms;
         x.t0 = 0; x.nsteps = 1; x.unfinished = flags;
-        static int chunk_steps = -1;
-        if (chunk_steps < 0) { const char* e = getenv("LXO_XDEC_DEC_CHUNK"); chunk_steps = (e && atoi(e) > 0) ? atoi(e) : 16; }
+        x.stop = ids_step + B;                            // one word behind the fed-back ids (region "dec_ids" holds B x max_steps ints)
+        HIPRC(hipMemsetAsync(x.stop, 0, sizeof(int), st));
+        HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC) + 8 * 64, 0, sizeof(unsigned), st));      // the error word: once per decode (the launcher leaves it alone)
+        int chunk_steps = 16;                             // steps per launch (LXO_XDEC_DEC_CHUNK: 1 .. 16; read per call so that a test can vary it)
+        { const char* e = getenv("LXO_XDEC_DEC_CHUNK"); if (e && atoi(e) > 0 && atoi(e) < 16) chunk_steps = atoi(e); }
         bool took = true;
         const int rc = decode_loop_chunked(max_iter, chunk_steps, flags, st, steps_out, [&](int first, int n, int* unfinished) -> int {
             XDecDec y = x; y.t0 = first; y.nsteps = n; y.unfinished = unfinished;
@@ -746,8 +749,17 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
             if (r == -2 && first == 0) { took = false; return -2; }
             return r;
         });
-        if (took) return rc;
-        HIPRC(hipStreamSynchronize(st));                  // (nothing was enqueued by the refused first chunk but its counter memset)
+        if (took) {
+            if (rc) return rc;
+            // the chain's error word (a hand-over that timed out: the ids are garbage).  The call has synchronised with the stream already.
+            unsigned errw = 0;
+            HIPRC(hipMemcpyAsync(&errw, P.ws<unsigned>(ws, W_XSYNC) + 8 * 64, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            HIPRC(hipStreamSynchronize(st));
+            if (errw == 0) return 0;
+            // fall back to the launch-per-step kernels: the initial state, the finished flags and the token table are rebuilt first
+            RC(attention_prepare(P, prm, wp, ws, 1, st));
+            if (fused_steps(P)) RC(mirror_oh(P, ws, 0, B, st));
+        } else HIPRC(hipStreamSynchronize(st));           // (nothing was enqueued by the refused first chunk but its counter memset)
         HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st));
     }
     RC(decode_loop(max_iter, flags, st, steps_out, [&](int time, int* unfinished) -> int {

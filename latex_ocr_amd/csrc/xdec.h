@@ -52,7 +52,10 @@ struct XDecDec {
     int* ids_step;                    // [B] in: the ids fed at step t0 (t0 > 0); out: the ids of the launch's last step
     int* ids_out;                     // [B][max_steps]
     int* finished;                    // [B] (0 / 1, sticky)
-    int* unfinished;                  // [nsteps] rows still unfinished after each step of this launch (zeroed by the caller)
+    int* unfinished;                  // [32] zeroed by the caller: [0 .. nsteps) rows still unfinished after each step of this launch; [16 .. 16 + nsteps) chains
+                                      // that have reported that step (8 = all).  nsteps <= 16
+    int* stop;                        // one word, zero at the start of the decode: set once every row of every chain has finished -- the chains of
+                                      // this launch stop within three steps of that point, later (speculative) launches return at once
     int B, R, REC, RECB, V, id_end, t0, nsteps, max_steps;
 };
 int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_t st);

@@ -691,8 +691,8 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
     __shared__ float cst[8][16];
     __shared__ float stm[NB][NQ], stl[NB][NQ], wgt[NB][NQ];
     __shared__ float wred[2 * XW];
-    __shared__ int ids_l[8];
-    __shared__ int s_rank, s_dead;
+    __shared__ int ids_l[8], unf_l[8];
+    __shared__ int s_rank, s_dead, s_stop;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g4 = lane >> 4;
@@ -701,14 +701,17 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
     xcc &= 7u;
     unsigned* xsync = p.sync + xcc * 64;
     unsigned* err = p.sync + 8 * 64;
-    if (tid == 0) { s_dead = 0; s_rank = (int)atomicAdd(xsync + 32, 1u); }
+    if (tid == 0) { s_dead = 0; s_stop = 0; s_rank = (int)atomicAdd(xsync + 32, 1u); }
     for (int i = tid; i < 8 * (XC + 8); i += 512) (&actx[0][0])[i] = 0;
     __syncthreads();
     const int rank = s_rank;
-    if (rank >= 32) { if (tid == 0) *reinterpret_cast<volatile unsigned*>(err) = 2u; return; }
+    if (rank >= 32) { if (tid == 0) { *reinterpret_cast<volatile unsigned*>(err) = 2u; *reinterpret_cast<volatile int*>(p.stop) = 1; } return; }
     const int B = p.B, T = p.nsteps;
     const int b0 = (int)xcc * NB;
     const int u0 = rank * 16, e0 = rank * 8, o0 = rank * 16, v0 = rank * 16;
+    // the decode is over (an earlier launch saw every row finished): a speculative launch has nothing to do.  Every workgroup reads the same
+    // word, written before this kernel started.
+    if (*reinterpret_cast<volatile const int*>(p.stop) != 0) return;
 
 #define P1K(ks) ((ks) < 2 ? wave * 64 + (ks) * 32 : XO + wave * 64 + ((ks) - 2) * 32)
     u32x4 wrt0[4], wow[4];
@@ -763,6 +766,10 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
     const rsrc_t rll_o = make_rsrc(ll_o, (unsigned)B * 256u * 8u);
     const rsrc_t rll_am = make_rsrc(ll_am, (unsigned)B * 32u * 8u);
     unsigned ph = 0;
+    // early exit (dynamic_decode.py:38-51 stops once every row has finished): workgroup 0 of a chain looks, one boundary late and without
+    // waiting, at how many chains have reported a step and how many rows it left unfinished, and raises a STOP bit in its arg-max word --
+    // the one word every workgroup of the chain reads, so the whole chain leaves the loop at the same boundary
+    int pr_done = 0, pr_unf = 1;
     for (int t = 0; t <= T; ++t) {
         const int tg = p.t0 + t;                                 // global step index of the step this iteration runs
         const long long sp = (long long)(tg & 1) * B, sn = (long long)((tg + 1) & 1) * B;
@@ -822,7 +829,9 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                         const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(vi, o);
                         if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
                     }
-                    if (eu == 0) { const u32x2 wv = {__float_as_uint(v), ((unsigned)t << 16) | (unsigned)vi}; *reinterpret_cast<u32x2*>(ll_am + ((b0 + erow) * 32 + rank) * 2) = wv; }
+                    // (workgroup 0, row 0 carries the chain's STOP bit: what thread 0 probed at the previous boundary)
+                    const unsigned stopbit = (rank == 0 && erow == 0 && pr_done == 8 && pr_unf == 0) ? 0x8000u : 0u;
+                    if (eu == 0) { const u32x2 wv = {__float_as_uint(v), ((unsigned)t << 16) | stopbit | (unsigned)vi}; *reinterpret_cast<u32x2*>(ll_am + ((b0 + erow) * 32 + rank) * 2) = wv; }
                 }
                 // every workgroup gathers the 32 candidates of each of its chain's rows (thread = (row, candidate)) and reduces them
                 if (tid < NB * 32) {
@@ -833,13 +842,15 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                     for (;;) {
                         const u32x2 wv = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rll_am, (int)off, 0, 16));
                         const bool ok = (wv[1] >> 16) == (unsigned)t;
-                        if (ok) { v = __uint_as_float(wv[0]); vi = (int)(wv[1] & 0xffffu); }
+                        if (ok) { v = __uint_as_float(wv[0]); vi = (int)(wv[1] & 0xffffu); }      // (bit 15 of workgroup 0's row-0 word: STOP)
                         if (__ballot(!ok) == 0ull) break;
                         if (s_dead || wall_clock64() - c0 > 20000000ull) {
                             if ((tid & 63) == 0) { s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 4u; }
                             break;
                         }
                     }
+                    if (tid == 0) s_stop = (vi >> 15) & 1;               // thread 0 holds workgroup 0's row-0 word: the chain's STOP bit
+                    vi &= 0x7fff;
 #pragma unroll
                     for (int o = 16; o > 0; o >>= 1) {
                         const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(vi, o);
@@ -848,17 +859,34 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                     if (cr == 0) {
                         if (vi >= p.V) vi = 0;
                         ids_l[row] = vi;
-                        if (rank == 0) {                          // one workgroup per chain publishes: ids, finished flags, the unfinished count of the step
+                        if (rank == 0) {                          // one workgroup per chain publishes: ids, finished flags
                             const int bb = b0 + row;
                             p.ids_out[(long long)bb * p.max_steps + (tg - 1)] = vi;
                             p.ids_step[bb] = vi;
                             const int fo = p.finished[bb] | (vi == p.id_end ? 1 : 0);
                             p.finished[bb] = fo;
-                            if (!fo) atomicAdd(p.unfinished + (t - 1), 1);
+                            unf_l[row] = fo ? 0 : 1;
                         }
                     }
                 }
                 __syncthreads();
+                if (rank == 0 && tid == 0) {
+                    // the chain's unfinished rows of step t - 1, THEN its report (the first atomic returns: it has been performed when the
+                    // second is issued); then the probe of the step before, consumed at the next boundary
+                    int cnt = 0;
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) cnt += unf_l[r];
+                    const int before = atomicAdd(p.unfinished + (t - 1), cnt);
+                    if (before >= 0) atomicAdd(p.unfinished + 16 + (t - 1), 1);
+                    if (t >= 2) {
+                        pr_done = __hip_atomic_load(p.unfinished + 16 + (t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pr_unf = __hip_atomic_load(p.unfinished + (t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (s_stop) {
+                    if (rank == 0 && tid == 0) *reinterpret_cast<volatile int*>(p.stop) = 1;
+                    break;
+                }
             }
             if (t == T) break;
             if (tid < NB * 16) {
@@ -968,6 +996,9 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
             }
         }
         xbar(xsync, rank, ++ph, err, &s_dead);
+#ifdef LXO_TEST_DEC_FAULT          // diagnostic build only (never in liblxo.so): chain 3 declares itself broken in step 21 -- profiles/r05_dec_fault_fallback.txt
+        if (tg == 21 && xcc == 3u && tid == 0) { s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 9u; }
+#endif
         // =========================== P4: merge the chunks; ctx; o projection ===========================
         {
             const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * PST, (unsigned)(NB * NQ * PST) * 4u);
@@ -1060,6 +1091,9 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
         __syncthreads();
     }
 #undef P1K
+    // a hand-over that timed out: the ids are garbage from here on; later launches of this decode return at once, the host reads the error word
+    // (which the launcher leaves alone: it is cleared once per decode) and repeats the decode on the launch-per-step kernels
+    if (tid == 0 && s_dead) *reinterpret_cast<volatile int*>(p.stop) = 1;
 }
 
 template <int NB>
@@ -1534,7 +1568,7 @@ int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_
     if (on < 0) { const char* e = getenv("LXO_XDEC_DEC"); const char* f = getenv("LXO_XDEC"); on = ((e && e[0] == '0') || (f && f[0] == '0')) ? 0 : 1; }
     if (!on) return -2;
     if (U != XU || O != XO || C != XC || E != XE) return -2;
-    if (p.B % 8 != 0 || p.B > 64 || p.nsteps < 1 || p.V < 1 || p.V > 512 || p.V >= 65536) return -2;      // 32 workgroups x 16 vocabulary columns
+    if (p.B % 8 != 0 || p.B > 64 || p.nsteps < 1 || p.nsteps > 16 || p.V < 1 || p.V > 512 || !p.stop) return -2;      // 32 workgroups x 16 vocabulary columns; 16 report counters per launch
     const int nb = p.B / 8;
     if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return -2;
     const int nq = 32 / nb, rows_per = (p.R + nq - 1) / nq;
@@ -1546,7 +1580,9 @@ int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_
         dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
     }
     if (!dev_ok) return -2;
-    HIPRC(hipMemsetAsync(p.sync, 0, kXDecBlockBytes, st));
+    // tickets / flags and the hand-over area, but NOT the error word (int 512): an error of an earlier launch of this decode stays visible
+    HIPRC(hipMemsetAsync(p.sync, 0, 8 * 64 * 4, st));
+    HIPRC(hipMemsetAsync(p.sync + 8 * 64 + 1, 0, kXDecBlockBytes - (8 * 64 + 1) * 4, st));
     HIPRC(hipMemsetAsync(p.sync + kXDecBlockBytes / 4 + kXDecSyncBytes / 4, 0, (size_t)p.B * 32 * 8, st));      // the arg-max words (block 1's hand-over area)
     switch (nb) {
     case 1: return launch_dec_nb<1>(p, st);

@@ -30,6 +30,7 @@ for B in (64, 32, 16, 8):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     out["b%d" % B] = ids
+    print("chain_status (tickets taken, error word) after the last decode:", eng.chain_status())
     print("B=%d: %d steps, %.2f ms per batch (%.1f us per step incl. the encoder); distinct ids %d; first row %s" % (B, ids.shape[1], dt * 1e3, dt * 1e6 / ids.shape[1], len(np.unique(ids)), ids[0, :8]))
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez("gpurun_out/dec_ids_%s.npz" % tag, **out)
