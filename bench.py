@@ -171,7 +171,7 @@ def roofline_from_records(recs, family, label, bound, peak, unit):
     return {"kernel": label, "bound": bound, "achieved": round(work / secs / scale, 2), "peak": peak / scale, "unit": unit,
             "frac": round(work / secs / peak, 4), "traffic": None, "launches": len(sel),
             "work_per_launch": work / len(sel), "avg_launch_us": round(secs / len(sel) * 1e6, 2),
-            "source": "HIP events around each launch inside one real training step (lxo_timing_*)",
+            "source": "HIP events around each launch inside one real training step (lxo_timing_*); that step keeps every launch on ONE stream -- in the timed steps the weight-gradient launches run on a second stream beside the data-gradient launches (LXO_ENC_OVERLAP, default on), which would put two kernels inside one bracket",
             "per_launch": {k: {"n": v[0], "us": round(v[2] / v[0] * 1e6, 2), "rate": round(v[1] / v[2] / scale, 1)} for k, v in sorted(per.items())}}
 
 
@@ -664,6 +664,9 @@ def main():
                     r["note"] = ("achieved = algorithmic bytes / stream time; %.0f %% of them are L2 hits (traffic < work_per_launch): "
                                  "the memory system delivered hbm_GBps_from_traffic" % (100.0 * (1.0 - r["traffic"] / r["work_per_launch"])))
             out["ms_per_step_by_phase"] = phases
+            out["ms_per_step_by_phase_note"] = ("one instrumented step with every launch on one stream; the timed steps overlap the weight-gradient "
+                                                "launches (encoder, and the decoder's deferred ones) with the data-gradient path on a second stream, "
+                                                "so the phases sum to more than ms_per_step")
             if world == 1:
                 # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still
                 # inside their formula (same loss and gradients; the reference and `value` above run every padded step)

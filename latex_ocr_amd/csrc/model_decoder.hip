@@ -301,6 +301,13 @@ int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* len
     return 0;
 }
 
+// The weight-gradient side stream of the encoder backward (model_encoder.hip: lxo_set_encoder_side_stream) also takes the decoder's
+// deferred all-step weight gradients (round 5): behind the backward chain the critical path is init states -> d_att_img (bound by the
+// transcendental rate) -> d_img -> conv6; the four dense dW GEMMs, d_z's column sum, the embedding gradient and dW_att_img feed nothing
+// downstream and run beside it.  The call joins the two streams before it returns (its caller reduces / applies the gradients).
+hipStream_t lxo_impl_encoder_side_stream();
+static thread_local hipEvent_t g_dbw_fork = nullptr, g_dbw_fork2 = nullptr, g_dbw_join = nullptr, g_dbw_init = nullptr;
+
 int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads,
                                const int* active, int parts, hipStream_t st) {
     const int B = P.s.B, T = P.s.T, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
@@ -485,23 +492,56 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_k_slab_reduce(view(sb4, 4 * U, hb, P.XH), dxh + r0 * P.XH, P.XH, hb, P.XH, st));
     }
     // ---- deferred weight gradients over all steps ----
+    hipStream_t side = (P.bf && fused && !P.det() && !lxo_timer_on()) ? lxo_impl_encoder_side_stream() : nullptr;
+    if (side) {
+        if (!g_dbw_fork) {
+            HIPRC(hipEventCreateWithFlags(&g_dbw_fork, hipEventDisableTiming));
+            HIPRC(hipEventCreateWithFlags(&g_dbw_fork2, hipEventDisableTiming));
+            HIPRC(hipEventCreateWithFlags(&g_dbw_join, hipEventDisableTiming));
+            HIPRC(hipEventCreateWithFlags(&g_dbw_init, hipEventDisableTiming));
+        }
+        HIPRC(hipEventRecord(g_dbw_fork, st));
+        HIPRC(hipStreamWaitEvent(side, g_dbw_fork, 0));
+    }
+    hipStream_t sd = side ? side : st;
+    // ---- initial states (first on the side stream: d_img below needs d_mean) ----
+    float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
+    const int W3 = 2 * U + O;
+    { const Slabs one = {dxh, 1, 0, P.XH}; RC(lxo_k_init_bwd(dcc, one, cs, rec, P.REC, dpre, B, U, O, sd)); }
+    RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, sd));
+    RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, sd));
+    RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, sd));
+    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, det, sd));
+    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, det, sd));
+    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, det, sd));
+    const char* wi = (const char*)P.pk(wp, K_INIT);
+    if (fused_steps(P)) {
+        RC(rs_dense(P, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, false, false, sd));
+        RC(rs_dense(P, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, false, true, sd));
+        RC(rs_dense(P, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, false, true, sd));
+    } else {
+    RC(nt(P, true, true, true, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, 0, false, sd));
+    RC(nt(P, true, true, true, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, 0, true, sd));
+    RC(nt(P, true, true, true, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, 0, true, sd));
+    }
+    if (side) HIPRC(hipEventRecord(g_dbw_init, sd));
     if (P.bf && fused) {
         // the bf16 mirrors the step kernels left (record, g_t, d_z_t) are the operands: half the bytes of the f32 originals, and
         // these reductions over T*B rows are bound by operand re-reads (every 128 x 128 tile walks all rows of both operands)
         const bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         const bf16_t* gb = P.ws<bf16_t>(ws, W_GB); const bf16_t* dzb = P.ws<bf16_t>(ws, W_DZB);
-        RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, st, det));      // d[o_W_h; o_W_c]
-        if (bwd_chain) RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, P.ws<bf16_t>(ws, W_DATTHB), E, gw(P_ATT_H), E, TB, U, E, st, det));      // dW_att_h
-        else RC(tn(P, false, true, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, datth, E, gw(P_ATT_H), E, TB, U, E, st));
-        RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st, det));           // dK rows 0..D
-        RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st, det));     // dK rows D..
+        RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, sd, det));      // d[o_W_h; o_W_c]
+        if (bwd_chain) RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, P.ws<bf16_t>(ws, W_DATTHB), E, gw(P_ATT_H), E, TB, U, E, sd, det));      // dW_att_h
+        else RC(tn(P, false, true, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, datth, E, gw(P_ATT_H), E, TB, U, E, sd));
+        RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, sd, det));           // dK rows 0..D
+        RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, sd, det));     // dK rows D..
     } else {
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, datth, E, gw(P_ATT_H), E, TB, U, E, st));      // dW_att_h
     RC(tn(P, false, true, P.ws<void>(ws, W_EMB_IN), P.Dp, dz, 4 * U, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st)); // dK rows 0..D
     RC(tn(P, true, true, rec, P.REC, dz, 4 * U, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st)); // dK rows D..
     }
-    RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, det, st));
+    RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, det, sd));
     // embeddings
     float* demb = P.ws<float>(ws, W_DEMB);
     if (fused) {   // d_emb = d_z K[0:D]^T over all T*B rows: a tall GEMM on the step kernel (505 workgroups; the bf16 mirror of d_z halves its bytes)
@@ -509,30 +549,10 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         e.M = TB; e.N = D; e.K = 4 * U; e.U = U; e.O = O; e.zx_row = -1; e.epi = RS_PLAIN; e.dr.inv_keep = 1.f;
         e.A = P.bf ? (const void*)P.ws<bf16_t>(ws, W_DZB) : (const void*)dz; e.lda = P.bf ? P.DZBP : 4 * U;
         e.W = P.pk(wp, K_LSTM); e.ldw = P.ldK; e.out = demb; e.ldo = D;
-        RC(lxo_launch_rstep(P.s.dtype, P.bf, e, st));
+        RC(lxo_launch_rstep(P.s.dtype, P.bf, e, sd));
     } else
     RC(nt(P, true, true, true, dz, 4 * U, P.pk(wp, K_LSTM), P.ldK, demb, D, TB, D, 4 * U, nullptr, 0, false, st));
-    RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, P.det() ? 1 : 0, st));
-    // ---- initial states ----
-    float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
-    const int W3 = 2 * U + O;
-    { const Slabs one = {dxh, 1, 0, P.XH}; RC(lxo_k_init_bwd(dcc, one, cs, rec, P.REC, dpre, B, U, O, st)); }
-    RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, st));
-    RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, st));
-    RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, st));
-    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, det, st));
-    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, det, st));
-    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, det, st));
-    const char* wi = (const char*)P.pk(wp, K_INIT);
-    if (fused_steps(P)) {
-        RC(rs_dense(P, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, false, false, st));
-        RC(rs_dense(P, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, false, true, st));
-        RC(rs_dense(P, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, false, true, st));
-    } else {
-    RC(nt(P, true, true, true, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, 0, false, st));
-    RC(nt(P, true, true, true, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, 0, true, st));
-    RC(nt(P, true, true, true, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, 0, true, st));
-    }
+    RC(lxo_k_embed_scatter(demb, formula, gw(P_EMB), gw(P_START), B, T, D, V, P.det() ? 1 : 0, sd));
     // ---- d_img = sum_t alpha_t (x) d_ctx_t  (batched over samples)  + d_mean / R + d_att_img W_att_img^T ----
     float* dimg = P.ws<float>(ws, W_DIMG);
     if (P.dimg_masked()) {
@@ -540,6 +560,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         // in its epilogue (dimg.hip): region "d_img" receives d_y6 in the compute dtype, lxo_encoder_bwd skips its mask pass
         RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
                           T, B, P.R, P.Rp, E, det, st));
+        if (side) { HIPRC(hipEventRecord(g_dbw_fork2, st)); HIPRC(hipStreamWaitEvent(st, g_dbw_init, 0)); }      // d_mean comes from the side stream
         DimgArgs a; memset(&a, 0, sizeof(a));
         a.alpha = alpha; a.ld_alpha = (long long)B * P.Rp; a.Rp = P.Rp;
         a.dctx = dhc + U; a.ld_dctx = (long long)B * P.HC; a.HC = P.HC;
@@ -559,9 +580,15 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_k_add_mean_grad(dimg, dmean, B, P.R, C, st));
         RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
                           T, B, P.R, P.Rp, E, det, st));
+        if (side) { HIPRC(hipEventRecord(g_dbw_fork2, st)); HIPRC(hipStreamWaitEvent(st, g_dbw_init, 0)); }
         RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     }
-    RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, st, det));
+    if (side) HIPRC(hipStreamWaitEvent(side, g_dbw_fork2, 0));      // dW_att_img needs d_att_img, nothing needs dW_att_img
+    RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, sd, det));
+    if (side) {
+        HIPRC(hipEventRecord(g_dbw_join, side));
+        HIPRC(hipStreamWaitEvent(st, g_dbw_join, 0));
+    }
     // the backward chain's error word -> the probe element (as for the forward chain above; y_W_o's bucket is reduced behind this call
     // where the backward chain runs, Engine.backward)
     if (bwd_chain) RC(lxo_k_chain_poison(nullptr, P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4 + 8 * 64, grads + P.ptotal - 1, st));

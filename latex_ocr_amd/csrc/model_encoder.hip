@@ -180,14 +180,17 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
     return 0;
 }
 
-// ---- optional second stream for the weight gradients -------------------------------------------------
+// ---- second stream for the weight gradients ----------------------------------------------------------
 // Per layer, conv_wgrad and conv_dgrad both read d_y and are otherwise independent.  With a side stream bound
-// (lxo_set_encoder_side_stream) every conv_wgrad goes there, so that the unoverlapped prologue / epilogue
-// phases of one kernel family fall under the MFMA phases of the other and the memory-bound pool-backward
-// kernels run beside a weight-gradient kernel.  Three gradient buffers rotate (table below) so that the
+// (lxo_set_encoder_side_stream; the Python engine binds one by default since round 5) every conv_wgrad goes there, so that
+// the unoverlapped prologue / epilogue phases of one kernel family fall under the MFMA phases of the other and the
+// memory-bound pool-backward kernels run beside a weight-gradient kernel (round 5, with the decoder in two persistent
+// launches: 7.99 -> 7.87 ms per step; round 3 measured the same switch SLOWER because the cross-stream waits delayed the
+// ~1000 dependent launches of the launch-per-step decoder).  Three gradient buffers rotate (table below) so that the
 // buffer a weight gradient reads is not rewritten for a whole layer; one event per buffer orders the rewrite.
 static thread_local hipStream_t g_enc_side = nullptr;
 static thread_local hipEvent_t g_ev_x = nullptr, g_ev_free[3] = {nullptr, nullptr, nullptr}, g_ev_done = nullptr;
+hipStream_t lxo_impl_encoder_side_stream() { return g_enc_side; }
 int lxo_impl_set_encoder_side_stream(hipStream_t s) {
     g_enc_side = s;
     if (s && !g_ev_x) {
@@ -218,7 +221,9 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         if (!P.det()) return 0;
         return lxo_k_colsum_det(x, P.bf ? 1 : 0, Cc, gw(pid), rows, Cc, det, st);
     };
-    hipStream_t side = g_enc_side;
+    // no second stream in the deterministic modes (the weight gradients' slabs and the main stream's ordered slots share one scratch
+    // region) and while per-launch brackets are recorded (bench.py's instrumented step times every launch alone)
+    hipStream_t side = (P.det() || lxo_timer_on()) ? nullptr : g_enc_side;
     bool pending[3] = {false, false, false};
     // main is about to WRITE buffer i: wait for the weight gradient that still reads it
     auto acquire = [&](int i) -> int {

@@ -7,6 +7,7 @@
 // -> slot (>= 0) when timing is enabled, -1 otherwise.  family / name must be string literals.
 int lxo_timer_begin(const char* family, const char* name, double work, hipStream_t st);
 void lxo_timer_end(int slot, hipStream_t st);
+bool lxo_timer_on();          // per-launch brackets are being recorded on this host thread (launches are then kept on ONE stream)
 
 struct LxoTimed {
     int slot; hipStream_t st;

@@ -34,6 +34,8 @@ void lxo_timer_end(int slot, hipStream_t st) {
     if (hipEventRecord(R.slots[slot].e1, st) == hipSuccess) R.slots[slot].ended = true;
 }
 
+bool lxo_timer_on() { return g_reg.on; }
+
 extern "C" int lxo_timing_enable(int on) {
     g_reg.on = on != 0;
     if (on) g_reg.used = 0;

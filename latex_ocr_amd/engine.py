@@ -107,11 +107,12 @@ class Engine(object):
         self.side_stream = None
         if self.device.type == "cuda" and os.environ.get("LXO_DUAL_STREAM", "0") == "1":
             self.side_stream = torch.cuda.Stream(self.device)
-        # optional second stream for the encoder's weight-gradient kernels (LXO_ENC_OVERLAP=1).  Measured slower in
-        # round 1 (15.9 vs 15.5 ms/step: both kernel families want a whole CU's LDS, so they only take CUs from each
-        # other), so it is off by default.
+        # second stream for the encoder's weight-gradient kernels (LXO_ENC_OVERLAP=0 switches it off): their prologues / epilogues and
+        # the memory-bound pool-backward kernels overlap the data-gradient kernels.  Slower in rounds 1-3 (the cross-stream waits delayed
+        # the launch-per-step decoder); with the decoder in two persistent launches it pays: 7.99 -> 7.87 ms per step (round 5).  The
+        # library ignores it in the deterministic modes and while bench.py records per-launch times (model_encoder.hip).
         self.enc_side = None
-        if self.device.type == "cuda" and os.environ.get("LXO_ENC_OVERLAP", "0") == "1":
+        if self.device.type == "cuda" and os.environ.get("LXO_ENC_OVERLAP", "1") != "0":
             self.enc_side = torch.cuda.Stream(self.device)
         self.load_params(PP.init_params(self.n_tok, seed, self.dims))
 

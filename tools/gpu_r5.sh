@@ -13,10 +13,15 @@ case $what in
   stamps)   timeout 300 python tools/xdec_stamps.py > gpurun_out/${TAG}_xdec_stamps.txt 2>&1; echo "stamps rc=$?"; tail -15 gpurun_out/${TAG}_xdec_stamps.txt
             timeout 300 python tools/xdec_stamps_bwd.py > gpurun_out/${TAG}_xdec_bwd_stamps.txt 2>&1; echo "bwd stamps rc=$?"; tail -15 gpurun_out/${TAG}_xdec_bwd_stamps.txt;;
   prof)     cd /tmp && export TMPDIR=/tmp
-            timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_prof.log 2>&1; echo "prof rc=$?"
+            LXO_ENC_OVERLAP=${PROF_OVERLAP:-0} timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_prof.log 2>&1; echo "prof rc=$?"
             cd $R
             DB=$(ls gpurun_out/${TAG}_prof/*/*_results.db 2>/dev/null | head -1)
             if [ -n "$DB" ]; then python tools/prof_summary.py $DB gpurun_out/${TAG}_kernels.csv "$TAG"; head -30 gpurun_out/${TAG}_kernels.csv | cut -c1-160; python tools/prof_by_grid.py $DB > gpurun_out/${TAG}_bygrid.txt 2>&1; rm -rf gpurun_out/${TAG}_prof; fi;;
+  profdec)  cd /tmp && export TMPDIR=/tmp
+            timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_profdec -- python $R/tools/decode_timing.py > $R/gpurun_out/${TAG}_profdec.log 2>&1 < /dev/null; echo "profdec rc=$?"
+            cd $R; grep "^beam" gpurun_out/${TAG}_profdec.log
+            DB=$(ls gpurun_out/${TAG}_profdec/*/*_results.db 2>/dev/null | head -1)
+            if [ -n "$DB" ]; then timeout 120 python tools/prof_summary.py $DB gpurun_out/${TAG}_decode_kernels.csv "$TAG decode" < /dev/null; head -24 gpurun_out/${TAG}_decode_kernels.csv | cut -c1-160; rm -rf gpurun_out/${TAG}_profdec; fi;;
   sqconv)   bash tools/gpu_pmc_sq.sh ${TAG} > gpurun_out/${TAG}_sqconv.log 2>&1; echo "sqconv rc=$?"; tail -30 gpurun_out/${TAG}_sqconv.log;;
   *) if [ -f "tools/$what" ]; then timeout 600 python tools/$what > gpurun_out/${TAG}_${what%.py}.log 2>&1; echo "$what rc=$?"; tail -25 gpurun_out/${TAG}_${what%.py}.log; else echo "unknown $what"; fi;;
 esac
