@@ -181,9 +181,13 @@ int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, 
  * stream (fork/join by events), so the launch- and latency-bound step kernels of one half overlap the
  * other half's.  The only per-thread state the library keeps. */
 int lxo_set_side_stream(void* stream);
-/* Optional second HIP stream for lxo_encoder_bwd (NULL disables): the conv weight-gradient kernels run on it, beside
- * the data-gradient / pool-backward chain of the main stream (three rotating gradient buffers; fork/join by events;
- * every call returns with the main stream ordered after all of its weight gradients). */
+/* Optional second HIP stream for the weight gradients of the calling host thread (NULL disables; bf16 mode without
+ * lxo_shape.deterministic only, ignored while lxo_timing_enable(1) records).  lxo_encoder_bwd runs the conv weight-gradient
+ * kernels on it, beside the data-gradient / pool-backward chain of the main stream (three rotating gradient buffers);
+ * lxo_decoder_train_bwd runs its deferred all-step weight gradients (dense dW GEMMs, LSTM bias, embeddings, initial-state
+ * parameters, dW_att_img) on it, beside the d_att_img -> d_img path.  Fork / join by events inside each call: every call
+ * returns with `stream` ordered after all of its work on the side stream, so gradients are final in stream order as without
+ * it, and no kernel of the side stream is in flight when a later call launches a persistent chain. */
 int lxo_set_encoder_side_stream(void* stream);
 
 /* Decoder.__call__ training branch (model/decoder.py:41-57): AttentionMechanism
@@ -260,7 +264,11 @@ int lxo_optimizer_step(int method, long long n, float* params, const float* grad
 
 /* dynamic_decode + GreedyDecoderCell (dynamic_decode.py:17-74, greedy_decoder_cell.py:40-66):
  * runs on the encoder output already in ws; ids_out int32 [B, max_steps] (device),
- * *steps_out = number of steps executed (<= max_iter + 1).  Host-synchronising. */
+ * *steps_out = number of steps executed (<= max_iter + 1).  Host-synchronising.  Columns >= *steps_out of ids_out are
+ * unspecified (the loop runs ahead of the host's all-finished check).  Where the shape qualifies (bf16, step_kernels 0,
+ * U = O = C = 512, E = 256, B in {8, 16, 32, 64}, V <= 512, MI355X) the steps run as a persistent chain, up to 16 per
+ * launch (csrc/xdec.hip: xdec_dec_kernel; LXO_XDEC_DEC=0 disables); a chain that fails to assemble is detected by the
+ * call, which then repeats the decode on the launch-per-step kernels. */
 int lxo_greedy_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                       int id_end, int max_iter, int32_t* ids_out, int* steps_out, void* stream);
 /* lxo_greedy_decode that also exports the attention weights of every step: alpha_out f32

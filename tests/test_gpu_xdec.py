@@ -294,3 +294,28 @@ def test_bf16_cell_transcendentals_over_pm20(step_kernels):
     cs = eng.region("cs", "f32", (T + 1, 8, U))[1, 0].cpu().numpy().astype(np.float64)
     h = eng.region("rec", "f32", (T + 1, 8, 2048))[1, 0, 512:1024].cpu().numpy().astype(np.float64)
     assert np.abs(cs - c1).max() < 2e-6 and np.abs(h - h1).max() < 2e-6, (np.abs(cs - c1).max(), np.abs(h - h1).max())
+
+
+def test_weight_gradients_on_the_second_stream_agree_with_one_stream(monkeypatch):
+    """Round 5: the encoder's weight gradients and the decoder's deferred ones (dense dW GEMMs, d_z's column sum, the embedding gradient,
+    the init-state gradients, dW_att_img) run on a second stream beside the d_img path (Engine.enc_side, default on).  Same kernels, same
+    operands: against the one-stream order (LXO_ENC_OVERLAP=0) only the order of f32 atomics differs.  B = 16: behind the backward chain."""
+    img, f, l = batch(16, 64, 256, V, 5, 24, seed=91)
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LXO_ENC_OVERLAP", flag)
+        eng = Engine(V, dtype="bf16", seed=5)
+        assert (eng.enc_side is not None) == (flag == "1")
+        for _ in range(2):                                   # twice: the second pass reuses the events and the bound stream
+            eng.forward(img, f)
+            st = eng.loss(l, 1.0 / int(l.sum())).cpu().numpy().copy()
+            eng.backward()
+        torch.cuda.synchronize()
+        assert eng.chain_status(backward=True) == (True, 0)
+        out.append((st, eng.grad_dict()))
+    (sa, ga), (sb, gb) = out
+    assert sa[1] == sb[1] and abs(sa[0] - sb[0]) <= 1e-5 * abs(sb[0])
+    for k in ga:
+        c = cosine(ga[k], gb[k])
+        r = float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-30))
+        assert c > 0.99999 and r < 1e-2, (k, c, r)

@@ -16,7 +16,8 @@ mathematics with different kernels, so they must agree far more tightly than eit
 * fused recurrent-step kernels (default)  vs  round 1's split-K kernels (step_kernels = 1);
 * the two-workgroup conv kernel with fused pools (default)  vs  the general halo conv kernel + separate pools (LXO_CONV_2WG=0: the
   kernel that shapes outside the model's -- Cout % 64 != 0, tensors of 2 GB and more -- run on);
-* the off-by-default stream switches LXO_DUAL_STREAM=1 and LXO_ENC_OVERLAP=1 (both measured slower, kept as A/B paths).
+* the stream switches: LXO_DUAL_STREAM=1 (off by default: measured slower) and LXO_ENC_OVERLAP=0 (the weight gradients -- the encoder's and the
+  decoder's deferred ones -- on the compute stream instead of beside it on a second stream, the default since round 5).
 Odd image sizes exercise the clipped pool windows of both generations."""
 import os, subprocess, sys
 import numpy as np
@@ -68,10 +69,10 @@ def test_kernel_generations_agree(tmp_path, h, w):
             ("att_bwd_two_blocks_in_flight", {"LXO_ATT_BWD2": "1"}, (1e-5, 0.99999, 1e-2)),
             # the general halo conv kernel (what Cout % 64 != 0 or a tensor of 2 GB and more runs on) for every layer; no fused pools there
             ("general_halo_conv", {"LXO_CONV_2WG": "0"}, (1e-4, 0.9995, 5e-2)),
-            # the two off-by-default stream switches: half-batch chains on two streams (on the split-K step kernels) and the
-            # encoder's weight gradients on a second stream (the same kernels, other order of the f32 atomics)
+            # the stream switches: half-batch chains on two streams (on the split-K step kernels; off by default), and every weight gradient on
+            # the compute stream instead of the second stream (the same kernels, other order of the f32 atomics)
             ("two_half_batch_chains", {"LXO_DUAL_STREAM": "1"}, (1e-4, 0.9995, 5e-2)),
-            ("wgrad_side_stream", {"LXO_ENC_OVERLAP": "1"}, (1e-5, 0.99999, 1e-2))):
+            ("wgrad_on_the_compute_stream", {"LXO_ENC_OVERLAP": "0"}, (1e-5, 0.99999, 1e-2))):
         other = _run(tmp_path, name, env, h, w, 4)
         worst = _compare(base, other, *bars)
         print("%dx%d default vs %s: worst cosine %.8f (%s, max rel %.2e)" % (h, w, name, worst[0], worst[1], worst[2]))

@@ -16,7 +16,7 @@ case $what in
             LXO_ENC_OVERLAP=${PROF_OVERLAP:-0} timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${TAG}_prof.log 2>&1; echo "prof rc=$?"
             cd $R
             DB=$(ls gpurun_out/${TAG}_prof/*/*_results.db 2>/dev/null | head -1)
-            if [ -n "$DB" ]; then python tools/prof_summary.py $DB gpurun_out/${TAG}_kernels.csv "$TAG"; head -30 gpurun_out/${TAG}_kernels.csv | cut -c1-160; python tools/prof_by_grid.py $DB > gpurun_out/${TAG}_bygrid.txt 2>&1; rm -rf gpurun_out/${TAG}_prof; fi;;
+            if [ -n "$DB" ]; then python tools/prof_summary.py $DB gpurun_out/${TAG}_kernels.csv "$TAG"; head -30 gpurun_out/${TAG}_kernels.csv | cut -c1-160; python tools/prof_by_grid.py $DB > gpurun_out/${TAG}_bygrid.txt 2>&1; python tools/prof_timeline.py $DB > gpurun_out/${TAG}_timeline.txt 2>&1; rm -rf gpurun_out/${TAG}_prof; fi;;
   profdec)  cd /tmp && export TMPDIR=/tmp
             timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_profdec -- python $R/tools/decode_timing.py > $R/gpurun_out/${TAG}_profdec.log 2>&1 < /dev/null; echo "profdec rc=$?"
             cd $R; grep "^beam" gpurun_out/${TAG}_profdec.log
