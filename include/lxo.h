@@ -175,6 +175,13 @@ int lxo_encoder_fwd(const lxo_shape* s, const float* params, const void* wpack, 
  * all-reduce finished buckets while earlier layers still run. */
 int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                     const uint8_t* img, float* grads, int last_layer, int first_layer, void* stream);
+/* The same range in ONE call, for a data-parallel caller that does not want the compute stream to stop at every bucket:
+ * ready_events[l] (l = 1..6; a table of 7 hipEvent_t created by the caller, NULL entries skipped) is recorded as soon as layer l's
+ * weight and bias gradients are final -- on the weight-gradient side stream when one is bound (lxo_set_encoder_side_stream), else on
+ * `stream` -- so a communication stream can wait for a layer's event and reduce its bucket while the earlier layers, and the
+ * weight gradients beside them, still run.  Returns like lxo_encoder_bwd: `stream` ordered after the whole range. */
+int lxo_encoder_bwd_ready(const lxo_shape* s, const float* params, const void* wpack, void* ws, const uint8_t* img, float* grads,
+                          int last_layer, int first_layer, void* const* ready_events, void* stream);
 
 /* Optional second HIP stream for the calling host thread (NULL disables).  When set, the recurrent
  * loops of lxo_decoder_train_fwd / _bwd run the two halves of the batch on `stream` and on this side

@@ -100,6 +100,14 @@ extern "C" int lxo_encoder_bwd(const lxo_shape* s, const float* params, const vo
     CHECK_LAUNCH(lxo_impl_encoder_bwd(P, params, wpack, ws, img, grads, last_layer, first_layer, (hipStream_t)stream), "lxo_encoder_bwd");
     return 0;
 }
+extern "C" int lxo_encoder_bwd_ready(const lxo_shape* s, const float* params, const void* wpack, void* ws, const uint8_t* img, float* grads,
+                                     int last_layer, int first_layer, void* const* ready_events, void* stream) {
+    MAKE_PLAN(P, s);
+    if (last_layer > 6 || first_layer < 1 || last_layer < first_layer) return fail(-1, "lxo_encoder_bwd_ready: layer range");
+    if (!ready_events) return fail(-1, "lxo_encoder_bwd_ready: null event table");
+    CHECK_LAUNCH(lxo_impl_encoder_bwd(P, params, wpack, ws, img, grads, last_layer, first_layer, (hipStream_t)stream, ready_events), "lxo_encoder_bwd_ready");
+    return 0;
+}
 
 #include "decoder_kernels.h"
 extern "C" int lxo_decoder_train_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,

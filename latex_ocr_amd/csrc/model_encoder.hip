@@ -208,7 +208,7 @@ static const int XV[7] = {0, 0, 0, 1, 0, 2, 0}, YV[7] = {0, 0, 2, 2, 1, 1, 1};  
 static const int XC[7] = {0, 0, 1, 0, 1, 2, 0}, YC[7] = {0, 0, 2, 2, 0, 1, 1};     // "cnn" (no pools after 4, 5)
 
 int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, float* grads,
-                         int last_layer, int first_layer, hipStream_t st) {
+                         int last_layer, int first_layer, hipStream_t st, void* const* ready) {
     const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
     void* const G[3] = {P.ws<void>(ws, W_G0), P.ws<void>(ws, W_G1), P.ws<void>(ws, W_G2)};
     const int* XB = P.cnn ? XC : XV; const int* YB = P.cnn ? YC : YV;
@@ -324,6 +324,16 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
             RC(lxo_k_conv1_pool_bwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], G[YB[2]], gw(P_CONV1_W), gw(P_CONV1_B), B, P.s.H, P.s.W, det, st));
             break;
         default: return -4;
+        }
+        // lxo_encoder_bwd_ready: layer l's weight and bias gradients are final once what has been enqueued so far has run (conv_l's bias
+        // gradient comes from this layer's routing kernel or from the data gradient of the layer above).  With a side stream the event is
+        // recorded THERE, behind the main stream's kernels of this layer -- the main stream itself is not held up.
+        if (ready && ready[l]) {
+            if (side) {
+                HIPRC(hipEventRecord(g_ev_x, st));
+                HIPRC(hipStreamWaitEvent(side, g_ev_x, 0));
+                HIPRC(hipEventRecord((hipEvent_t)ready[l], side));
+            } else HIPRC(hipEventRecord((hipEvent_t)ready[l], st));
         }
     }
     if (side) {      // every weight gradient of this call is complete before the caller reduces / applies the gradients

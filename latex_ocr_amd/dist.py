@@ -227,7 +227,7 @@ class DataParallel(object):
         With grad_dtype = torch.bfloat16 (LXO_DP_BF16=1; off by default) a bucket travels as bf16 (17.3 MB per step instead
         of 34.5 MB): rounded once before the sum, summed by the collective in bf16, widened back.  Relative error of a summed
         gradient element <= (world + 1) * 2^-9 of the largest addend; tests/test_dp_gloo.py states the bound it holds."""
-        def comm(lo, hi):
+        def comm(lo, hi, ready=None):
             seg = flat[lo:hi]
             if not self.cuda:
                 if self.host_ordered:
@@ -235,8 +235,12 @@ class DataParallel(object):
                 else:
                     self._reduce(seg)
                 return
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            # ready: an event the producer has already recorded behind this range's gradients (lxo_encoder_bwd_ready: possibly on its
+            # weight-gradient side stream); else the range is final in compute-stream order here
+            ev = ready
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
             if self.host_ordered:
                 self._q.put((ev, seg))
             else:
@@ -244,6 +248,7 @@ class DataParallel(object):
                 with torch.cuda.stream(self.side):
                     self._reduce(seg)
             self._pending = True
+        comm.takes_ready = os.environ.get("LXO_DP_READY_EVENTS", "1") != "0"
         return comm
 
     def finish(self, timed=None):

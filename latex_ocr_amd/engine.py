@@ -410,7 +410,16 @@ class Engine(object):
             comm(*self.buckets[1])
         if phase_hook:
             phase_hook("decoder_bwd")
-        if comm:
+        if comm and getattr(comm, "takes_ready", False) and self.device.type == "cuda":
+            # ONE call for the six layers; the library records an event per layer when its gradients are final (on the weight-gradient
+            # side stream when one is bound) and the communication side waits for THAT: the compute stream does not stop at the buckets
+            evs = self._enc_ready_events()
+            table = (ctypes.c_void_p * 7)(*[ctypes.c_void_p(e.cuda_event) if e is not None else None for e in evs])
+            self._ck(self.lib.lxo_encoder_bwd_ready(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
+                                                    6, 1, table, st), "encoder_bwd_ready")
+            for (hi, lo), rng in self.enc_buckets:
+                comm(*rng, ready=evs[lo])
+        elif comm:
             # one all-reduce per encoder layer as its gradients become final: only conv2 + conv1 (0.3 MB) are left for the end
             for (hi, lo), rng in self.enc_buckets:
                 self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
@@ -419,6 +428,18 @@ class Engine(object):
         else:
             self._ck(self.lib.lxo_encoder_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), _p(self.grads),
                                               6, 1, st), "encoder_bwd")
+
+    def _enc_ready_events(self):
+        """events[l] for the layers that close a gradient bucket (enc_buckets: 6, 5, 4, 3 and 1); recorded once here so that their handles
+        exist, re-recorded by lxo_encoder_bwd_ready every step"""
+        if getattr(self, "_enc_ready", None) is None:
+            cur = torch.cuda.current_stream(self.device)
+            evs = [None] * 7
+            for (hi, lo), _ in self.enc_buckets:
+                evs[lo] = torch.cuda.Event()
+                evs[lo].record(cur)
+            self._enc_ready = evs
+        return self._enc_ready
 
     METHODS = {"adam": 0, "sgd": 1, "adagrad": 2, "rmsprop": 3}
 
