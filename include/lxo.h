@@ -182,6 +182,13 @@ int lxo_encoder_bwd(const lxo_shape* s, const float* params, const void* wpack, 
  * weight gradients beside them, still run.  Returns like lxo_encoder_bwd: `stream` ordered after the whole range. */
 int lxo_encoder_bwd_ready(const lxo_shape* s, const float* params, const void* wpack, void* ws, const uint8_t* img, float* grads,
                           int last_layer, int first_layer, void* const* ready_events, void* stream);
+/* The whole backward pass of a training step in one call: lxo_decoder_train_bwd followed by lxo_encoder_bwd for layers 6..1 (the two
+ * halves of what one sess.run(train_op) differentiates, img2seq.py:169), with the weight-gradient side stream -- when one is bound --
+ * joined ONCE, at the end, instead of once per call: the decoder's deferred weight gradients then also run beside conv6's data
+ * gradient.  ready_events (optional): as for lxo_encoder_bwd_ready, plus entry 0 = every decoder gradient final (incl. y_W_o and the
+ * chain-failure probe element lxo_chain_guard reads).  `stream` is ordered after everything when the call returns. */
+int lxo_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws, const int32_t* formula, const uint8_t* img,
+                  float* grads, void* const* ready_events, void* stream);
 
 /* Optional second HIP stream for the calling host thread (NULL disables).  When set, the recurrent
  * loops of lxo_decoder_train_fwd / _bwd run the two halves of the batch on `stream` and on this side

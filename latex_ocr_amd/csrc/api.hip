@@ -151,6 +151,14 @@ extern "C" int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, co
     CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, nullptr, 3, (hipStream_t)stream), "lxo_decoder_train_bwd");
     return 0;
 }
+extern "C" int lxo_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws, const int32_t* formula, const uint8_t* img,
+                            float* grads, void* const* ready_events, void* stream) {
+    MAKE_PLAN(P, s);
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, nullptr, 3, (hipStream_t)stream, true, ready_events ? ready_events[0] : nullptr),
+                 "lxo_train_bwd (decoder)");
+    CHECK_LAUNCH(lxo_impl_encoder_bwd(P, params, wpack, ws, img, grads, 6, 1, (hipStream_t)stream, ready_events), "lxo_train_bwd (encoder)");
+    return 0;
+}
 extern "C" int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                                           const int32_t* formula, float* grads, const int32_t* active_rows, int parts, void* stream) {
     MAKE_PLAN(P, s);

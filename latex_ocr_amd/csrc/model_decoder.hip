@@ -309,7 +309,7 @@ hipStream_t lxo_impl_encoder_side_stream();
 static thread_local hipEvent_t g_dbw_fork = nullptr, g_dbw_fork2 = nullptr, g_dbw_join = nullptr, g_dbw_init = nullptr;
 
 int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads,
-                               const int* active, int parts, hipStream_t st) {
+                               const int* active, int parts, hipStream_t st, bool defer_join, void* ready) {
     const int B = P.s.B, T = P.s.T, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
     const int TB = T * B;
     auto gw = [&](int pid) { return grads + P.poff[pid]; };
@@ -585,13 +585,24 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     }
     if (side) HIPRC(hipStreamWaitEvent(side, g_dbw_fork2, 0));      // dW_att_img needs d_att_img, nothing needs dW_att_img
     RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, sd, det));
-    if (side) {
+    // lxo_train_bwd (defer_join): the side stream's work is NOT joined here -- lxo_impl_encoder_bwd follows on the same two streams and
+    // joins them once, at its end; the deferred gradients then also run beside conv6's data gradient instead of holding the main stream
+    if (side && !defer_join) {
         HIPRC(hipEventRecord(g_dbw_join, side));
         HIPRC(hipStreamWaitEvent(st, g_dbw_join, 0));
     }
     // the backward chain's error word -> the probe element (as for the forward chain above; y_W_o's bucket is reduced behind this call
     // where the backward chain runs, Engine.backward)
     if (bwd_chain) RC(lxo_k_chain_poison(nullptr, P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4 + 8 * 64, grads + P.ptotal - 1, st));
+    // `ready`: every decoder gradient (and the probe element) is final -- recorded on the side stream behind both streams' work when
+    // one is in use, so that a communication stream can wait for it without the main stream stopping
+    if (ready) {
+        if (side) {
+            HIPRC(hipEventRecord(g_dbw_fork, st));
+            HIPRC(hipStreamWaitEvent(side, g_dbw_fork, 0));
+            HIPRC(hipEventRecord((hipEvent_t)ready, side));
+        } else HIPRC(hipEventRecord((hipEvent_t)ready, st));
+    }
     return 0;
 }
 

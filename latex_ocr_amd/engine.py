@@ -390,6 +390,27 @@ class Engine(object):
                 self._ck(self.lib.lxo_decoder_train_bwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
                                                                _p(self.grads), act, st), "decoder_train_bwd_active")
 
+        # After the first backward of this shape has been looked at (below), the whole pass is ONE call: lxo_train_bwd joins the weight-gradient
+        # side stream once, at the end (the decoder's deferred weight gradients then also run beside conv6's data gradient), and records
+        # an event per gradient bucket for the data-parallel exchange.  bench.py's instrumented step (phase_hook) keeps the two calls.
+        key = (self.shape.B, self.shape.H, self.shape.W)
+        looked = self._xdec_bwd_checked or key in self._nochain_shapes_bwd or not chain
+        ready_ok = comm is None or (getattr(comm, "takes_ready", False) and chain)      # (no chain: y_W_o's bucket goes out while the recurrence runs)
+        if (self.device.type == "cuda" and self._active is None and looked and ready_ok and phase_hook is None
+                and os.environ.get("LXO_TRAIN_BWD_FUSED", "1") != "0"):
+            self.grads.zero_()
+            table = None
+            if comm:
+                evs = self._enc_ready_events()
+                table = (ctypes.c_void_p * 7)(*[ctypes.c_void_p(e.cuda_event) if e is not None else None for e in evs])
+            self._ck(self.lib.lxo_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), _p(self._img),
+                                            _p(self.grads), table, st), "train_bwd")
+            if comm:
+                comm(*self.buckets[0], ready=evs[0])
+                comm(*self.buckets[1], ready=evs[0])
+                for (hi, lo), rng in self.enc_buckets:
+                    comm(*rng, ready=evs[lo])
+            return
         decoder_bwd(chain)
         if chain and not self._xdec_bwd_checked and (self.shape.B, self.shape.H, self.shape.W) not in self._nochain_shapes_bwd:
             # as for the forward chain, after the first backward that RAN it: a chain that did not assemble leaves an error word -> launch
@@ -430,12 +451,12 @@ class Engine(object):
                                               6, 1, st), "encoder_bwd")
 
     def _enc_ready_events(self):
-        """events[l] for the layers that close a gradient bucket (enc_buckets: 6, 5, 4, 3 and 1); recorded once here so that their handles
-        exist, re-recorded by lxo_encoder_bwd_ready every step"""
+        """events[l] for the layers that close a gradient bucket (enc_buckets: 6, 5, 4, 3 and 1) and [0] for the decoder's parameters; recorded
+        once here so that their handles exist, re-recorded by lxo_encoder_bwd_ready / lxo_train_bwd every step"""
         if getattr(self, "_enc_ready", None) is None:
             cur = torch.cuda.current_stream(self.device)
             evs = [None] * 7
-            for (hi, lo), _ in self.enc_buckets:
+            for lo in [0] + [lo for (hi, lo), _ in self.enc_buckets]:      # 0: the decoder's parameters (lxo_train_bwd)
                 evs[lo] = torch.cuda.Event()
                 evs[lo].record(cur)
             self._enc_ready = evs
