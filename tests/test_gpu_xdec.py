@@ -319,3 +319,27 @@ def test_weight_gradients_on_the_second_stream_agree_with_one_stream(monkeypatch
         c = cosine(ga[k], gb[k])
         r = float(np.abs(ga[k] - gb[k]).max() / max(np.abs(gb[k]).max(), 1e-30))
         assert c > 0.99999 and r < 1e-2, (k, c, r)
+
+
+@pytest.mark.parametrize("dtype,det", [("f32", False), ("bf16", True), ("bf16", False)])
+def test_train_bwd_in_one_call_equals_the_two_calls(monkeypatch, dtype, det):
+    """lxo_train_bwd (decoder + encoder backward, one join of the weight-gradient stream) against lxo_decoder_train_bwd + lxo_encoder_bwd:
+    the same kernels on the same operands.  In the reproducible modes (f32; bf16 deterministic) every gradient is bit-identical; in the default
+    bf16 mode only the order of f32 atomics may differ.  Engine.backward takes the one-call form from the second backward of a shape on."""
+    img, f, l = batch(16, 48, 160, V, 5, 24, seed=33)
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LXO_TRAIN_BWD_FUSED", fused)
+        eng = Engine(V, dtype=dtype, seed=6, deterministic=det)
+        for _ in range(2):                                   # the first backward of a shape is always the two calls (the chain is looked at)
+            eng.forward(img, f)
+            eng.loss(l, 1.0 / int(l.sum()))
+            eng.backward()
+        torch.cuda.synchronize()
+        out.append(eng.grad_dict())
+    ga, gb = out
+    for k in ga:
+        if dtype == "f32" or det:
+            assert ga[k].tobytes() == gb[k].tobytes(), k
+        else:
+            assert cosine(ga[k], gb[k]) > 0.99999, (k, cosine(ga[k], gb[k]))
