@@ -510,3 +510,28 @@ def test_skip_padded_steps_same_loss_and_gradients():
         assert np.abs(a0 - a1).max() <= 1e-5 * max(np.abs(a0).max(), 1e-6) + 1e-9, k
     bad = active.copy(); bad[0] = 1
     assert S.L.lxo_decoder_train_fwd_active(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(bad), None) != 0
+
+
+def test_train_bwd_and_ready_entry_points_vs_golden():
+    """lxo_encoder_bwd_ready (one call for a layer range, with a per-layer event table whose NULL entries are skipped) behind
+    lxo_decoder_train_bwd against the golden gradients, and lxo_train_bwd (the backward pass in one call) from the same forward state: the
+    same kernels in the same order on one stream -- every gradient bit-identical.  f32."""
+    S, img, f, l = _run(0)
+    S.grads[:] = 0
+    S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), None), "decbwd")
+    table = (ctypes.c_void_p * 7)()
+    S.ck(S.L.lxo_encoder_bwd_ready(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, table, None), "encbwd_ready")
+    checked = 0
+    for k, _, _ in S.specs:
+        key = k.replace("/", "__")
+        if key in GOLD.files:
+            g, r = S.grad(k), GOLD[key]
+            assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1e-6) + 1e-9, k
+            checked += 1
+    assert checked >= 9
+    first = S.grads.copy()
+    S.grads[:] = 0
+    S.ck(S.L.lxo_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(img), ptr(S.grads), None, None), "train_bwd")
+    assert first.tobytes() == S.grads.tobytes()
+    assert S.L.lxo_encoder_bwd_ready(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, None, None) != 0     # no table
+    assert S.L.lxo_encoder_bwd_ready(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 7, 1, table, None) != 0   # layer range
