@@ -299,13 +299,17 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
     # id_end = -1 can never be emitted: every row runs to the bound (max_iter + 1 = 152 steps), as an untrained model does
     ns = int(eng.greedy_decode(dec_img, -1, max_iter=151).shape[1])
     dt = timed(lambda: eng.greedy_decode(dec_img, -1, max_iter=151), 3, warm=1)
+    dte = timed(lambda: eng._encode_only(dec_img, 1), 5, warm=1)           # the encoder of the same batch alone: what the per-step figures below exclude
+    used, err = eng.chain_status()
     out["decode_greedy_bound"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": ns, "us_per_step": round(dt * 1e6 / ns, 1),
-                                  "tokens_per_s": round(B * ns / dt, 0), "batch": B}
+                                  "tokens_per_s": round(B * ns / dt, 0), "batch": B, "encoder_ms": round(dte * 1e3, 3),
+                                  "loop_us_per_step": round((dt - dte) * 1e6 / ns, 1), "persistent_chain": bool(used and not err),
+                                  "note": "us_per_step = the whole call (encoder + decode loop) / steps; loop_us_per_step leaves the encoder out; the loop runs as the persistent decode chain (xdec_dec_kernel, 16 steps per launch)"}
     ns = int(eng.beam_decode(dec_img, -1, 5, max_iter=151).shape[1])
     dt = timed(lambda: eng.beam_decode(dec_img, -1, 5, max_iter=151), 2, warm=1)
     out["decode_beam5_bound"] = {"ms_per_batch": round(dt * 1e3, 2), "steps": ns, "us_per_step": round(dt * 1e6 / ns, 1),
-                                 "tokens_per_s": round(B * ns / dt, 0), "batch": B, "beam": 5,
-                                 "note": "tokens = emitted positions of the best hypothesis per image (B x steps); the encoder is inside the timing"}
+                                 "tokens_per_s": round(B * ns / dt, 0), "batch": B, "beam": 5, "loop_us_per_step": round((dt - dte) * 1e6 / ns, 1),
+                                 "note": "tokens = emitted positions of the best hypothesis per image (B x steps); the encoder is inside the timing (us_per_step), outside loop_us_per_step"}
     engc = Engine(V, dtype="bf16", device=dev, seed=0)
     for step in range(260):
         ci, cf = count_set(16, 100 + step, H, W)

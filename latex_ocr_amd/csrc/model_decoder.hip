@@ -797,9 +797,12 @@ int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void
             // fall back to the launch-per-step kernels: the initial state, the finished flags and the token table are rebuilt first
             RC(attention_prepare(P, prm, wp, ws, 1, st));
             if (fused_steps(P)) RC(mirror_oh(P, ws, 0, B, st));
-        } else HIPRC(hipStreamSynchronize(st));           // (nothing was enqueued by the refused first chunk but its counter memset)
+        } else {
+            HIPRC(hipStreamSynchronize(st));              // (nothing was enqueued by the refused first chunk but its counter memset)
+            HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC), 0, 8 * 64 * 4, st));      // no chain in this call: no tickets (Engine.chain_status reads them)
+        }
         HIPRC(hipMemsetAsync(flags, 0, 256 + (size_t)B * 4, st));
-    }
+    } else if (P.bf) HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC), 0, 8 * 64 * 4, st));
     RC(decode_loop(max_iter, flags, st, steps_out, [&](int time, int* unfinished) -> int {
         const int cur = (time + 1) & 1;
         RC(decode_common_step(P, prm, wp, ws, B, 1, cur, time == 0 ? nullptr : ids_step, st));
