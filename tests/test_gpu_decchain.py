@@ -111,3 +111,18 @@ def test_decode_chain_twice_and_after_training(end_params):
     ids, alpha = eng.greedy_decode(img, V - 1, max_iter=151, return_attention=True)      # the attention maps come from the launch-per-step path
     assert ids.shape == a.shape and (ids == a).mean() >= 0.999
     assert np.abs(alpha.reshape(alpha.shape[0], alpha.shape[1], -1).sum(-1) - 1.0).max() < 1e-3
+
+
+@pytest.mark.parametrize("B", [1, 5, 20, 40])
+def test_odd_batches_are_filled_up_to_a_chain_batch(end_params, monkeypatch, B):
+    """Engine.greedy_decode fills a batch the chain does not take (B not in {8, 16, 32, 64}) with copies of its own images: the chain runs
+    (tickets taken, no error), the real rows' ids and the step count are those of the launch-per-step path on the B images alone."""
+    imgs, forms = count_set(B, 500 + B)
+    img = pad_batch_images(imgs)
+    a, used, err = _decode(end_params, img, 0, 151)
+    assert used and err == 0, (used, err)
+    monkeypatch.setenv("LXO_DECODE_PAD", "0")
+    b, used_b, _ = _decode(end_params, img, 0, 151)
+    assert not used_b                                           # B images alone: the launch-per-step kernels
+    assert a.shape == b.shape and a.shape[0] == B, (a.shape, b.shape)
+    assert (a == b).mean() >= 0.999, np.argwhere(a != b)[:8]
