@@ -335,7 +335,7 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
         fd_d = torch.from_numpy(fd).to(dev)
         dtd = timed(lambda: engd.train_step(imgd, fd_d, ld, 1e-3, sync_loss=False), 10, warm=3)
         out["deterministic_bf16"] = {"ms_per_step": round(dtd * 1e3, 3), "img_per_s": round(B / dtd, 1), "chains": bool(engd.chain_used and engd.chain_used_bwd),
-                                     "note": "the headline workload with Engine(deterministic=True): conv and dense weight gradients through per-range slabs + an ordered pass, bias sums / d_beta / loss / conv1 through ordered per-workgroup slots (no float atomics: two runs agree bit for bit, tests/test_gpu_determinism.py); tools/det_ab.py alternates the two modes in one process (profiles/r05_det_ab.txt: +1.9 %)"}
+                                     "note": "the headline workload with Engine(deterministic=True): conv and dense weight gradients through per-range slabs + an ordered pass, bias sums / d_beta / loss / conv1 through ordered per-workgroup slots (no float atomics: two runs agree bit for bit, tests/test_gpu_determinism.py); tools/det_ab.py alternates the two modes in one process (profiles/r05_det_ab_two_streams.txt: +0.7 %; with one stream +1.9 %)"}
         del engd
     except Exception as e:
         out["deterministic_bf16"] = {"error": repr(e)}

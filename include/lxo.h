@@ -195,8 +195,8 @@ int lxo_train_bwd(const lxo_shape* s, const float* params, const void* wpack, vo
  * stream (fork/join by events), so the launch- and latency-bound step kernels of one half overlap the
  * other half's.  The only per-thread state the library keeps. */
 int lxo_set_side_stream(void* stream);
-/* Optional second HIP stream for the weight gradients of the calling host thread (NULL disables; bf16 mode without
- * lxo_shape.deterministic only, ignored while lxo_timing_enable(1) records).  lxo_encoder_bwd runs the conv weight-gradient
+/* Optional second HIP stream for the weight gradients of the calling host thread (NULL disables; bf16 mode only,
+ * ignored while lxo_timing_enable(1) records).  lxo_encoder_bwd runs the conv weight-gradient
  * kernels on it, beside the data-gradient / pool-backward chain of the main stream (three rotating gradient buffers);
  * lxo_decoder_train_bwd runs its deferred all-step weight gradients (dense dW GEMMs, LSTM bias, embeddings, initial-state
  * parameters, dW_att_img) on it, beside the d_att_img -> d_img path.  Fork / join by events inside each call: every call

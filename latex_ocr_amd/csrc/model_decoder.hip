@@ -492,7 +492,8 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(lxo_k_slab_reduce(view(sb4, 4 * U, hb, P.XH), dxh + r0 * P.XH, P.XH, hb, P.XH, st));
     }
     // ---- deferred weight gradients over all steps ----
-    hipStream_t side = (P.bf && fused && !P.det() && !lxo_timer_on()) ? lxo_impl_encoder_side_stream() : nullptr;
+    hipStream_t side = (P.bf && fused && !lxo_timer_on()) ? lxo_impl_encoder_side_stream() : nullptr;
+    const DetScratch det_s = side ? P.det_scratch_side(ws) : det;      // deterministic mode: the side stream's own half of the ordered-partials scratch
     if (side) {
         if (!g_dbw_fork) {
             HIPRC(hipEventCreateWithFlags(&g_dbw_fork, hipEventDisableTiming));
@@ -511,9 +512,9 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, sd));
     RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, sd));
     RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, sd));
-    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, det, sd));
-    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, det, sd));
-    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, det, sd));
+    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, det_s, sd));
+    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, det_s, sd));
+    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, det_s, sd));
     const char* wi = (const char*)P.pk(wp, K_INIT);
     if (fused_steps(P)) {
         RC(rs_dense(P, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, false, false, sd));
@@ -530,18 +531,18 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         // these reductions over T*B rows are bound by operand re-reads (every 128 x 128 tile walks all rows of both operands)
         const bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         const bf16_t* gb = P.ws<bf16_t>(ws, W_GB); const bf16_t* dzb = P.ws<bf16_t>(ws, W_DZB);
-        RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, sd, det));      // d[o_W_h; o_W_c]
-        if (bwd_chain) RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, P.ws<bf16_t>(ws, W_DATTHB), E, gw(P_ATT_H), E, TB, U, E, sd, det));      // dW_att_h
+        RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, gb, P.GBP, gw(P_OWH), O, TB, P.HC, O, sd, det_s));      // d[o_W_h; o_W_c]
+        if (bwd_chain) RC(tn(P, false, false, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, P.ws<bf16_t>(ws, W_DATTHB), E, gw(P_ATT_H), E, TB, U, E, sd, det_s));      // dW_att_h
         else RC(tn(P, false, true, recb + (size_t)B * P.RECB + P.OFF_HT, P.RECB, datth, E, gw(P_ATT_H), E, TB, U, E, sd));
-        RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, sd, det));           // dK rows 0..D
-        RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, sd, det));     // dK rows D..
+        RC(tn(P, false, false, P.ws<void>(ws, W_EMB_IN), P.Dp, dzb, P.DZBP, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, sd, det_s));           // dK rows 0..D
+        RC(tn(P, false, false, recb, P.RECB, dzb, P.DZBP, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, sd, det_s));     // dK rows D..
     } else {
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, gall, O, gw(P_OWH), O, TB, P.HC, O, st));      // d[o_W_h; o_W_c]
     RC(tn(P, true, true, rec + (size_t)B * P.REC + P.OFF_HT, P.REC, datth, E, gw(P_ATT_H), E, TB, U, E, st));      // dW_att_h
     RC(tn(P, false, true, P.ws<void>(ws, W_EMB_IN), P.Dp, dz, 4 * U, gw(P_LSTM_K), 4 * U, TB, D, 4 * U, st)); // dK rows 0..D
     RC(tn(P, true, true, rec, P.REC, dz, 4 * U, gw(P_LSTM_K) + (size_t)D * 4 * U, 4 * U, TB, P.XH, 4 * U, st)); // dK rows D..
     }
-    RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, det, sd));
+    RC(lxo_k_colsum(dz, 4 * U, gw(P_LSTM_B), TB, 4 * U, det_s, sd));
     // embeddings
     float* demb = P.ws<float>(ws, W_DEMB);
     if (fused) {   // d_emb = d_z K[0:D]^T over all T*B rows: a tall GEMM on the step kernel (505 workgroups; the bf16 mirror of d_z halves its bytes)
@@ -584,7 +585,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     }
     if (side) HIPRC(hipStreamWaitEvent(side, g_dbw_fork2, 0));      // dW_att_img needs d_att_img, nothing needs dW_att_img
-    RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, sd, det));
+    RC(tn(P, false, false, P.ws<void>(ws, W_IMG), C, P.ws<void>(ws, W_DATTIMG), E, gw(P_ATT_IMG), E, B * P.R, C, E, sd, det_s));
     // lxo_train_bwd (defer_join): the side stream's work is NOT joined here -- lxo_impl_encoder_bwd follows on the same two streams and
     // joins them once, at its end; the deferred gradients then also run beside conv6's data gradient instead of holding the main stream
     if (side && !defer_join) {

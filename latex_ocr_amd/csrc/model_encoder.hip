@@ -221,9 +221,10 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         if (!P.det()) return 0;
         return lxo_k_colsum_det(x, P.bf ? 1 : 0, Cc, gw(pid), rows, Cc, det, st);
     };
-    // no second stream in the deterministic modes (the weight gradients' slabs and the main stream's ordered slots share one scratch
-    // region) and while per-launch brackets are recorded (bench.py's instrumented step times every launch alone)
-    hipStream_t side = (P.det() || lxo_timer_on()) ? nullptr : g_enc_side;
+    // no second stream in the f32 parity mode and while per-launch brackets are recorded (bench.py's instrumented step times every launch
+    // alone).  bf16 deterministic mode: the side stream's slabs live in their own half of the ordered-partials scratch.
+    hipStream_t side = ((P.det() && !P.bf) || lxo_timer_on()) ? nullptr : g_enc_side;
+    const DetScratch det_w = side ? P.det_scratch_side(ws) : det;      // what a weight gradient uses on whichever stream it runs
     bool pending[3] = {false, false, false};
     // main is about to WRITE buffer i: wait for the weight gradient that still reads it
     auto acquire = [&](int i) -> int {
@@ -236,7 +237,7 @@ int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* 
         if (!side) return conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, det, st);
         HIPRC(hipEventRecord(g_ev_x, st));
         HIPRC(hipStreamWaitEvent(side, g_ev_x, 0));
-        RC(conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, det, side));
+        RC(conv_wgrad(P, in, dy, dw, H, W, Cin, Cout, valid, det_w, side));
         HIPRC(hipEventRecord(g_ev_free[xi], side));
         pending[xi] = true;
         return 0;

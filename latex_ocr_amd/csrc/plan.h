@@ -106,7 +106,10 @@ struct Plan {
     // bf16 training: the attention kernels of the recurrence read E_x = e^{2 att_img} (region att_exp) and form tanh from one reciprocal
     // per element; LXO_ATT_EXP=0 keeps the x form (A/B)
     bool att_exp() const;
-    DetScratch det_scratch(void* base) const { DetScratch d = {nullptr, 0}; if (det()) { d.p = ws<float>(base, W_DET); d.floats = wbytes[W_DET] / 4; } return d; }   // with the row encoder "d_img" is the gradient w.r.t. ITS output: plain f32
+    // bf16 deterministic mode: the region is two halves -- the main stream's ordered slots / slabs and those of the weight-gradient side stream
+    // (model_encoder.hip, model_decoder.hip: two streams must not share one scratch)
+    DetScratch det_scratch(void* base) const { DetScratch d = {nullptr, 0}; if (det()) { d.p = ws<float>(base, W_DET); d.floats = wbytes[W_DET] / 4 / (bf ? 2 : 1); } return d; }
+    DetScratch det_scratch_side(void* base) const { DetScratch d = {nullptr, 0}; if (det() && bf) { d.floats = wbytes[W_DET] / 8; d.p = ws<float>(base, W_DET) + d.floats; } return d; }   // with the row encoder "d_img" is the gradient w.r.t. ITS output: plain f32
     template <class T> T* ws(void* base, WsId id) const { return reinterpret_cast<T*>(static_cast<char*>(base) + woff[id]); }
     const void* pk(const void* base, PackId id) const { return static_cast<const char*>(base) + koff[id]; }
     void* pk(void* base, PackId id) const { return static_cast<char*>(base) + koff[id]; }

@@ -150,6 +150,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
         // -- at most 264 of them (256 rounded up to whole XCD rounds) -- and an ordered pass adds them (conv_wgrad.hip)
         const size_t wg = (size_t)264 * 9 * 64 * 128 * f4;
         if (bf && wb[W_DET] < wg) wb[W_DET] = wg;
+        if (bf) wb[W_DET] = 2 * ((wb[W_DET] + 255) / 256 * 256);      // one half per stream (Plan::det_scratch / det_scratch_side)
     }
     const int nb = s.beam > 1 ? s.beam : 1;
     const size_t BK_ = BL * nb;                      // decoder rows (beam-expanded for decode)

@@ -110,7 +110,7 @@ class Engine(object):
         # second stream for the encoder's weight-gradient kernels (LXO_ENC_OVERLAP=0 switches it off): their prologues / epilogues and
         # the memory-bound pool-backward kernels overlap the data-gradient kernels.  Slower in rounds 1-3 (the cross-stream waits delayed
         # the launch-per-step decoder); with the decoder in two persistent launches it pays: 7.99 -> 7.87 ms per step (round 5).  The
-        # library ignores it in the deterministic modes and while bench.py records per-launch times (model_encoder.hip).
+        # library ignores it in the f32 parity mode and while bench.py records per-launch times (model_encoder.hip).
         self.enc_side = None
         if self.device.type == "cuda" and os.environ.get("LXO_ENC_OVERLAP", "1") != "0":
             self.enc_side = torch.cuda.Stream(self.device)
