@@ -343,3 +343,42 @@ def test_train_bwd_in_one_call_equals_the_two_calls(monkeypatch, dtype, det):
             assert ga[k].tobytes() == gb[k].tobytes(), k
         else:
             assert cosine(ga[k], gb[k]) > 0.99999, (k, cosine(ga[k], gb[k]))
+
+
+def test_ready_events_fire_when_a_buckets_gradients_are_final():
+    """lxo_train_bwd with an event table (what the data-parallel exchange waits for): a third stream that waits for a bucket's event and copies
+    the bucket at once must see the FINAL gradients -- the event is recorded behind both streams' work on that range (the weight gradients run
+    on the side stream, bias gradients and the chain-failure probe on the compute stream)."""
+    import ctypes
+    from latex_ocr_amd.engine import _p
+    img, f, l = batch(16, 64, 256, V, 5, 24, seed=17)
+    eng = Engine(V, dtype="bf16", seed=8)
+    assert eng.enc_side is not None
+    for _ in range(2):
+        eng.forward(img, f)
+        eng.loss(l, 1.0 / int(l.sum()))
+        eng.backward()
+    torch.cuda.synchronize()
+    ranges = {0: (eng.buckets[1][0], eng.buckets[0][1])}               # every decoder parameter: [first_dec, n_params)
+    for (hi, lo), rng in eng.enc_buckets:
+        ranges[lo] = rng
+    for rep in range(3):
+        eng.forward(img, f)
+        eng.loss(l, 1.0 / int(l.sum()))
+        evs = eng._enc_ready_events()
+        table = (ctypes.c_void_p * 7)(*[ctypes.c_void_p(e.cuda_event) if e is not None else None for e in evs])
+        eng._bind_side()
+        eng.grads.zero_()
+        eng._ck(eng.lib.lxo_train_bwd(eng.sref(), _p(eng.params), _p(eng.wpack), _p(eng.ws), _p(eng._formula), _p(eng._img), _p(eng.grads), table,
+                                      eng._stream()), "train_bwd")
+        third = torch.cuda.Stream()
+        snaps = {}
+        for k in (0, 6, 5, 4, 3, 1):                                   # the order the events are recorded in
+            third.wait_event(evs[k])
+            with torch.cuda.stream(third):
+                snaps[k] = eng.grads[ranges[k][0]:ranges[k][1]].clone()
+        torch.cuda.synchronize()
+        for k, (lo, hi) in ranges.items():
+            final = eng.grads[lo:hi]
+            assert torch.isfinite(final).all() and float(final.abs().max()) > 0, k
+            assert torch.equal(snaps[k], final), (rep, k, float((snaps[k] - final).abs().max()))
