@@ -739,7 +739,7 @@ static int decode_loop_chunked(int max_iter, int CHUNK, int* flags, hipStream_t 
         HIPRC(hipEventSynchronize(g_poll.ev[slot]));
         const int n = g_poll.host[slot * 64 + 32], first = g_poll.host[slot * 64 + 33];
         for (int c = 0; c < n; ++c)
-            if (g_poll.host[slot * 64 + c] == 0 || first + c >= max_iter) { steps = first + c + 1; break; }
+            if ((g_poll.host[slot * 64 + c] & 0xffff) == 0 || first + c >= max_iter) { steps = first + c + 1; break; }      // low 16 bits: unfinished rows (high bits: chains that reported)
         ++checked;
         if (steps < 0 && checked == nchunks && enq > max_iter) steps = enq;
     }

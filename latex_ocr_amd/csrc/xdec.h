@@ -52,8 +52,8 @@ struct XDecDec {
     int* ids_step;                    // [B] in: the ids fed at step t0 (t0 > 0); out: the ids of the launch's last step
     int* ids_out;                     // [B][max_steps]
     int* finished;                    // [B] (0 / 1, sticky)
-    int* unfinished;                  // [32] zeroed by the caller: [0 .. nsteps) rows still unfinished after each step of this launch; [16 .. 16 + nsteps) chains
-                                      // that have reported that step (8 = all).  nsteps <= 16
+    int* unfinished;                  // [nsteps <= 16] zeroed by the caller, one word per step of this launch: low 16 bits = rows still unfinished after
+                                      // the step (summed over the chains), high bits = chains that have reported it (8 = all)
     int* stop;                        // one word, zero at the start of the decode: set once every row of every chain has finished -- the chains of
                                       // this launch stop within three steps of that point, later (speculative) launches return at once
     int B, R, REC, RECB, V, id_end, t0, nsteps, max_steps;

@@ -871,16 +871,16 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                 }
                 __syncthreads();
                 if (rank == 0 && tid == 0) {
-                    // the chain's unfinished rows of step t - 1, THEN its report (the first atomic returns: it has been performed when the
-                    // second is issued); then the probe of the step before, consumed at the next boundary
+                    // ONE word per step: low 16 bits = the unfinished rows of step t - 1 summed over the chains, high bits = the number of chains
+                    // that have reported -- one atomic per chain and step, and the probe of the step before (consumed at the next boundary)
+                    // is ONE load: a consistent snapshot of both fields
                     int cnt = 0;
 #pragma unroll
                     for (int r = 0; r < NB; ++r) cnt += unf_l[r];
-                    const int before = atomicAdd(p.unfinished + (t - 1), cnt);
-                    if (before >= 0) atomicAdd(p.unfinished + 16 + (t - 1), 1);
+                    atomicAdd(p.unfinished + (t - 1), cnt | 0x10000);
                     if (t >= 2) {
-                        pr_done = __hip_atomic_load(p.unfinished + 16 + (t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pr_unf = __hip_atomic_load(p.unfinished + (t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int w = __hip_atomic_load(p.unfinished + (t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pr_done = w >> 16; pr_unf = w & 0xffff;
                     }
                 }
                 if (s_stop) {
@@ -1568,7 +1568,7 @@ int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_
     if (on < 0) { const char* e = getenv("LXO_XDEC_DEC"); const char* f = getenv("LXO_XDEC"); on = ((e && e[0] == '0') || (f && f[0] == '0')) ? 0 : 1; }
     if (!on) return -2;
     if (U != XU || O != XO || C != XC || E != XE) return -2;
-    if (p.B % 8 != 0 || p.B > 64 || p.nsteps < 1 || p.nsteps > 16 || p.V < 1 || p.V > 512 || !p.stop) return -2;      // 32 workgroups x 16 vocabulary columns; 16 report counters per launch
+    if (p.B % 8 != 0 || p.B > 64 || p.nsteps < 1 || p.nsteps > 16 || p.V < 1 || p.V > 512 || !p.stop) return -2;      // 32 workgroups x 16 vocabulary columns; one counter word per step and launch
     const int nb = p.B / 8;
     if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return -2;
     const int nq = 32 / nb, rows_per = (p.R + nq - 1) / nq;
