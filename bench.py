@@ -405,6 +405,62 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
     return out
 
 
+def real_buckets(torch, dev, V=500, batches=(20, 64), steps=8, warm=3, shapes=None, log=None):
+    """SURVEY 8(f)2 / VERDICT r5 #1: the training step on the reference's REAL image sizes (latex_ocr_amd.synthetic.REAL_BUCKETS =
+    configs/data.json:22-28 after the /2 downsample) at the reference's bucket / evaluation batch (20: data_generator.py:41,
+    evaluate_txt.py:42) and at the benchmark's 64.  Per bucket: ms per step, img/s, us per image, the conv fwd+dgrad and wgrad
+    fractions of the bf16 MFMA peak (HIP events around each launch of one instrumented step, algorithmic FLOPs of THAT shape), the
+    decoder chains' us per step.  Never `value`."""
+    from latex_ocr_amd import synthetic
+    from latex_ocr_amd.engine import Engine
+    from latex_ocr_amd.model.utils.image import pad_batch_images, encoder_out_hw
+    from latex_ocr_amd.model.utils.text import pad_batch_formulas
+    rows = []
+    for (H, W) in (shapes or synthetic.REAL_BUCKETS):
+        lo, hi = synthetic.bucket_lengths(W)
+        for B in batches:
+            try:
+                eng = Engine(V, dtype="bf16", device=dev, seed=0)
+                imgs, forms = synthetic.make_set(B, H, W, V, lo, hi, seed=1234 + H + W)
+                img = torch.from_numpy(pad_batch_images(imgs)).to(dev)
+                f, l = pad_batch_formulas(forms, V - 2, V - 1)
+                f_d = torch.from_numpy(f).to(dev)
+                for _ in range(warm):
+                    eng.train_step(img, f_d, l, 1e-3, sync_loss=False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    eng.train_step(img, f_d, l, 1e-3, sync_loss=False)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                recs, phases = instrumented_step(eng, img, f_d, l, torch)
+                T = int(f.shape[1])
+                Hp, Wp = encoder_out_hw(H, W)
+
+                def fam(names):
+                    sel = [r for r in recs if r[0] in names]
+                    w = sum(r[2] for r in sel); s_ = sum(r[3] for r in sel)
+                    return (round(w / s_ / MFMA_BF16_PEAK, 4), round(s_ * 1e3, 4)) if sel and s_ > 0 else (None, None)
+                cf, cms = fam(("conv_fwd", "conv_dgrad"))
+                wf, wms = fam(("conv_wgrad",))
+                xf = [r for r in recs if r[0] == "xdec_fwd"]; xb = [r for r in recs if r[0] == "xdec_bwd"]
+                row = {"H": H, "W": W, "B": B, "chain_batch": int(eng.shape.B), "T": T, "regions": Hp * Wp,
+                       "ms_per_step": round(dt * 1e3, 3), "img_per_s": round(B / dt, 1), "us_per_image": round(dt * 1e6 / B, 1),
+                       "chains": bool(eng.chain_used and eng.chain_used_bwd),
+                       "conv_fwd_dgrad_frac": cf, "conv_fwd_dgrad_ms": cms, "conv_wgrad_frac": wf, "conv_wgrad_ms": wms,
+                       "chain_fwd_us_per_step": round(xf[0][3] * 1e6 / T, 2) if xf else None,
+                       "chain_bwd_us_per_step": round(xb[0][3] * 1e6 / T, 2) if xb else None,
+                       "ms_by_phase_one_stream": phases}
+                del eng, img, f_d
+            except Exception as e:
+                row = {"H": H, "W": W, "B": B, "error": repr(e)}
+            rows.append(row)
+            if log:
+                log(row)
+            torch.cuda.empty_cache()
+    return rows
+
+
 def cpu_baselines_secondary(eng_train, torch, dev, V):
     """The CPU side of the non-training configurations, bounded samples, never `value`:
     beam-5 decode tokens/s of the oracle (beam_search_decoder_cell.py:123-187 restated) and configs[0] end to end

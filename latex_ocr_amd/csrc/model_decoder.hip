@@ -578,10 +578,11 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             g.nsplit = 1; g.nbatch = B; g.strideA = P.Rp; g.strideB = P.HC; g.strideC = (long long)P.R * C; g.atomic = 0;
             RC(lxo_launch_gemm_tn(P.s.dtype, 1, 1, g, st));
         }
+        if (side) HIPRC(hipStreamWaitEvent(st, g_dbw_init, 0));      // d_mean comes from the side stream (init_bwd / rs_dense above): before its first reader
         RC(lxo_k_add_mean_grad(dimg, dmean, B, P.R, C, st));
         RC(lxo_k_datt_img(P.s.dtype, P.ws<void>(ws, W_ATT_IMG), atth, prm + P.poff[P_BETA], de, P.ws<void>(ws, W_DATTIMG), gw(P_BETA),
                           T, B, P.R, P.Rp, E, det, st));
-        if (side) { HIPRC(hipEventRecord(g_dbw_fork2, st)); HIPRC(hipStreamWaitEvent(st, g_dbw_init, 0)); }
+        if (side) HIPRC(hipEventRecord(g_dbw_fork2, st));
         RC(nt(P, false, true, false, P.ws<void>(ws, W_DATTIMG), E, P.pk(wp, K_ATT_IMG), E, dimg, C, B * P.R, C, E, nullptr, 0, true, st));
     }
     if (side) HIPRC(hipStreamWaitEvent(side, g_dbw_fork2, 0));      // dW_att_img needs d_att_img, nothing needs dW_att_img

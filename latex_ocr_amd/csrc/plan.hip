@@ -200,7 +200,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     wb[W_CARRYH] = BL * U * f4;
     const int ms = s.max_steps > 0 ? s.max_steps : 0;
     if (ms > 0) {
-        wb[W_DEC_IDS] = BK_ * ms * 4;
+        wb[W_DEC_IDS] = BK_ * ms * 4 + 64;                // + the greedy chain's stop word, one int behind the B fed-back ids (model_decoder.hip: x.stop), whatever max_steps
         wb[W_DEC_FLAGS] = 256 + BK_ * 4;
         wb[W_DEC_EMB] = BK_ * Dp * esz;
         wb[W_DEC_TX] = (size_t)(V + 1) * 4 * U * f4;       // row v = embedding_table[v] K[0:D] + b, row V = start_token K[0:D] + b

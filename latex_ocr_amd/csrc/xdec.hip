@@ -76,7 +76,7 @@ constexpr int kPF = LXO_XDEC_PF;
 constexpr int kPFB = LXO_XDEC_PFB;
 
 constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
-constexpr int SCMAX = 2048;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB)
+constexpr int SCMAX = 2432;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB, 58.4 KB used).  2432: the largest bucket of the reference (800 x 800 -> 9604 regions, configs/data.json:28) at B = 64 is 4 chunks of 2401 rows
 
 typedef __attribute__((ext_vector_type(4))) float v4f;
 LXO_DEV v4f mfma16(u32x4 a, u32x4 b, v4f c) {

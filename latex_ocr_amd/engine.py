@@ -230,6 +230,18 @@ class Engine(object):
         backward() regenerates the same masks from the bound shape."""
         B, H, W = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
         T = int(formula.shape[1])
+        # a batch the persistent chains do not take (the reference trains at 3, buckets and evaluates at 20: configs/training.json:6,
+        # data_generator.py:41, evaluate_txt.py:42) is filled up to the next chain batch with DEAD rows: copies of its own samples whose
+        # formula length is 0 (loss() appends the zeros), so no token of theirs is inside the loss mask (img2seq.py:68-71), their d(logits)
+        # and with it every gradient contribution is an exact 0, and n_words does not see them
+        self.live_B = B
+        Bp = B if active_rows is not None else self._train_chain_batch(B, H, W)
+        if Bp != B:
+            img = self._to_dev(img, torch.uint8)
+            formula = self._to_dev(formula, torch.int32)
+            fill = torch.arange(Bp, device=self.device) % B
+            img, formula = img.index_select(0, fill), formula.index_select(0, fill)
+            B = Bp
         self.ensure(B, H, W, T)
         if dropout is not None and 0.0 < float(dropout[0]) < 1.0:
             self.shape.keep_prob = float(dropout[0])
@@ -296,14 +308,17 @@ class Engine(object):
     def _chains_possible(self):
         return self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda" and not self.skip_padded
 
-    def _chain_health_post(self, have_scale):
+    def _chain_health_post(self, have_scale, dp=False):
         """Behind backward(), before the optimizer: lxo_chain_guard (device: scale[0] = NaN when a chain of this step failed, so the optimizer
-        drops the step) + an asynchronous copy of the two error words into a pinned ring slot.  No host synchronisation."""
+        drops the step) + an asynchronous copy of the two error words into a pinned ring slot.  No host synchronisation.
+        The NaN probe element of the gradients (a PEER's chain failed) is only looked at in a data-parallel step: a single process whose
+        gradients are NaN for numeric reasons is not protected from itself -- the reference would write the NaNs into its weights too
+        (img2seq.py:119-123), and a silently dropped update would hide the divergence."""
         st = self._stream()
         if self._health_ring is None:
             self._health_dev = torch.zeros(4, dtype=torch.int32, device=self.device)
             self._health_ring = [{"host": torch.zeros(4, dtype=torch.int32).pin_memory(), "ev": None} for _ in range(4)]
-        self._ck(self.lib.lxo_chain_guard(self.sref(), _p(self.ws), _p(self.grads), _p(self.scale), 1 if have_scale else 0, _p(self._health_dev), st),
+        self._ck(self.lib.lxo_chain_guard(self.sref(), _p(self.ws), _p(self.grads if dp else None), _p(self.scale), 1 if have_scale else 0, _p(self._health_dev), st),
                  "chain_guard")
         slot = self._health_ring[self._health_i % len(self._health_ring)]
         self._health_i += 1
@@ -348,6 +363,12 @@ class Engine(object):
     def loss(self, lengths, inv_ntok=None, ntok_dev=None, ntok_event=None):
         """Loss statistics + d(logits).  Either inv_ntok (host float) or ntok_dev (device float32 [1] = the global token count,
         e.g. from DataParallel.sum_count_async; the compute stream waits for ntok_event, the host does not)."""
+        dead = int(self.shape.B) - int(getattr(self, "live_B", self.shape.B))
+        if dead > 0:                                               # the dead rows forward() appended: length 0 = outside the loss mask
+            if isinstance(lengths, torch.Tensor):
+                lengths = torch.cat([lengths.to(torch.int32), torch.zeros(dead, dtype=torch.int32, device=lengths.device)])
+            else:
+                lengths = np.concatenate([np.asarray(lengths, dtype=np.int32).reshape(-1), np.zeros(dead, np.int32)])
         self._lengths = self._lengths_dev(lengths)
         if ntok_dev is not None:
             if ntok_event is not None:
@@ -475,17 +496,21 @@ class Engine(object):
         elif self.method == 3:
             self.adam_v.fill_(1.0)        # RMSProp rms slot starts at ones
 
-    def optimizer_step(self, lr, clip=-1.0, beta1=0.9, beta2=0.999, eps=1e-8, guard=False):
-        """guard: fold the decoder chains' error words into the scale first (train_step does; a failed step is then dropped on the device)."""
+    def optimizer_step(self, lr, clip=-1.0, beta1=0.9, beta2=0.999, eps=1e-8, guard=False, dp=False):
+        """guard: fold the decoder chains' error words into the scale first (train_step does; a failed step is then dropped on the device).
+        dp: a data-parallel step -- the guard then runs on EVERY bf16 rank whatever this rank's own step_kernels: a rank that already fell
+        back to the launch-per-step kernels must still drop the step a PEER's chain failed in (the peer's NaN probe element arrives through
+        the all-reduce), or the replicas part (its own error words are cleared by the no-chain paths, so the check is harmless there)."""
         st = self._stream()
-        guard = guard and self._chains_possible() and self.ws is not None and self.shape is not None
+        possible = self._chains_possible() or (dp and self.dtype == _abi.LXO_BF16 and self.device.type == "cuda")
+        guard = guard and possible and self.ws is not None and self.shape is not None
         if getattr(self, "method", 0) != 0:
             scale = None
             if clip is not None and clip > 0:
                 self._ck(self.lib.lxo_global_norm_scale(self.n_params, _p(self.grads), ctypes.c_float(clip), _p(self.scale), st), "clip")
                 scale = self.scale
             if guard:
-                self._chain_health_post(scale is not None)
+                self._chain_health_post(scale is not None, dp)
                 scale = self.scale
             self._ck(self.lib.lxo_optimizer_step(self.method, self.n_params, _p(self.params), _p(self.grads), _p(self.adam_v),
                                                  ctypes.c_float(float(lr)), _p(scale), st), "optimizer_step")
@@ -498,7 +523,7 @@ class Engine(object):
             self._ck(self.lib.lxo_global_norm_scale(self.n_params, _p(self.grads), ctypes.c_float(clip), _p(self.scale), st), "clip")
             scale = self.scale
         if guard:
-            self._chain_health_post(scale is not None)
+            self._chain_health_post(scale is not None, dp)
             scale = self.scale
         self._ck(self.lib.lxo_adam_step(self.n_params, _p(self.params), _p(self.grads), _p(self.adam_m), _p(self.adam_v),
                                         ctypes.c_float(lr_t), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
@@ -518,8 +543,11 @@ class Engine(object):
         if self.skip_padded:
             img, formula, lengths, active = self.sort_by_length(img, formula, lengths)
         n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
-        if self._health_ring is not None:
-            self._chain_health_poll()                 # error words of the steps the device has finished meanwhile (no stall)
+        if self._health_ring is not None and dist is None:
+            # error words of the steps the device has finished meanwhile (no stall).  Not under data parallelism: WHEN the host notices a
+            # finished step differs from rank to rank, and the Adam time step a dropped update gives back enters lr_t -- there every rank
+            # looks at a step's words at the same distance (the ring slot's reuse, four steps later, or a synchronising caller's wait)
+            self._chain_health_poll()
         if dist is not None:
             # the global token count travels rank -> device -> all-reduce -> loss kernel; no host sync inside the step
             ntok, ev = dist.sum_count_async(n_local)
@@ -531,7 +559,7 @@ class Engine(object):
         self.backward(comm=dist.reduce_range_fn(self.grads) if dist is not None else None)
         if dist is not None:
             dist.finish()
-        self.optimizer_step(lr, clip, guard=True)
+        self.optimizer_step(lr, clip, guard=True, dp=dist is not None)
         if not sync_loss:
             return None
         if dist is not None:
@@ -589,6 +617,25 @@ class Engine(object):
         self._ck(self.lib.lxo_encoder_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._img), self._stream()),
                  "encoder_fwd")
         return B
+
+    def _train_chain_batch(self, B, H=None, W=None):
+        """The batch the persistent training chains (csrc/xdec.hip: xdec_fwd_kernel / xdec_bwd_kernel) take for B samples -- 8, 16, 32 or 64 --
+        or B itself where they would not run anyway (mirrors lxo_launch_xdec_fwd's conditions).  LXO_TRAIN_PAD=0 / Engine.pad_train = False
+        switch the padding off (the launch-per-step kernels then take the batch as it is)."""
+        d = self.dims
+        if (self.device.type != "cuda" or self.dtype != _abi.LXO_BF16 or self.step_kernels != 0 or self.skip_padded or B >= 64 or B in (8, 16, 32)
+                or not getattr(self, "pad_train", True)
+                or not (d["C"] == 512 and d["U"] == 512 and d["O"] == 512 and d["E"] == 256)
+                or "0" in (os.environ.get("LXO_TRAIN_PAD", "1"), os.environ.get("LXO_XDEC", "1"))):
+            return B
+        Bp = next(n for n in (8, 16, 32, 64) if B < n)
+        if H is not None and not d.get("cnn"):
+            from .model.utils.image import encoder_out_hw
+            Hp, Wp = encoder_out_hw(int(H), int(W))
+            nq = 32 // (Bp // 8)                                    # attention chunks per sample; a chunk's raw scores stay in LDS (xdec.hip: SCMAX rows)
+            if (Hp * Wp + nq - 1) // nq > 2432:
+                return B
+        return Bp
 
     def _decode_chain_batch(self, B):
         """The batch the persistent greedy-decode chain (csrc/xdec.hip: xdec_dec_kernel) takes for B images -- 8, 16, 32 or 64 -- or B itself where

@@ -26,6 +26,19 @@ def make_set(n, H, W, n_tok, len_lo, len_hi, seed=1234, ink=0.08):
     return imgs, forms
 
 
+# The 21 image sizes of the reference's dataset, as (H, W) after the build-time /2 downsample (configs/data.json:22-28 lists them as
+# [W, H] of the rendered PNGs; model/utils/image.py:74-81 `downsample` halves both axes): what DataGenerator's shape buckets
+# (data_generator.py:84-122) actually hand to the model, in groups of 20.
+REAL_BUCKETS = [(50, 120), (40, 160), (40, 200), (50, 200), (40, 240), (50, 240), (40, 280), (50, 280), (40, 320), (50, 320), (40, 360),
+                (50, 360), (60, 360), (100, 360), (50, 400), (160, 400), (100, 500), (200, 500), (100, 600), (100, 800), (800, 800)]
+
+
+def bucket_lengths(W):
+    """Formula-length range used with a bucket of width W in the synthetic sweeps: a rendered formula is about as long as it is wide
+    (~4 .. 16 pixels per token after the downsample), capped by max_length_formula = 150 (configs/data.json:20)."""
+    return max(5, W // 16), min(150, max(8, W // 4)) + 1
+
+
 def config1(seed=1234):
     """100 crops 32x128, vocab 50, lengths U{5..20} (BASELINE.json configs[0])."""
     return make_set(100, 32, 128, 50, 5, 21, seed)

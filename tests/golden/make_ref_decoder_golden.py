@@ -26,7 +26,13 @@ What remains RESTATED (TF primitives, tests/tfshim/tensorflow/__init__.py lists 
 conv / pool / dense / softmax / top_k / argmax / dropout / cross-entropy ops themselves, optimizer update formulas.
 Build container only: /root/reference does not exist on the GPU box; tests read the committed .npz.
 
-    python tests/golden/make_ref_decoder_golden.py
+    python tests/golden/make_ref_decoder_golden.py [--out FILE] [--retrain-toy] [--only-init]
+
+The "toy" read-out weights (`toyw_*`, 35 k numbers) are INPUTS of the fixture, produced once by 220 multi-threaded Adam steps whose
+float summation order is not reproducible; by default they are therefore LOADED from the committed ref_decoder.npz, so that every array
+of the fixture regenerates bit for bit (tests/test_oracle.py::test_ref_decoder_fixture_regenerates_bit_for_bit does that in the build
+container).  --retrain-toy trains them afresh (a new, equally valid fixture whose `*_toy_*` half differs in the last bits and, through
+near-ties, in some decoded ids).
 """
 import os
 import sys
@@ -192,11 +198,24 @@ def adam_trajectory(tag, V, out, steps=5, clip=-1.0):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(HERE, "ref_decoder.npz"))
+    ap.add_argument("--retrain-toy", action="store_true")
+    ap.add_argument("--only-init", action="store_true", help="the v11_init_* / v50_init_* / adam* arrays only (the quick half)")
+    args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     out = {"bias_seed": np.int64(refgold.BIAS_SEED)}
-    for V in (11, 50):
-        train_toy_readout(V, out)
+    committed = os.path.join(HERE, "ref_decoder.npz")
+    if args.retrain_toy or not os.path.exists(committed):
+        for V in (11, 50):
+            train_toy_readout(V, out)
+    else:
+        with np.load(committed) as z:
+            for k in z.files:
+                if k.startswith("toyw_"):
+                    out[k] = z[k].copy()
     for V in (11, 50):
         H, W = refgold.shape_of(V)
         # (1) random-initialisation regime: train graph + gradients; at V = 50 also decode to the step bound of the
@@ -204,6 +223,8 @@ def main():
         imgs, forms = synthetic.make_set(3 if V == 11 else 4, H, W, V, 3 if V == 11 else 5, 7 if V == 11 else 12, seed=5 if V == 11 else 6)
         case("v%d_init_" % V, V, perturbed_params(V), imgs, forms, 12 if V == 11 else 150, out,
              beams=[(2, 1, 0)] if V == 50 else [], greedy=(V == 50))
+        if args.only_init:
+            continue
         # (2) "toy" weights: varied tokens, END at staggered steps, finished-beam masking, parents that move
         imgs, forms = refgold.toy_set(6, H, W, V, 9)
         case("v%d_toy_" % V, V, refgold.toy_params(V, out), imgs, forms, 30, out,
@@ -211,8 +232,8 @@ def main():
     adam_trajectory("adam_", 50, out)
     adam_trajectory("adamclip_", 50, out, steps=3, clip=0.5)
     out["variable_names"] = np.array(sorted(tf.shim_requested()))
-    np.savez_compressed(os.path.join(HERE, "ref_decoder.npz"), **out)
-    print("wrote ref_decoder.npz: %d arrays, %.1f KB" % (len(out), os.path.getsize(os.path.join(HERE, "ref_decoder.npz")) / 1e3))
+    np.savez_compressed(args.out, **out)
+    print("wrote %s: %d arrays, %.1f KB" % (args.out, len(out), os.path.getsize(args.out) / 1e3))
 
 
 if __name__ == "__main__":

@@ -217,9 +217,7 @@ def test_beam5_batch64_f32_identical_and_bf16_agreement(end_checkpoint):
     gref = gref.numpy()
     assert g16.shape == gref.shape, (g16.shape, gref.shape)
     bad = np.argwhere(g16 != gref)
-    for b, t in bad[:12]:
-        top2 = torch.topk(logits[b, t], 2).values
-        print("greedy bf16 mismatch row %d step %d: hip %d oracle %d, oracle top1-top2 margin %.3e" % (b, t, g16[b, t], gref[b, t], float(top2[0] - top2[1])))
+    assert_flips_are_near_ties(g16, gref, logits.numpy(), "greedy bf16, B = 64 at 128x512")      # a flip must be a near-tie of the oracle's logits: asserted
     print("greedy bf16, 64 crops at 128x512: agreement %.4f (%d of %d tokens differ)" % (float((g16 == gref).mean()), len(bad), gref.size))
     assert (g16 == gref).mean() >= 0.999       # measured 640 of 640 tokens
 

@@ -133,11 +133,11 @@ class _FaultyEngine(Engine):
             self._poke(False, 7)
         return Engine.chain_status(self, backward)
 
-    def _chain_health_post(self, have_scale):
+    def _chain_health_post(self, have_scale, dp=False):
         if self.fault_guard:                                     # a later step's chain breaks: seen by the device-side guard only
             self.fault_guard -= 1
             self._poke(True, 7)
-        return Engine._chain_health_post(self, have_scale)
+        return Engine._chain_health_post(self, have_scale, dp)
 
 
 def test_engine_falls_back_when_a_chain_reports_an_error():

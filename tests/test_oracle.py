@@ -245,3 +245,20 @@ def test_adam_trajectory_pinned_to_reference_wiring(tag, steps):
     got = P["Encoder/convolutional_encoder/conv2d/kernel"].numpy().reshape(-1)[::7]
     # Adam turns a gradient's rounding noise into an O(lr) step wherever |g| ~ eps: hold conv1 to 1 % of the 5e-3 it may travel
     assert np.abs(got - REFDEC[tag + "final_conv0_sample"]).max() <= 5e-5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="build container only: the reference's Python is imported from /root/reference")
+def test_ref_decoder_fixture_regenerates_bit_for_bit(tmp_path):
+    """tests/golden/ref_decoder.npz is what the reference's UNCHANGED graph-building code (img2seq.py, encoder.py, decoder.py, components/*)
+    produces under tests/tfshim -- every array of it, also the early-exit / staggered-END / moving-parents legs on the "toy" weights: the
+    generator loads the committed `toyw_*` INPUT weights (its 220-step multi-threaded toy training is not reproducible to the bit; round 5's
+    fixture could not be re-derived) and everything compared is then a deterministic function of committed inputs."""
+    import subprocess
+    import sys
+    out = str(tmp_path / "regen.npz")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_ref_decoder_golden.py")
+    subprocess.check_call([sys.executable, script, "--out", out], stdout=subprocess.DEVNULL)
+    with np.load(out) as a, np.load(os.path.join(os.path.dirname(script), "ref_decoder.npz")) as b:
+        assert sorted(a.files) == sorted(b.files)
+        bad = [k for k in b.files if a[k].dtype != b[k].dtype or not np.array_equal(a[k], b[k])]
+        assert not bad, bad[:10]
