@@ -614,13 +614,25 @@ def main():
     dp_info = None
     if dist is not None:
         # per-rank step time and exposed all-reduce wait, gathered before the MAX that defines `value`
-        mine = torch.zeros(world, 2, dtype=torch.float64, device=dev)
+        mine = torch.zeros(world, 6, dtype=torch.float64, device=dev)
         ex = dist.exposed_allreduce_ms() if not args.sim else None
+        if getattr(eng, "_health_ring", None) is not None:
+            eng._chain_health_poll(wait=True)                    # the device is idle (sync above): every posted step's chain error words are in
         mine[rank, 0] = dt / args.steps * 1e3
         mine[rank, 1] = -1.0 if ex is None else ex
+        mine[rank, 2] = eng.chain_failures
+        mine[rank, 3] = getattr(eng, "dropped_steps", 0)
+        mine[rank, 4] = 1.0 if eng.step_kernels != int(os.environ.get("LXO_STEP_KERNELS", "0")) else 0.0     # this rank left the persistent chains for the launch-per-step kernels
+        mine[rank, 5] = 1.0 if (eng.chain_used and eng.chain_used_bwd) else 0.0
         dist.all_reduce(mine)
         dp_info = {"per_rank_ms_per_step": [round(float(x), 3) for x in mine[:, 0].tolist()],
                    "exposed_allreduce_ms_per_step": [round(float(x), 3) for x in mine[:, 1].tolist()],
+                   # health of the persistent decoder chains next to RCCL's kernels, per rank: a chain that does not assemble drops its step on
+                   # EVERY rank (lxo_chain_guard) and moves that rank to the launch-per-step kernels -- a silent 8-GPU slow path must show here
+                   "chains_ran": [bool(x) for x in mine[:, 5].tolist()],
+                   "chain_failures": [int(x) for x in mine[:, 2].tolist()],
+                   "dropped_steps": [int(x) for x in mine[:, 3].tolist()],
+                   "fell_back": [bool(x) for x in mine[:, 4].tolist()],
                    "gradient_dtype": "bf16" if getattr(dist, "grad_dtype", None) is not None else "f32",
                    # how many ranks the RCCL communicator itself reports (ncclCommCount through lxo_comm_info): proves N ranks met on RCCL
                    "rccl_ranks_seen": dist.lxo.ranks_seen if getattr(dist, "lxo", None) is not None else None,

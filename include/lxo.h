@@ -24,10 +24,11 @@ extern "C" {
 const char* lxo_last_error(void);
 /* ABI version of this header.  Bumped whenever lxo_shape grows or an entry point changes (round 4: 4 -- lxo_comm_*,
  * lxo_allreduce_bucket, LXO_GNORM_FLOATS behind lxo_global_norm_scale's scale_out; round 5: 5 -- lxo_shape.deterministic,
- * lxo_chain_guard, lxo_decode_state_get / _set, lxo_decode_cell_step; a NaN *scale_dev drops an optimizer step).  A binding must check
+ * lxo_chain_guard, lxo_decode_state_get / _set, lxo_decode_cell_step; a NaN *scale_dev drops an optimizer step; round 6: 6 --
+ * lxo_beam_decode_attn).  A binding must check
  * lxo_version() == LXO_ABI_VERSION and lxo_shape_size() == sizeof(its own lxo_shape) before the first call: a caller built
  * against an older header passes a shorter struct and the library would read past its end. */
-#define LXO_ABI_VERSION 5
+#define LXO_ABI_VERSION 6
 int lxo_version(void);
 int lxo_shape_size(void);
 
@@ -322,6 +323,15 @@ int lxo_decode_cell_step(const lxo_shape* s, const float* params, const void* wp
 int lxo_beam_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                     int id_end, int max_iter, int32_t* ids_out, int32_t* parents_out,
                     int* steps_out, void* stream);
+/* lxo_beam_decode that also exports the attention weights: alpha_out f32 [max_steps][B * beam][Rp] (device), Rp = (R+7)/8*8 --
+ * entry [t][b * beam + j] = the weights decoder row j of image b attended with AT step t, i.e. of hypothesis slot j as it stood
+ * BEFORE step t's top-k re-ordering: the rows the reference's tf.py_func tap sees on the merged batch x beam tensor when
+ * config.decoding == "beam_search" (attention_mechanism.py:59-65,96-121; the shipped configs/model.json:13-14 decodes with beam 2).
+ * The token ids_out[b][t][i] was read off row parents_out[b][t][i] of that step, so the map under which token i of step t was emitted is
+ * alpha_out[t][b * beam + parents_out[b][t][i]] (time 0: every slot descends from row 0, whose k copies are identical). */
+int lxo_beam_decode_attn(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                         int id_end, int max_iter, int32_t* ids_out, int32_t* parents_out, float* alpha_out,
+                         int* steps_out, void* stream);
 
 /* ---- data parallel: one process per GPU, RCCL over xGMI -------------------------------------
  * The reference trains on one device (one sess.run per step, model/img2seq.py:169).  Samples are independent through encoder,

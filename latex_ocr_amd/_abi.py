@@ -14,7 +14,7 @@ LXO_GNORM_FLOATS = 2 + 1024   # include/lxo.h: floats lxo_global_norm_scale need
 LIB_PATH = os.environ.get("LXO_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblxo.so")   # the override is a measurement aid (diagnostic builds)
 
 
-ABI_VERSION = 5          # include/lxo.h LXO_ABI_VERSION
+ABI_VERSION = 6          # include/lxo.h LXO_ABI_VERSION
 LXO_COMM_ID_BYTES = 128
 LXO_I32, LXO_U8 = 2, 3
 LXO_XDEC_BLOCK_BYTES, LXO_XDEC_ERR_WORD = 4096 + (384 << 10), 512      # include/lxo.h: the chains' error words in ws region "xdec_sync"
@@ -74,6 +74,7 @@ def bind(lib):
         "lxo_decode_begin": (c_int, [S, c_void, c_void, c_void, c_void]),
         "lxo_decode_step": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, c_void, P(c_int), c_void]),
         "lxo_beam_decode": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, P(c_int), c_void]),
+        "lxo_beam_decode_attn": (c_int, [S, c_void, c_void, c_void, c_int, c_int, c_void, c_void, c_void, P(c_int), c_void]),
         "lxo_chain_guard": (c_int, [S, c_void, c_void, c_void, c_int, c_void, c_void]),
         "lxo_decode_state_get": (c_int, [S, c_void, c_int, c_void, c_void, c_void, c_void]),
         "lxo_decode_state_set": (c_int, [S, c_void, c_int, c_void, c_void, c_void, c_void, c_void]),
@@ -106,7 +107,7 @@ ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_shape_size", "lxo_ws_regio
                 "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
                 "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_encoder_bwd_ready", "lxo_train_bwd", "lxo_set_side_stream", "lxo_set_encoder_side_stream", "lxo_decoder_train_fwd", "lxo_decoder_train_fwd_active", "lxo_decoder_train_bwd_active",
                 "lxo_ce_loss_fwd_bwd", "lxo_ce_loss_fwd_bwd_dev", "lxo_decoder_train_bwd", "lxo_decoder_train_bwd_part", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",
-                "lxo_greedy_decode", "lxo_greedy_decode_attn", "lxo_beam_decode", "lxo_decode_begin", "lxo_decode_step",
+                "lxo_greedy_decode", "lxo_greedy_decode_attn", "lxo_beam_decode", "lxo_beam_decode_attn", "lxo_decode_begin", "lxo_decode_step",
                 "lxo_chain_guard", "lxo_decode_state_get", "lxo_decode_state_set", "lxo_decode_cell_step",
                 "lxo_comm_unique_id", "lxo_comm_init", "lxo_comm_info", "lxo_allreduce_bucket", "lxo_comm_destroy", "lxo_comm_last_error"]
 

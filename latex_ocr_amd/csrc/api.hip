@@ -211,7 +211,14 @@ extern "C" int lxo_decode_step(const lxo_shape* s, const float* params, const vo
 extern "C" int lxo_beam_decode(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                                int id_end, int max_iter, int32_t* ids_out, int32_t* parents_out, int* steps_out, void* stream) {
     MAKE_PLAN(P, s);
-    CHECK_LAUNCH(lxo_impl_beam_decode(P, params, wpack, ws, id_end, max_iter, ids_out, parents_out, steps_out, (hipStream_t)stream), "lxo_beam_decode");
+    CHECK_LAUNCH(lxo_impl_beam_decode(P, params, wpack, ws, id_end, max_iter, ids_out, parents_out, nullptr, steps_out, (hipStream_t)stream), "lxo_beam_decode");
+    return 0;
+}
+extern "C" int lxo_beam_decode_attn(const lxo_shape* s, const float* params, const void* wpack, void* ws,
+                                    int id_end, int max_iter, int32_t* ids_out, int32_t* parents_out, float* alpha_out, int* steps_out, void* stream) {
+    MAKE_PLAN(P, s);
+    if (!alpha_out) return fail(-1, "lxo_beam_decode_attn: null alpha_out");
+    CHECK_LAUNCH(lxo_impl_beam_decode(P, params, wpack, ws, id_end, max_iter, ids_out, parents_out, alpha_out, steps_out, (hipStream_t)stream), "lxo_beam_decode_attn");
     return 0;
 }
 

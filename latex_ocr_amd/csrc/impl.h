@@ -18,7 +18,7 @@ int lxo_impl_chain_guard(const Plan& P, void* ws, const float* grads, float* sca
 int lxo_impl_decode_state_get(const Plan& P, void* ws, int time, float* c, float* h, float* o, hipStream_t st);
 int lxo_impl_decode_state_set(const Plan& P, void* ws, int time, const float* c, const float* h, const float* o, const int* ids_prev, hipStream_t st);
 int lxo_impl_decode_cell_step(const Plan& P, const float* prm, const void* wp, void* ws, int time, int start_token, hipStream_t st);
-int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, int* parents_out, int* steps_out, hipStream_t st);
+int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, int* parents_out, float* alpha_out, int* steps_out, hipStream_t st);
 int lxo_impl_set_side_stream(hipStream_t s);
 int lxo_impl_set_encoder_side_stream(hipStream_t s);
 // optional row-BiLSTM encoder (model_rowenc.hip): features in ws region "img" in place; backward: "d_img" (f32) in place + parameter gradients

@@ -899,7 +899,7 @@ int lxo_impl_decode_step(const Plan& P, const float* prm, const void* wp, void* 
 }
 
 int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter,
-                         int* ids_out, int* parents_out, int* steps_out, hipStream_t st) {
+                         int* ids_out, int* parents_out, float* alpha_out, int* steps_out, hipStream_t st) {
     const int B = P.s.B, k = P.s.beam, ms = P.s.max_steps, nv = B * k, U = P.s.U;
     if (ms < max_iter + 1 || k < 1 || k > 16) return -5;
     RC(attention_prepare(P, prm, wp, ws, k, st));
@@ -918,6 +918,9 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
     RC(decode_loop(max_iter, flags, st, steps_out, [&](int time, int* unfinished) -> int {
         const int cur = (time + 1) & 1;
         RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st));
+        if (alpha_out)      // the attention weights of this step's B x k decoder rows, as they ran (row b * k + j = hypothesis slot j BEFORE this step's
+                            // re-ordering: what the reference's py_func tap sees on the merged batch x beam rows, attention_mechanism.py:59-65,96-105)
+            HIPRC(hipMemcpyAsync(alpha_out + (size_t)time * nv * P.Rp, P.ws<float>(ws, W_ALPHA), (size_t)nv * P.Rp * 4, hipMemcpyDeviceToDevice, st));
         RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, P.s.div_gamma, P.s.div_prob, P.s.div_seed, tmp,
                            logp, finished, ids_step, par_step,
                            ids_out, parents_out, ms, unfinished, st));

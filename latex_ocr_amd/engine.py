@@ -744,9 +744,11 @@ class Engine(object):
         Vp = (self.n_tok + 31) // 32 * 32
         return self.region("dec_logits", "f32", (self._dec_rows(), Vp))[:, :self.n_tok].cpu().numpy()
 
-    def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False, div_gamma=1.0, div_prob=0.0, div_seed=0):
+    def beam_decode(self, img, id_end, beam_size, max_iter=151, return_parents=False, div_gamma=1.0, div_prob=0.0, div_seed=0, return_attention=False):
         """ids int32 [B, T', k] as pred_test.ids of the beam graph before the transpose at img2seq.py:241.
-        div_gamma / div_prob: add_div_penalty of beam_search_decoder_cell.py:258-287 (off at 1 / 0, the shipped values)."""
+        div_gamma / div_prob: add_div_penalty of beam_search_decoder_cell.py:258-287 (off at 1 / 0, the shipped values).
+        return_attention: -> (ids, parents, alpha f32 [B, T', k, H', W']): alpha[b, t, j] = the map decoder row j of image b attended with at
+        step t (lxo_beam_decode_attn; the rows the reference's py_func tap sees under config.decoding = "beam_search")."""
         if self.max_steps < max_iter + 1:
             self.max_steps, self.ws = max_iter + 1, None
         B = self._encode_only(img, int(beam_size))
@@ -755,6 +757,17 @@ class Engine(object):
         ids = torch.zeros(B, self.max_steps, beam_size, dtype=torch.int32, device=self.device)
         par = torch.zeros(B, self.max_steps, beam_size, dtype=torch.int32, device=self.device)
         steps = ctypes.c_int(0)
+        if return_attention:
+            from .model.utils.image import encoder_out_hw
+            Hp, Wp = encoder_out_hw(int(img.shape[1]), int(img.shape[2]))
+            R = Hp * Wp
+            Rp = (R + 7) // 8 * 8
+            alpha = torch.zeros(self.max_steps, B * beam_size, Rp, dtype=torch.float32, device=self.device)
+            self._ck(self.lib.lxo_beam_decode_attn(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(max_iter),
+                                                   _p(ids), _p(par), _p(alpha), ctypes.byref(steps), self._stream()), "beam_decode_attn")
+            n = steps.value
+            a = alpha[:n, :, :R].reshape(n, B, beam_size, Hp, Wp).permute(1, 0, 2, 3, 4).contiguous().cpu().numpy()
+            return ids[:, :n].cpu().numpy(), par[:, :n].cpu().numpy(), a
         self._ck(self.lib.lxo_beam_decode(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), int(id_end), int(max_iter),
                                           _p(ids), _p(par), ctypes.byref(steps), self._stream()), "beam_decode")
         out = ids[:, :steps.value].cpu().numpy()

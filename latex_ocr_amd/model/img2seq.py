@@ -178,10 +178,30 @@ class Img2SeqModel(BaseModel):
         return [hyp[0] for hyp in self.predict_batch([img])]
 
     def predict_with_attention(self, img):
-        """Greedy hypothesis of one image plus its per-token attention maps [T', H', W'] -- the data the reference
-        gathers in the global `ctx_vector` through tf.py_func (attention_mechanism.py:96-105) for visualize_attention.py."""
+        """Best hypothesis of one image plus its per-step attention maps [T', H', W'] -- the data the reference gathers in the global
+        `ctx_vector` through tf.py_func (attention_mechanism.py:96-121) for visualize_attention.py -- under WHATEVER config.decoding says
+        (the shipped configs/model.json:13-14 decodes with beam_search, k = 2).
+        Beam search: the reference's visualiser draws row 0 of the merged batch x beam tensor of every step (`attentionVector[0]`,
+        visualize_attention.py:55), for every step the loop ran -- it ends when ALL beams have finished, so there are more slices than tokens
+        in the best hypothesis (51 slices for 48 tokens at k = 2); that is what comes back here.  With the
+        `beam_backtrace` extension each step's map is the one of the row its best token was read off (parents[t][0])."""
         fd = self._get_feed_dict([img], dropout=1)
-        max_iter = getattr(self._config, "max_length_formula", 150) + 1
-        ids, alpha = self.engine.greedy_decode(fd["img"], self._vocab.id_end, max_iter=max_iter, return_attention=True)
-        p = truncate_end(ids[0], self._vocab.id_end)
-        return " ".join(self._vocab.id_to_tok[int(i)] for i in p), alpha[0]
+        cfg = self._config
+        max_iter = getattr(cfg, "max_length_formula", 150) + 1
+        if getattr(cfg, "decoding", "greedy") == "beam_search":
+            self._div_calls = getattr(self, "_div_calls", 0) + 1
+            ids, par, alpha = self.engine.beam_decode(fd["img"], self._vocab.id_end, cfg.beam_size, max_iter=max_iter,
+                                                      div_gamma=getattr(cfg, "div_gamma", 1), div_prob=getattr(cfg, "div_prob", 0),
+                                                      div_seed=self._div_calls, return_attention=True)
+            if getattr(cfg, "beam_backtrace", False):
+                from .utils.text import beam_backtrace
+                maps = np.stack([alpha[0, t, par[0, t, 0]] for t in range(alpha.shape[1])])
+                ids = beam_backtrace(ids, par)
+            else:
+                maps = alpha[0, :, 0]
+            best = ids[0, :, 0]
+        else:
+            ids, alpha = self.engine.greedy_decode(fd["img"], self._vocab.id_end, max_iter=max_iter, return_attention=True)
+            best, maps = ids[0], alpha[0]
+        p = truncate_end(best, self._vocab.id_end)
+        return " ".join(self._vocab.id_to_tok[int(i)] for i in p), maps

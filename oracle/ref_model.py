@@ -412,9 +412,10 @@ def add_div_penalty(lp, div_gamma, div_prob, div_seed, time):
     return lp + pen.reshape(B, k, V)
 
 
-def beam_decode(P, img_u8, id_end, beam_size, max_iter=151, positional=True, div_gamma=1.0, div_prob=0.0, div_seed=0):
+def beam_decode(P, img_u8, id_end, beam_size, max_iter=151, positional=True, div_gamma=1.0, div_prob=0.0, div_seed=0, return_alpha=False):
     """beam_search_decoder_cell.py:98-250 (`finalize` never follows parents, quirk C-1, so hypothesis
-    i is ids[:, t, i] at every t).  Returns int32 [B, T', k] and the parents."""
+    i is ids[:, t, i] at every t).  Returns int32 [B, T', k] and the parents; with return_alpha also the attention weights
+    [B, T', k, R] of the merged batch x beam rows as each step ran (what the py_func tap of attention_mechanism.py:96-121 is handed)."""
     enc = encoder(P, img_u8, positional)
     img, att_img, (c, h, o) = attention_prepare(P, enc)
     B, k = img.shape[0], beam_size
@@ -427,10 +428,11 @@ def beam_decode(P, img_u8, id_end, beam_size, max_iter=151, positional=True, div
     log_probs = torch.zeros(B, k)
     finished = torch.zeros(B, k, dtype=torch.bool)
     fmin = torch.finfo(torch.float32).min
-    ids_all, par_all = [], []
+    ids_all, par_all, alpha_all = [], [], []
     time = 0
     while not bool(finished.all()):
-        logits, new_state = cell_step(P, img_t, att_t, emb, state)           # :137
+        logits, new_state, alpha = cell_step(P, img_t, att_t, emb, state, return_alpha=True)           # :137
+        alpha_all.append(alpha.reshape(B, k, -1))
         step_lp = F.log_softmax(logits.reshape(B, k, V), dim=-1)             # :146
         one_hot = torch.full((V,), fmin); one_hot[id_end] = 0.0              # :353-367
         fin = finished.to(torch.float32)[:, :, None]
@@ -451,6 +453,8 @@ def beam_decode(P, img_u8, id_end, beam_size, max_iter=151, positional=True, div
         if time >= max_iter:
             finished = torch.ones_like(finished)
         time += 1
+    if return_alpha:
+        return torch.stack(ids_all, dim=1), torch.stack(par_all, dim=1), torch.stack(alpha_all, dim=1)
     return torch.stack(ids_all, dim=1), torch.stack(par_all, dim=1)
 
 

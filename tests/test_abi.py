@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared and set(declared) == set(_abi.ENTRY_POINTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.lxo_version() == _abi.ABI_VERSION == 5
+    assert lib.lxo_version() == _abi.ABI_VERSION == 6
     assert lib.lxo_shape_size() == ctypes.sizeof(_abi.LxoShape)
 
 

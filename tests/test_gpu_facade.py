@@ -58,6 +58,10 @@ def test_train_eval_predict(tmp_path, monkeypatch):
         m.build_pred()
         hyps.append((m.predict(img), m.predict_with_attention(img)))
     assert hyps[0][0] == hyps[1][0] and hyps[0][1][0] == hyps[1][1][0]
+    # the attention path honours config.decoding (the shipped model.json decodes with beam_search, k = 2): the same best hypothesis as
+    # predict(), and one attention slice per STEP of the loop -- it runs until every beam has finished, so >= tokens + END
+    assert m._config.decoding == "beam_search" and hyps[1][1][0] == hyps[1][0][0]
+    assert hyps[1][1][1].ndim == 3 and hyps[1][1][1].shape[0] >= len(hyps[1][1][0].split()) and abs(float(hyps[1][1][1][0].sum()) - 1.0) < 1e-2
     assert np.array_equal(hyps[0][1][1], hyps[1][1][1])
     import visualize_attention as VA
     hyp, files = VA.vis_img_with_attention(m, "data/synthetic/test/" + img_path, "results/tf/")

@@ -260,3 +260,39 @@ def test_skip_padded_steps_same_loss_and_gradients(dtype, tol):
             assert np.abs(a0 - a1).max() <= 2e-5 * max(np.abs(a0).max(), 1e-6) + 1e-9, k
         else:
             assert cosine(a0, a1) > 0.98, (k, cosine(a0, a1))
+
+
+def test_beam_attention_export_f32():
+    """lxo_beam_decode_attn: the attention weights of every decoder row (image x hypothesis slot) of every beam-search step, as the step ran
+    -- what the reference's py_func tap is handed on the merged batch x beam tensor under config.decoding = "beam_search"
+    (attention_mechanism.py:59-65,96-121; configs/model.json:13-14 ships beam_search, k = 2) -- against the oracle's, with ids and
+    parents still identical; at time 0 the k rows of an image are copies of one state, so their maps are equal."""
+    V = 50
+    imgs, _ = synthetic.config1()
+    img = pad_batch_images(imgs[:5])
+    eng = Engine(V, dtype="f32", seed=4)
+    for k in (2, 3):
+        ids, par, alpha = eng.beam_decode(img, V - 1, k, max_iter=9, return_attention=True)
+        rid, rpar, ralpha = R.beam_decode(oracle_params(eng), torch.from_numpy(img), V - 1, k, max_iter=9, return_alpha=True)
+        assert np.array_equal(ids, rid.numpy()) and np.array_equal(par, rpar.numpy())
+        B, T = ids.shape[:2]
+        assert alpha.shape[:3] == (B, T, k)
+        a = alpha.reshape(B, T, k, -1)
+        assert np.abs(a - ralpha.numpy()).max() < 1e-6, np.abs(a - ralpha.numpy()).max()
+        assert np.abs(a.sum(-1) - 1).max() < 1e-5
+        assert np.array_equal(a[:, 0, 0], a[:, 0, k - 1])
+    # the plain call is unchanged by the export
+    assert np.array_equal(eng.beam_decode(img, V - 1, 3, max_iter=9), ids)
+
+
+def test_beam_attention_export_bf16():
+    V = 50
+    imgs, _ = synthetic.config1()
+    img = pad_batch_images(imgs[:8])
+    eng = Engine(V, dtype="bf16", seed=4)
+    ids, par, alpha = eng.beam_decode(img, V - 1, 2, max_iter=9, return_attention=True)
+    rid, rpar, ralpha = R.beam_decode(oracle_params(eng), torch.from_numpy(img), V - 1, 2, max_iter=9, return_alpha=True)
+    B, T = ids.shape[:2]
+    a = alpha.reshape(B, T, 2, -1)
+    assert np.abs(a.sum(-1) - 1).max() < 1e-3
+    assert np.abs(a[:, 0] - ralpha.numpy()[:, 0]).max() < 2e-2 * ralpha.numpy()[:, 0].max()      # step 0: the same state on both sides

@@ -5,6 +5,8 @@ lxo_shape.step_kernels = 2), which is itself held to the oracle and to the refer
 Both compute the same mathematics in bf16 mode (same operand roundings, same transcendental forms); the contraction of a step GEMM is
 split over 8 waves instead of 4, so sums differ in the last f32 bits and a bf16 mirror may round the other way here and there.  Every
 batch size the chain takes (8, 16, 32, 64: one to eight samples per XCD), dropout, and the error word / ticket counters of the chain."""
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -382,3 +384,52 @@ def test_ready_events_fire_when_a_buckets_gradients_are_final():
             final = eng.grads[lo:hi]
             assert torch.isfinite(final).all() and float(final.abs().max()) > 0, k
             assert torch.equal(snaps[k], final), (rep, k, float((snaps[k] - final).abs().max()))
+
+
+def test_a_foreign_kernel_holding_a_cu_breaks_the_chain_and_the_guard_drops_exactly_that_step():
+    """No injected error word here: a FOREIGN kernel (torch's one-wave spin kernel on a third stream) holds one CU for ~0.7 s while a
+    training step launches its chains.  A chain workgroup needs a whole CU (8 waves x 255 VGPRs, 158 KB LDS), so one XCD gets 31 of its 32
+    workgroups until the foreigner leaves: the chain's bounded waits (200 ms) give up, leave the error word, the loss kernel's backstop and
+    lxo_chain_guard drop the step ON THE DEVICE (weights and Adam slots bit-identical to before it), nothing hangs; the next train_step
+    learns of it without a stall, takes the dropped update's Adam time step back and continues on the launch-per-step kernels -- from there
+    on the run IS the fallback's run: same weights as an engine that ran the launch-per-step kernels throughout and never saw that batch.
+    (The situation at N > 1: a collective kernel of a lagging peer resident when a chain launches.)"""
+    b1 = batch(16, 48, 160, V, 5, 24, seed=41)
+    b2 = batch(16, 48, 160, V, 5, 24, seed=42)
+    b3 = batch(16, 48, 160, V, 5, 24, seed=43)
+    eng = Engine(V, dtype="bf16", seed=8, deterministic=True)
+    ref = Engine(V, dtype="bf16", seed=8, deterministic=True)
+    ref.step_kernels = 2
+    eng.train_step(*b1, 1e-3, sync_loss=False)
+    torch.cuda.synchronize()
+    assert eng.chain_used and eng.chain_used_bwd and eng.adam_t == 1
+    before, m_before = eng.params.clone(), eng.adam_m.clone()
+    # how long one spin cycle of torch.cuda._sleep is on this box
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
+    per_ms = 20_000_000 / e0.elapsed_time(e1)
+    foreign = torch.cuda.Stream()
+    with torch.cuda.stream(foreign):
+        torch.cuda._sleep(int(700 * per_ms))                     # ~0.7 s on one CU: longer than the forward chain's 200 ms patience
+    t0 = time.perf_counter()
+    eng.train_step(*b2, 1e-3, sync_loss=False)                   # its chains cannot assemble
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    assert waited < 5.0, waited                                  # bounded: the chains gave up, nothing hung
+    assert torch.equal(eng.params, before) and torch.equal(eng.adam_m, m_before)      # the step was dropped on the device
+    with pytest.warns(RuntimeWarning, match="did not assemble"):
+        eng.train_step(*b3, 1e-3, sync_loss=False)               # the host learns of it here, without a stall
+    torch.cuda.synchronize()
+    eng._chain_health_poll(wait=True)
+    assert eng.step_kernels == 2 and eng.chain_failures == 1 and getattr(eng, "dropped_steps", 0) == 1 and eng.adam_t == 2
+    # the fallback's run: launch-per-step kernels throughout, batches 1 and 3
+    ref.train_step(*b1, 1e-3, sync_loss=False)
+    ref.train_step(*b3, 1e-3, sync_loss=False)
+    torch.cuda.synchronize()
+    c = cosine(eng.params.cpu().numpy(), ref.params.cpu().numpy())
+    d = float((eng.params - ref.params).abs().max())
+    print("foreign kernel: the broken step took %.2f s; weights vs the fallback's run: cosine %.9f, max |diff| %.2e" % (waited, c, d))
+    assert c > 0.999999 and d <= 5e-3                            # step 1 ran on the chains here, on the launch-per-step kernels there (bf16 K-split noise through one Adam step of lr 1e-3)
+    la = eng.train_step(*b1, 1e-3)                               # and both continue alike
+    lb = ref.train_step(*b1, 1e-3)
+    assert abs(la - lb) <= 2e-3 * abs(lb), (la, lb)
