@@ -399,6 +399,14 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
         eng_train.train_step(b.img, b.formula, b.lengths, 1e-3, sync_loss=False); n += 1
     torch.cuda.synchronize()
     dtp = (time.perf_counter() - t0) / max(n, 1)
+    try:
+        rows = real_buckets(torch, dev, V=V, batches=(20, 64), steps=4, warm=2)
+        keep = ("H", "W", "B", "chain_batch", "T", "regions", "ms_per_step", "img_per_s", "us_per_image", "chains", "conv_fwd_dgrad_frac", "conv_wgrad_frac",
+                "chain_fwd_us_per_step", "chain_bwd_us_per_step", "error")
+        out["real_buckets"] = {"rows": [{k: r[k] for k in keep if k in r} for r in rows],
+                               "note": "one training step (bf16, V=%d, Adam) on each of the reference's 21 image sizes (configs/data.json:22-28 after the build-time /2 downsample) at the reference's bucket / evaluation batch 20 (data_generator.py:41, evaluate_txt.py:42; filled up to a chain batch of 32 with dead rows) and at 64; formula lengths per latex_ocr_amd.synthetic.bucket_lengths; conv fractions = algorithmic FLOPs of THAT shape / HIP-event time of the launches / 2.5 PFLOP/s; chain us per step = whole persistent launch / T; 4 timed steps per row (tools/real_buckets.py takes 8; profiles/r06_buckets.json)" % V}
+    except Exception as e:
+        out["real_buckets"] = {"error": repr(e)}
     out["pipeline_fed"] = {"img_per_s": round(B / dtp, 1), "ms_per_step": round(dtp * 1e3, 3), "steps": n, "host_pad_ms_per_batch": round(t_host * 1e3, 2),
                            "h2d_bytes_per_batch": int(B * H * W + B * 101 * 4),
                            "note": "fresh host lists every step through latex_ocr_amd.pipeline.Prefetcher (depth 3): padding on a background thread, pinned staging, copy stream; T varies per batch (batch-max + 1)"}
@@ -729,6 +737,11 @@ def main():
                         "source": "in-kernel 100 MHz timestamps (lxo_xdec_debug_bwd), as for the forward chain"}
             for key in ("roofline_attention", "roofline_attention_bwd"):
                 r = out.get(key)
+                if r and r.get("whole_chain_GBps"):
+                    # `frac` above prices the STREAM PHASE of a step (P3 / Q2 + the wait behind it); the launch as a whole also runs the step's serial
+                    # phases (LSTM / att_h / o-projection GEMMs, hand-overs), during which nothing streams: algorithmic bytes of all T steps / launch time
+                    r["whole_launch_frac"] = round(r["whole_chain_GBps"] * 1e9 / HBM_PEAK, 4)
+                    r["frac_is"] = "stream phase only; whole_launch_frac = the same bytes over the whole persistent launch"
                 if r and r.get("traffic") and r.get("avg_launch_us"):
                     # `achieved` counts ALGORITHMIC bytes (every region row of att_exp + img once per step); consecutive steps walk the chunk in
                     # opposite directions, so part of them is still in the XCD's L2 -- the PMC traffic is what HBM / Infinity Cache delivered
@@ -740,21 +753,6 @@ def main():
                                                 "launches (encoder, and the decoder's deferred ones) with the data-gradient path on a second stream, "
                                                 "so the phases sum to more than ms_per_step")
             if world == 1:
-                # secondary, NOT the headline: the opt-in extension that runs each decoder step only for the samples still
-                # inside their formula (same loss and gradients; the reference and `value` above run every padded step)
-                eng.skip_padded = True
-                for _ in range(2):
-                    step()
-                sync()
-                t1 = time.perf_counter()
-                for _ in range(min(args.steps, 10)):
-                    step()
-                sync()
-                dts = (time.perf_counter() - t1) / min(args.steps, 10)
-                eng.skip_padded = False
-                out["extension_skip_padded_steps"] = {"value": round(B / dts, 2), "unit": "img/s", "ms_per_step": round(dts * 1e3, 3),
-                                                      "slower_than_headline": bool(dts * 1e3 > ms),
-                                                      "note": "not the headline metric (the reference and `value` run every padded step): padded (sample, step) pairs skipped, batch sorted by length, same loss and gradients (tests/test_gpu_parity.py).  Since round 4 this is SLOWER than the headline: the persistent decoder chains do not take per-step row counts, so the extension runs the launch-per-step kernels (covering active[t] rows per step) and gives back more than the skipped steps save"}
                 if not args.no_secondary:
                     try:
                         out["secondary"] = secondary(args, eng, torch, dev, B, H, W, V)

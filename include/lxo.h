@@ -25,7 +25,7 @@ const char* lxo_last_error(void);
 /* ABI version of this header.  Bumped whenever lxo_shape grows or an entry point changes (round 4: 4 -- lxo_comm_*,
  * lxo_allreduce_bucket, LXO_GNORM_FLOATS behind lxo_global_norm_scale's scale_out; round 5: 5 -- lxo_shape.deterministic,
  * lxo_chain_guard, lxo_decode_state_get / _set, lxo_decode_cell_step; a NaN *scale_dev drops an optimizer step; round 6: 6 --
- * lxo_beam_decode_attn).  A binding must check
+ * lxo_beam_decode_attn, lxo_shape.live_B; the lxo_decoder_train_*_active calls are gone: they ran the launch-per-step kernels and were slower than the persistent chains computing every padded step).  A binding must check
  * lxo_version() == LXO_ABI_VERSION and lxo_shape_size() == sizeof(its own lxo_shape) before the first call: a caller built
  * against an older header passes a shorter struct and the library would read past its end. */
 #define LXO_ABI_VERSION 6
@@ -136,6 +136,13 @@ typedef struct lxo_shape {
      * two runs of one binary on the same inputs give bit-identical losses, gradients and weights.  Costs a few per cent of a step
      * (bench.py: secondary.deterministic_bf16); off by default.  SURVEY.md Appendix D step 8. */
     int deterministic;
+    /* training only: 0 (or B) = every batch row is a sample.  0 < live_B < B: rows live_B .. B - 1 are DEAD PADDING ROWS -- a batch the
+     * persistent chains do not take (the reference trains at 3, buckets and evaluates at 20: configs/training.json:6, data_generator.py:41,
+     * evaluate_txt.py:42) filled up to a chain batch of 8 / 16 / 32 / 64.  The caller gives them any valid token ids and formula
+     * length 0 (so no token of theirs is inside the loss mask, img2seq.py:68-71: their d(logits) and every gradient contribution is an
+     * exact zero, n_words does not see them); `img` needs only live_B images.  The encoder computes the live images only (the dead
+     * rows' features are zeros), the decoder steps all B rows.  Ignored with encoder_rnn. */
+    int live_B;
 } lxo_shape;
 
 /* flat f32 parameter / gradient / Adam-slot buffers: variable inventory in TF
@@ -210,15 +217,6 @@ int lxo_set_encoder_side_stream(void* stream);
  * (attention_cell.py:58-89) under teacher forcing, logits for every step. */
 int lxo_decoder_train_fwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                           const int32_t* formula, void* stream);
-/* Extension (off by default; the reference runs every padded step, decoder.py:50-57): the same recurrence restricted
- * to the live (sample, step) pairs.  The batch must be sorted by formula length, longest first;
- * active_rows (HOST, T entries) = number of samples with length > t.  The skipped steps are dead code for the loss
- * (masked at img2seq.py:68-71) and for every gradient, so loss and gradients are unchanged; their rows of the workspace
- * regions "logits", "alpha", "rec" are not written.  The _bwd_active call must get the same active_rows. */
-int lxo_decoder_train_fwd_active(const lxo_shape* s, const float* params, const void* wpack, void* ws,
-                                 const int32_t* formula, const int32_t* active_rows, void* stream);
-int lxo_decoder_train_bwd_active(const lxo_shape* s, const float* params, const void* wpack, void* ws,
-                                 const int32_t* formula, float* grads, const int32_t* active_rows, void* stream);
 /* loss of model/img2seq.py:68-75 and d(loss)/d(logits).  inv_ntok = 1 / (number of
  * unmasked tokens in the GLOBAL batch).  ws region "loss" = {sum CE, token count}. */
 int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula,
@@ -235,9 +233,9 @@ int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* w
                           const int32_t* formula, float* grads, void* stream);
 /* The same in two parts so that a data-parallel caller can start reducing gradients before the recurrence has run:
  * parts bit 0 = d_o from the logits for every step + the y_W_o gradient (final after this part);
- * parts bit 1 = BPTT, every other decoder gradient and d(enc).  active_rows = NULL or as in the _active calls. */
+ * parts bit 1 = BPTT, every other decoder gradient and d(enc). */
 int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const void* wpack, void* ws,
-                               const int32_t* formula, float* grads, const int32_t* active_rows, int parts, void* stream);
+                               const int32_t* formula, float* grads, int parts, void* stream);
 
 /* Health of the persistent decoder chains (lxo_shape.step_kernels == 0, bf16: lxo_decoder_train_fwd / _bwd run the recurrence as ONE
  * launch of 8 XCD-local chains that rely on the hardware placing 32 workgroups of the grid on every XCD).  A chain that does not

@@ -23,7 +23,7 @@ LXO_XDEC_BLOCK_BYTES, LXO_XDEC_ERR_WORD = 4096 + (384 << 10), 512      # include
 class LxoShape(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("B", "H", "W", "T", "V", "C", "E", "U", "O", "D", "dtype", "beam", "max_steps")] + \
                [("keep_prob", c_float), ("dropout_seed", c_int), ("div_gamma", c_float), ("div_prob", c_float), ("div_seed", c_int),
-                ("encoder_cnn", c_int), ("no_positional", c_int), ("step_kernels", c_int), ("encoder_rnn", c_int), ("deterministic", c_int)]
+                ("encoder_cnn", c_int), ("no_positional", c_int), ("step_kernels", c_int), ("encoder_rnn", c_int), ("deterministic", c_int), ("live_B", c_int)]
 
 
 def bind(lib):
@@ -60,11 +60,9 @@ def bind(lib):
         "lxo_set_encoder_side_stream": (c_int, [c_void]),
         "lxo_set_side_stream": (c_int, [c_void]),
         "lxo_decoder_train_fwd": (c_int, [S, c_void, c_void, c_void, c_void, c_void]),
-        "lxo_decoder_train_fwd_active": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void]),
-        "lxo_decoder_train_bwd_active": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
         "lxo_ce_loss_fwd_bwd": (c_int, [S, c_void, c_void, c_void, c_float, c_void]),
         "lxo_ce_loss_fwd_bwd_dev": (c_int, [S, c_void, c_void, c_void, c_void, c_void]),
-        "lxo_decoder_train_bwd_part": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void, c_int, c_void]),
+        "lxo_decoder_train_bwd_part": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_int, c_void]),
         "lxo_decoder_train_bwd": (c_int, [S, c_void, c_void, c_void, c_void, c_void, c_void]),
         "lxo_global_norm_scale": (c_int, [c_ll, c_void, c_float, c_void, c_void]),
         "lxo_adam_step": (c_int, [c_ll, c_void, c_void, c_void, c_void, c_float, c_float, c_float, c_float, c_void, c_void]),
@@ -105,7 +103,7 @@ def bind(lib):
 
 ENTRY_POINTS = ["lxo_last_error", "lxo_version", "lxo_shape_size", "lxo_ws_region_dtype", "lxo_timing_enable", "lxo_timing_count", "lxo_timing_get", "lxo_gemm_nt", "lxo_gemm_tn", "lxo_conv3x3", "lxo_conv3x3_ex", "lxo_conv3x3_wgrad", "lxo_gemm_slab", "lxo_attention_fwd", "lxo_param_num", "lxo_param_name", "lxo_param_name_for",
                 "lxo_param_total", "lxo_param_info", "lxo_wpack_bytes", "lxo_workspace_bytes", "lxo_ws_region",
-                "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_encoder_bwd_ready", "lxo_train_bwd", "lxo_set_side_stream", "lxo_set_encoder_side_stream", "lxo_decoder_train_fwd", "lxo_decoder_train_fwd_active", "lxo_decoder_train_bwd_active",
+                "lxo_pack_weights", "lxo_encoder_fwd", "lxo_encoder_bwd", "lxo_encoder_bwd_ready", "lxo_train_bwd", "lxo_set_side_stream", "lxo_set_encoder_side_stream", "lxo_decoder_train_fwd",
                 "lxo_ce_loss_fwd_bwd", "lxo_ce_loss_fwd_bwd_dev", "lxo_decoder_train_bwd", "lxo_decoder_train_bwd_part", "lxo_global_norm_scale", "lxo_adam_step", "lxo_optimizer_step",
                 "lxo_greedy_decode", "lxo_greedy_decode_attn", "lxo_beam_decode", "lxo_beam_decode_attn", "lxo_decode_begin", "lxo_decode_step",
                 "lxo_chain_guard", "lxo_decode_state_get", "lxo_decode_state_set", "lxo_decode_cell_step",

@@ -114,22 +114,7 @@ extern "C" int lxo_decoder_train_fwd(const lxo_shape* s, const float* params, co
                                      const int32_t* formula, void* stream) {
     MAKE_PLAN(P, s);
     if (s->T <= 0) return fail(-1, "T must be positive");
-    CHECK_LAUNCH(lxo_impl_decoder_train_fwd(P, params, wpack, ws, formula, nullptr, (hipStream_t)stream), "lxo_decoder_train_fwd");
-    return 0;
-}
-static int check_active(const lxo_shape* s, const int32_t* active) {
-    if (!active) return fail(-1, "active_rows is null");
-    if (active[0] != s->B) return fail(-1, "active_rows[0] must be B (every formula has at least its END token)");
-    for (int t = 1; t < s->T; ++t)
-        if (active[t] > active[t - 1] || active[t] < 0) return fail(-1, "active_rows must be non-increasing (sort the batch by length, longest first)");
-    return 0;
-}
-extern "C" int lxo_decoder_train_fwd_active(const lxo_shape* s, const float* params, const void* wpack, void* ws,
-                                            const int32_t* formula, const int32_t* active_rows, void* stream) {
-    MAKE_PLAN(P, s);
-    if (s->T <= 0) return fail(-1, "T must be positive");
-    if (int rc = check_active(s, active_rows)) return rc;
-    CHECK_LAUNCH(lxo_impl_decoder_train_fwd(P, params, wpack, ws, formula, active_rows, (hipStream_t)stream), "lxo_decoder_train_fwd_active");
+    CHECK_LAUNCH(lxo_impl_decoder_train_fwd(P, params, wpack, ws, formula, (hipStream_t)stream), "lxo_decoder_train_fwd");
     return 0;
 }
 extern "C" int lxo_ce_loss_fwd_bwd(const lxo_shape* s, void* ws, const int32_t* formula, const int32_t* lengths,
@@ -148,30 +133,22 @@ extern "C" int lxo_ce_loss_fwd_bwd_dev(const lxo_shape* s, void* ws, const int32
 extern "C" int lxo_decoder_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws,
                                      const int32_t* formula, float* grads, void* stream) {
     MAKE_PLAN(P, s);
-    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, nullptr, 3, (hipStream_t)stream), "lxo_decoder_train_bwd");
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, 3, (hipStream_t)stream), "lxo_decoder_train_bwd");
     return 0;
 }
 extern "C" int lxo_train_bwd(const lxo_shape* s, const float* params, const void* wpack, void* ws, const int32_t* formula, const uint8_t* img,
                             float* grads, void* const* ready_events, void* stream) {
     MAKE_PLAN(P, s);
-    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, nullptr, 3, (hipStream_t)stream, true, ready_events ? ready_events[0] : nullptr),
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, 3, (hipStream_t)stream, true, ready_events ? ready_events[0] : nullptr),
                  "lxo_train_bwd (decoder)");
     CHECK_LAUNCH(lxo_impl_encoder_bwd(P, params, wpack, ws, img, grads, 6, 1, (hipStream_t)stream, ready_events), "lxo_train_bwd (encoder)");
     return 0;
 }
 extern "C" int lxo_decoder_train_bwd_part(const lxo_shape* s, const float* params, const void* wpack, void* ws,
-                                          const int32_t* formula, float* grads, const int32_t* active_rows, int parts, void* stream) {
+                                          const int32_t* formula, float* grads, int parts, void* stream) {
     MAKE_PLAN(P, s);
     if (parts < 1 || parts > 3) return fail(-1, "lxo_decoder_train_bwd_part: parts must be 1, 2 or 3");
-    if (active_rows) { if (int rc = check_active(s, active_rows)) return rc; }
-    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, active_rows, parts, (hipStream_t)stream), "lxo_decoder_train_bwd_part");
-    return 0;
-}
-extern "C" int lxo_decoder_train_bwd_active(const lxo_shape* s, const float* params, const void* wpack, void* ws,
-                                            const int32_t* formula, float* grads, const int32_t* active_rows, void* stream) {
-    MAKE_PLAN(P, s);
-    if (int rc = check_active(s, active_rows)) return rc;
-    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, active_rows, 3, (hipStream_t)stream), "lxo_decoder_train_bwd_active");
+    CHECK_LAUNCH(lxo_impl_decoder_train_bwd(P, params, wpack, ws, formula, grads, parts, (hipStream_t)stream), "lxo_decoder_train_bwd_part");
     return 0;
 }
 extern "C" int lxo_global_norm_scale(long long n, const float* grads, float clip, float* scale_out, void* stream) {

@@ -6,10 +6,10 @@ int lxo_impl_pack_weights(const Plan& P, const float* prm, void* wp, hipStream_t
 int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, hipStream_t st);
 int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, float* grads,
                          int last_layer, int first_layer, hipStream_t st, void* const* ready = nullptr);
-int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, const int* active, hipStream_t st);
+int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, hipStream_t st);
 int lxo_impl_ce_loss(const Plan& P, void* ws, const int* formula, const int* lengths, float inv_ntok, const float* ntok_dev, hipStream_t st);
 // parts: bit 0 = d_o from the logits + d y_W_o (final before the recurrence runs), bit 1 = BPTT + every other decoder gradient + d_img
-int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads, const int* active, int parts, hipStream_t st,
+int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads, int parts, hipStream_t st,
                                bool defer_join = false, void* ready = nullptr);
 int lxo_impl_greedy_decode(const Plan& P, const float* prm, const void* wp, void* ws, int id_end, int max_iter, int* ids_out, float* alpha_out, int* steps_out, hipStream_t st);
 int lxo_impl_decode_begin(const Plan& P, const float* prm, const void* wp, void* ws, hipStream_t st);

@@ -217,11 +217,9 @@ static int mirror_oh(const Plan& P, void* ws, size_t slot_rows, int rows, hipStr
     return lxo_k_mirror(P.ws<float>(ws, W_REC) + slot_rows * P.REC, P.REC, P.ws<bf16_t>(ws, W_RECB) + slot_rows * P.RECB, P.RECB, rows, P.XH, st);
 }
 
-// active (host, T entries, non-increasing, may be null): rows [0, active[t]) are the samples whose formula is longer
-// than t (batch sorted by length, longest first); the steps of the other rows are dead for the loss (masked,
-// img2seq.py:68-71) and for every gradient, so they are not run.  null = the reference's behaviour: all B rows, all T steps.
-int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, const int* active,
-                               hipStream_t st) {
+// All B rows run all T steps, padded ones included, as the reference does (decoder.py:57: dynamic_rnn without sequence_length; the padded
+// steps are masked in the loss, img2seq.py:68-71).
+int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, hipStream_t st) {
     const int B = P.s.B, T = P.s.T, U = P.s.U, O = P.s.O, E = P.s.E, D = P.s.D, V = P.s.V, C = P.s.C;
     RC(attention_prepare(P, prm, wp, ws, 1, st));
     if (P.att_exp()) RC(lxo_k_att_exp(P.ws<void>(ws, W_ATT_IMG), P.ws<void>(ws, W_ATT_EXP), (long long)B * P.R * E, st));     // E_x = e^{2 att_img}: what the recurrence's attention kernels read
@@ -230,11 +228,11 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     RC(nt(P, false, true, false, P.ws<void>(ws, W_EMB_IN), P.Dp, P.pk(wp, K_LSTM_XT), P.Dp, zx, 4 * U, T * B, 4 * U, P.Dp,
           prm + P.poff[P_LSTM_B], 0, false, st));
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
-    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
+    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
     const int nh = dual ? 2 : 1;
     const bool fused = fused_steps(P) && !dual;
     bool chain_done = false;
-    if (fused && P.bf && !active && P.s.step_kernels == 0) {
+    if (fused && P.bf && P.s.step_kernels == 0) {
         // the whole recurrence in one launch: 8 XCD-local chains of B / 8 samples (xdec.hip); -2 = the shape does not qualify
         RC(mirror_oh(P, ws, 0, B, st));
         XDecFwd x; memset(&x, 0, sizeof(x));
@@ -259,7 +257,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
         bf16_t* recb = P.ws<bf16_t>(ws, W_RECB);
         RC(mirror_oh(P, ws, 0, B, st));
         for (int t = 0; t < T; ++t) {
-            const int nr = active ? active[t] : B;          // rows [0, nr) are the samples whose formula is longer than t (non-increasing)
+            const int nr = B;
             if (nr <= 0) break;
             RC(cell_step_fused(P, prm, wp, ws, nr, 1, zx + (size_t)t * B * 4 * U,
                                rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
@@ -273,7 +271,7 @@ int lxo_impl_decoder_train_fwd(const Plan& P, const float* prm, const void* wp, 
     if (dual) RC(fork_side(st));
     for (int t = 0; t < T && !fused; ++t)
         for (int h = 0; h < nh; ++h) {
-            const int hb = active ? active[t] : B / nh;
+            const int hb = B / nh;
             if (hb <= 0) continue;
             RC(cell_step(P, prm, wp, ws, h * hb, hb, 1, zx + (size_t)t * B * 4 * U,
                          rec + (size_t)t * B * P.REC, cs + (size_t)t * B * U,
@@ -309,7 +307,7 @@ hipStream_t lxo_impl_encoder_side_stream();
 static thread_local hipEvent_t g_dbw_fork = nullptr, g_dbw_fork2 = nullptr, g_dbw_join = nullptr, g_dbw_init = nullptr;
 
 int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const int* formula, float* grads,
-                               const int* active, int parts, hipStream_t st, bool defer_join, void* ready) {
+                               int parts, hipStream_t st, bool defer_join, void* ready) {
     const int B = P.s.B, T = P.s.T, C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
     const int TB = T * B;
     auto gw = [&](int pid) { return grads + P.poff[pid]; };
@@ -322,7 +320,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     const DetScratch det = P.det_scratch(ws);      // f32 parity mode: ordered reductions (no float atomics); null in bf16 mode
 
     // the same conditions as in lxo_impl_decoder_train_fwd: the fused step kernels ran (and left the bf16 mirrors of the record)
-    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0 && !active;
+    const bool dual = g_side != nullptr && B >= 2 && (B % 2) == 0;
     const bool fused = fused_steps(P) && !dual;
     // d_o (from logits) for every step, and dy_W_o
     if (parts & 1) {
@@ -336,7 +334,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     if (!(parts & 2)) return 0;
 
     // the launch-per-step kernels accumulate d_c in place and d_att_h with atomics; the backward chain writes both with plain stores
-    const bool want_chain = fused && P.bf && !active && P.s.step_kernels == 0;
+    const bool want_chain = fused && P.bf && P.s.step_kernels == 0;
     bool bwd_chain = false;                              // the backward chain ran (and left the bf16 mirror of d_att_h)
     auto zero_acc = [&]() -> int {
         HIPRC(hipMemsetAsync(dcc, 0, (size_t)B * U * 4, st));
@@ -347,16 +345,6 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     // no backward chain in this call: clear block 1's tickets and error word (lxo_chain_guard / Engine.chain_status read them; the workspace
     // is reused across shapes and the region offsets move with the shape, so stale bytes there would read as a broken chain)
     if (P.bf && !want_chain) HIPRC(hipMemsetAsync(P.ws<unsigned>(ws, W_XSYNC) + kXDecBlockBytes / 4, 0, kXDecSyncBytes, st));
-    if (active) {    // rows of skipped steps must read as zero in the deferred all-step GEMMs below
-        HIPRC(hipMemsetAsync(gall, 0, (size_t)TB * O * 4, st));
-        HIPRC(hipMemsetAsync(dhc, 0, (size_t)TB * P.HC * 4, st));
-        HIPRC(hipMemsetAsync(de, 0, (size_t)TB * P.Rp * 4, st));
-        HIPRC(hipMemsetAsync(dz, 0, (size_t)TB * 4 * U * 4, st));
-        if (fused && P.bf) {     // the bf16 mirrors are the operands of those GEMMs and of the carry GEMM (rows a step did not run contribute nothing)
-            HIPRC(hipMemsetAsync(P.ws<bf16_t>(ws, W_GB), 0, (size_t)TB * P.GBP * 2, st));
-            HIPRC(hipMemsetAsync(P.ws<bf16_t>(ws, W_DZB), 0, (size_t)TB * P.DZBP * 2, st));
-        }
-    }
     const int nh = dual ? 2 : 1;
     float* dxh = P.ws<float>(ws, W_DXH);
     if (fused) {
@@ -367,13 +355,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         float* carry_h = P.ws<float>(ws, W_CARRYH);
         const char* att_img = (const char*)P.ws<void>(ws, W_ATT_IMG);
         const char* img = (const char*)P.ws<void>(ws, W_IMG);
-        // With `active` (rows sorted by length, rows [0, active[t]) run step t): the last step that runs is t_last; step t's kernels
-        // cover active[t] rows; the carry kernel of step t covers the active[t - 1] rows of step t - 1 -- for the rows that end at
-        // t - 1 its GEMM operand (d_z_t, zeroed above, never written) is zero, so their g_{t-1} is the no-carry formula.
-        int t_last = T - 1;
-        while (active && t_last > 0 && active[t_last] <= 0) --t_last;
-        const int n_last = active ? active[t_last] : B;
-        if (n_last <= 0) return -5;                       // malformed active_rows (the *_active entry points check it; a direct caller gets a clean error, not a zero-sized launch)
+        const int t_last = T - 1, n_last = B;
         // g_{t_last} = d_o(logits) * tanh'   (no carry yet)
         RC(lxo_k_tanh_bwd(dolog + (size_t)t_last * B * O, O, kNoSlabs, rec + (size_t)(t_last + 1) * B * P.REC, P.REC,
                           gall + (size_t)t_last * B * O, O, bf ? gb + (size_t)t_last * B * P.GBP : nullptr, P.GBP, P.drop(t_last, 0), 0, n_last, O, st));
@@ -403,7 +385,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         RStep a; memset(&a, 0, sizeof(a));
         a.U = U; a.O = O; a.zx_row = -1;
         for (int t = t_last; t >= 0 && !chain_done; --t) {
-            const int nr = active ? active[t] : B;
+            const int nr = B;
             const int nchb = P.det() ? 1 : P.attn_chunks(nr);      // parity mode: one chunk per sample = one writer per d_att_h element
             a.M = nr;
             const float* rec_cur = rec + (size_t)(t + 1) * B * P.REC;
@@ -428,7 +410,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             RStep b3 = a;
             b3.A = datth_t; b3.lda = E;                                  // f32 (atomically accumulated), converted on load
             b3.W = P.pk(wp, K_ATT_H); b3.ldw = P.ldAH; b3.N = U; b3.K = E; b3.epi = RS_LSTM_BWD;
-            b3.dhm = dhc_t; b3.lddhm = P.HC; b3.carry_h = carry_h; b3.carry_rows = (t == t_last) ? 0 : (active ? active[t + 1] : B);
+            b3.dhm = dhc_t; b3.lddhm = P.HC; b3.carry_h = carry_h; b3.carry_rows = (t == t_last) ? 0 : B;
             b3.gates_in = gates + (size_t)t * B * 4 * U; b3.c_prev = cs + (size_t)t * B * U; b3.c_cur = cs + (size_t)(t + 1) * B * U;
             b3.dcc = dcc; b3.out = dz_t; b3.outb = bf ? dzb + (size_t)t * B * P.DZBP : nullptr; b3.ldob = P.DZBP; b3.dr = P.drop(t, 0);
             RC(lxo_launch_rstep(P.s.dtype, 0, b3, st));
@@ -438,7 +420,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
             b4.W = (const char*)P.pk(wp, K_LSTM) + (size_t)D * P.ldK * P.esz; b4.ldw = P.ldK; b4.N = P.XH; b4.K = 4 * U; b4.epi = RS_CARRY;
             if (t == 0) { b4.first = 1; b4.out = dxh; b4.ldo = P.XH; }
             else {
-                b4.M = active ? active[t - 1] : B;                       // the rows of step t - 1 (>= nr)
+                b4.M = B;
                 b4.out = gall + (size_t)(t - 1) * B * O; b4.outb = bf ? gb + (size_t)(t - 1) * B * P.GBP : nullptr; b4.ldob = P.GBP; b4.out2 = carry_h;
                 b4.dolog = dolog + (size_t)(t - 1) * B * O; b4.o_prev = rec + (size_t)t * B * P.REC; b4.ldoprev = P.REC;
                 b4.dr = P.drop(t - 1, 0);
@@ -449,10 +431,10 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     if (dual) RC(fork_side(st));
     for (int t = T - 1; t >= 0 && !fused; --t) {
         for (int h = 0; h < nh; ++h) {
-            const int hb = active ? active[t] : B / nh;
+            const int hb = B / nh;
             if (hb <= 0) continue;
             // rows that also ran step t+1 receive its carries; the others end here (their later steps were skipped)
-            const int crows = (t == T - 1) ? 0 : (active ? active[t + 1] : hb);
+            const int crows = (t == T - 1) ? 0 : hb;
             const int nchb = P.det() ? 1 : P.attn_chunks(hb);
             hipStream_t sh = h ? g_side : st;
             const size_t r0 = (size_t)h * hb;
@@ -486,7 +468,7 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     if (dual) RC(join_side(st));
     // the final carries of the two halves are separate slab sets; gather them into one [B][XH] buffer
     for (int h = 0; h < nh && !fused; ++h) {
-        const int hb = active ? active[0] : B / nh;       // every formula has at least its END token: step 0 runs all rows
+        const int hb = B / nh;
         const size_t r0 = (size_t)h * hb;
         float* sb4 = P.ws<float>(ws, W_S_B4) + r0 * (4 * U / 128) * P.XH;
         RC(lxo_k_slab_reduce(view(sb4, 4 * U, hb, P.XH), dxh + r0 * P.XH, P.XH, hb, P.XH, st));

@@ -84,7 +84,7 @@ static int conv_fwd(const Plan& P, const void* in, const void* wpk, const float*
     g.A = in; g.Bp = wpk; g.C = out;
     g.conv = 1; g.H = H; g.W = W; g.Cin = Cin;
     g.Ho = valid ? H - 2 : H; g.Wo = valid ? W - 2 : W; g.pad = valid ? 0 : 1;
-    g.M = P.s.B * g.Ho * g.Wo; g.N = Cout; g.K = 9 * Cin;
+    g.M = P.Be * g.Ho * g.Wo; g.N = Cout; g.K = 9 * Cin;
     g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
     g.bias = bias; g.act = 1; g.alpha = 1.f;
     g.addend = addend; g.addend_rows = addend_rows > 0 ? addend_rows : 1; g.out_pre = out_pre;
@@ -97,7 +97,7 @@ static int conv_fwd_pool(const Plan& P, const void* in, const void* wpk, const f
     GemmNT g; memset(&g, 0, sizeof(g));
     g.A = in; g.Bp = wpk; g.C = nullptr;
     g.conv = 1; g.H = H; g.W = W; g.Cin = Cin; g.Ho = H; g.Wo = W; g.pad = 1;
-    g.M = P.s.B * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.M = P.Be * H * W; g.N = Cout; g.K = 9 * Cin;
     g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout;
     g.bias = bias; g.act = 1; g.alpha = 1.f; g.addend_rows = 1;
     g.pool_out = pooled; g.pool_mask = (unsigned char*)mask; g.pool_h = ph; g.pool_w = pw;
@@ -112,7 +112,7 @@ static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din
     g.A = dout; g.Bp = wd; g.C = din;
     g.conv = 1; g.H = Hout; g.W = Wout; g.Cin = Cout;
     g.Ho = Hin; g.Wo = Win; g.pad = valid ? 2 : 1;
-    g.M = P.s.B * Hin * Win; g.N = Cin; g.K = 9 * Cout;
+    g.M = P.Be * Hin * Win; g.N = Cin; g.K = 9 * Cout;
     g.lda = Cout; g.ldb = 9 * Cout; g.ldc = Cin;
     g.act = 0; g.alpha = 1.f; g.addend_rows = 1;
     g.relu_ref = relu_ref; g.ldr = Cin; g.colsum = colsum;
@@ -120,7 +120,7 @@ static int conv_dgrad(const Plan& P, const void* dout, const void* wd, void* din
     // form (the bf16 two-workgroup kernel), else an ordered column-sum pass over the masked result (lxo_launch_gemm_nt)
     if (P.det() && colsum) { g.colsum_part = det.p; g.colsum_part_floats = det.floats; }
     // algorithmic FLOPs of a data gradient = those of the layer's forward, whatever grid the kernel pads to
-    LxoTimed tm("conv_dgrad", conv_name(Cin, Cout, valid), 2.0 * P.s.B * Hout * Wout * 9.0 * Cin * Cout, st);
+    LxoTimed tm("conv_dgrad", conv_name(Cin, Cout, valid), 2.0 * P.Be * Hout * Wout * 9.0 * Cin * Cout, st);
     return lxo_launch_gemm_nt(P.s.dtype, 0, 0, 0, g, st);
 }
 // wgrad: dW[(kh,kw,ci)][co] += sum_m in[m shifted][ci] * d_out[m][co]
@@ -130,7 +130,7 @@ static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw
     g.A = in; g.B = dout; g.C = dw;
     g.conv = 1; g.H = H; g.W = W; g.Cin = Cin;
     g.Ho = valid ? H - 2 : H; g.Wo = valid ? W - 2 : W; g.pad = valid ? 0 : 1;
-    g.M = P.s.B * g.Ho * g.Wo; g.I = 9 * Cin; g.J = Cout;
+    g.M = P.Be * g.Ho * g.Wo; g.I = 9 * Cin; g.J = Cout;
     g.lda = Cin; g.ldb = Cout; g.ldc = Cout;
     const int tiles = cdiv(g.I, 128) * cdiv(g.J, 128);
     int ns = cdiv(1024, tiles);
@@ -143,7 +143,9 @@ static int conv_wgrad(const Plan& P, const void* in, const void* dout, float* dw
 }
 
 int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, hipStream_t st) {
-    const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
+    // B = the images the encoder computes (Plan::Be): with lxo_shape.live_B the rows behind them are dead padding rows -- their features are
+    // zeros (written below), their gradient rows are never read
+    const int dt = P.s.dtype, B = P.Be, C = P.s.C;
     void* p1 = P.ws<void>(ws, W_P1);
     RC(lxo_k_conv1_pool_fwd(dt, img, prm + P.poff[P_CONV1_W], prm + P.poff[P_CONV1_B], p1, B, P.s.H, P.s.W, st));
     const bool pf = P.pool_fused();
@@ -176,6 +178,11 @@ int lxo_impl_encoder_fwd(const Plan& P, const float* prm, const void* wp, void* 
     if (pos) RC(lxo_k_timing_signal(P.ws<float>(ws, W_POS), P.Hp, P.Wp, C, st));
     RC(conv_fwd(P, P.ws<void>(ws, W_P5), P.pk(wp, K_CONV6_F), prm + P.poff[P_CONV6_B], P.ws<void>(ws, W_IMG), P.H6, P.W5, C, C, true,
                 pos ? P.ws<float>(ws, W_POS) : nullptr, P.R, P.ws<void>(ws, W_Y6), st));
+    if (P.Be < P.s.B) {     // dead rows: defined, finite features for the decoder (which steps all B rows): zeros
+        const size_t row = (size_t)P.R * C * P.esz;
+        HIPRC(hipMemsetAsync((char*)P.ws<void>(ws, W_IMG) + (size_t)P.Be * row, 0, (size_t)(P.s.B - P.Be) * row, st));
+        HIPRC(hipMemsetAsync((char*)P.ws<void>(ws, W_Y6) + (size_t)P.Be * row, 0, (size_t)(P.s.B - P.Be) * row, st));
+    }
     if (P.rnn) RC(lxo_impl_rowenc_fwd(P, prm, wp, ws, st));        // optional row-BiLSTM over the feature rows (not in the reference; off by default)
     return 0;
 }
@@ -209,7 +216,7 @@ static const int XC[7] = {0, 0, 1, 0, 1, 2, 0}, YC[7] = {0, 0, 2, 2, 0, 1, 1};  
 
 int lxo_impl_encoder_bwd(const Plan& P, const float* prm, const void* wp, void* ws, const uint8_t* img, float* grads,
                          int last_layer, int first_layer, hipStream_t st, void* const* ready) {
-    const int dt = P.s.dtype, B = P.s.B, C = P.s.C;
+    const int dt = P.s.dtype, B = P.Be, C = P.s.C;                 // (the live images: the d_img rows of dead padding rows are exact zeros and are not read)
     void* const G[3] = {P.ws<void>(ws, W_G0), P.ws<void>(ws, W_G1), P.ws<void>(ws, W_G2)};
     const int* XB = P.cnn ? XC : XV; const int* YB = P.cnn ? YC : YV;
     auto gw = [&](int pid) { return grads + P.poff[pid]; };

@@ -71,6 +71,7 @@ struct Plan {
     int H1, W1, H2, W2, H4, W5, H6, Hp, Wp, R;   // conv5 runs at H4 x W2, conv6 reads H6 x W5 (vanilla: H6 == H4)
     bool cnn;                                    // encoder_cnn == "cnn": no pools after conv4/conv5, (2,4)/2 conv instead
     bool rnn;                                    // encoder_rnn: row-BiLSTM between conv6 and the decoder
+    int Be;                                      // images the ENCODER computes: lxo_shape.live_B (the rows behind them are dead padding rows of a filled-up batch), else B
     int Ur;                                      //   units per direction (C / 2)
     int convCin[6], convCout[6], convW[6], convB[6];   // per 3x3 layer: channels and ParamIds
     int Vp, Dp, Rp, XH, HC, REC;   // padded V / D / R (row pitches), O+U, U+C, record width O+2U+C

@@ -65,6 +65,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     H2 = cd2(H1); W2 = cd2(W1);            // after conv2's 2x2 pool      (encoder.py:39)
     cnn = s.encoder_cnn != 0;
     rnn = s.encoder_rnn != 0;
+    Be = (s.live_B > 0 && s.live_B < s.B && !rnn) ? s.live_B : s.B;
     Ur = C / 2;
     H4 = cnn ? H2 : cd2(H2);               // after conv4's (2,1) pool    (encoder.py:47; "cnn": no pool)
     W5 = cd2(W2);                          // after conv5's (1,2) pool    (encoder.py:52) / the stride-2 conv (:54-56)

@@ -28,7 +28,7 @@ XDEC_BLOCK_BYTES = _abi.LXO_XDEC_BLOCK_BYTES
 
 
 class Engine(object):
-    def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None, skip_padded=None, deterministic=None):
+    def __init__(self, n_tok, dims=None, dtype="bf16", device="cuda:0", seed=0, beam=1, max_steps=0, lib=None, deterministic=None):
         self.lib = lib if lib is not None else _abi.load()
         self.device = torch.device(device)
         if self.device.type != "cuda" and lib is None:
@@ -37,10 +37,6 @@ class Engine(object):
         self.n_tok = int(n_tok)
         self.dtype = _abi.LXO_BF16 if dtype in ("bf16", 1) else _abi.LXO_F32
         self.beam, self.max_steps = int(beam), int(max_steps)
-        # extension, off by default (the reference runs every padded step): train_step sorts the batch by length and runs
-        # each decoder step only for the samples still inside their formula (lxo_decoder_train_*_active); same loss and gradients
-        self.skip_padded = (os.environ.get("LXO_SKIP_PADDED", "0") == "1") if skip_padded is None else bool(skip_padded)
-        self._active = None
         # decoder step decomposition (lxo_shape.step_kernels): 0 = automatic (the persistent XCD-local chain of csrc/xdec.hip where the shape
         # qualifies, else the fused step kernels), 2 = always the fused step kernels, 1 = round 1's split-K slab path
         self.step_kernels = int(os.environ.get("LXO_STEP_KERNELS", "0"))
@@ -224,7 +220,7 @@ class Engine(object):
         return slot["dev"][:n]
 
     # ---------------------------------------------------------------- steps --
-    def forward(self, img, formula, dropout=None, active_rows=None, phase_hook=None, before_decoder=None):
+    def forward(self, img, formula, dropout=None, phase_hook=None, before_decoder=None):
         """Encoder + teacher-forced decoder; leaves logits in the workspace.  dropout = (keep_prob, seed)
         applies tf.nn.dropout on h and o (attention_cell.py:72,83) with this step's counter-based masks;
         backward() regenerates the same masks from the bound shape."""
@@ -235,14 +231,17 @@ class Engine(object):
         # formula length is 0 (loss() appends the zeros), so no token of theirs is inside the loss mask (img2seq.py:68-71), their d(logits)
         # and with it every gradient contribution is an exact 0, and n_words does not see them
         self.live_B = B
-        Bp = B if active_rows is not None else self._train_chain_batch(B, H, W)
+        drop_on = dropout is not None and 0.0 < float(dropout[0]) < 1.0
+        # (with config.dropout < 1 the batch stays as it is: the counter-based masks are keyed by (step, row, batch size), and the oracle the
+        # dropout tests compare with draws them for the caller's batch -- the reference ships keep-probability 1, configs/training.json:7)
+        Bp = B if drop_on else self._train_chain_batch(B, H, W)
         if Bp != B:
-            img = self._to_dev(img, torch.uint8)
+            # (lxo_shape.live_B: the encoder computes the B live images only -- `img` stays as it is -- and leaves zero features for the dead rows)
             formula = self._to_dev(formula, torch.int32)
-            fill = torch.arange(Bp, device=self.device) % B
-            img, formula = img.index_select(0, fill), formula.index_select(0, fill)
-            B = Bp
-        self.ensure(B, H, W, T)
+            formula = formula.index_select(0, torch.arange(Bp, device=self.device) % B)
+        self.ensure(Bp, H, W, T)
+        self.shape.live_B = B if Bp != B else 0
+        B = Bp
         if dropout is not None and 0.0 < float(dropout[0]) < 1.0:
             self.shape.keep_prob = float(dropout[0])
             self.shape.dropout_seed = int(dropout[1]) & 0x7FFFFFFF
@@ -257,17 +256,11 @@ class Engine(object):
             # data parallel: the token-count all-reduce (its own stream) must be OFF the GPU before the persistent decoder chain starts --
             # the chain wants every CU, and a collective kernel that waits for a late rank would hold some of them
             torch.cuda.current_stream(self.device).wait_event(before_decoder)
-        self._active = None if active_rows is None else np.ascontiguousarray(active_rows, dtype=np.int32)
-        if self._active is None:
-            self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
-                     "decoder_train_fwd")
-            if (not self._xdec_checked and self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda"
-                    and (B, H, W) not in self._nochain_shapes):
-                self._check_chain(st)
-        else:
-            assert self._active.shape == (T,)
-            self._ck(self.lib.lxo_decoder_train_fwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                           self._active.ctypes.data_as(ctypes.c_void_p), st), "decoder_train_fwd_active")
+        self._ck(self.lib.lxo_decoder_train_fwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula), st),
+                 "decoder_train_fwd")
+        if (not self._xdec_checked and self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda"
+                and (B, H, W) not in self._nochain_shapes):
+            self._check_chain(st)
 
     def chain_status(self, backward=False):
         """(used, error) of the persistent XCD-local decoder chain (csrc/xdec.hip) in the last lxo_decoder_train_fwd (backward=True: the
@@ -306,7 +299,7 @@ class Engine(object):
                       "launch-per-step decoder kernels (lxo_shape.step_kernels = 2)" % (which, err), RuntimeWarning)
 
     def _chains_possible(self):
-        return self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda" and not self.skip_padded
+        return self.dtype == _abi.LXO_BF16 and self.step_kernels == 0 and self.device.type == "cuda"
 
     def _chain_health_post(self, have_scale, dp=False):
         """Behind backward(), before the optimizer: lxo_chain_guard (device: scale[0] = NaN when a chain of this step failed, so the optimizer
@@ -389,27 +382,23 @@ class Engine(object):
         part (bench.py's per-phase table)."""
         st = self._stream()
         self._bind_side()
-        act = None if self._active is None else self._active.ctypes.data_as(ctypes.c_void_p)
         # the recurrence may run as the persistent backward chain (csrc/xdec.hip): it wants every CU, so no collective kernel is put
         # beside it -- y_W_o's all-reduce then follows the recurrence instead of overlapping it
-        chain = (self.dtype == _abi.LXO_BF16 and self.shape.step_kernels == 0 and self._active is None and self.device.type == "cuda")
+        chain = (self.dtype == _abi.LXO_BF16 and self.shape.step_kernels == 0 and self.device.type == "cuda")
 
         def decoder_bwd(defer_b0):
             self.grads.zero_()
             if comm:
                 # y_W_o's gradient needs only d(logits): reduce it while the recurrence runs
                 self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                             _p(self.grads), act, 1, st), "decoder_train_bwd_part")
+                                                             _p(self.grads), 1, st), "decoder_train_bwd_part")
                 if not defer_b0:
                     comm(*self.buckets[0])
                 self._ck(self.lib.lxo_decoder_train_bwd_part(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                             _p(self.grads), act, 2, st), "decoder_train_bwd_part")
-            elif self._active is None:
+                                                             _p(self.grads), 2, st), "decoder_train_bwd_part")
+            else:
                 self._ck(self.lib.lxo_decoder_train_bwd(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
                                                         _p(self.grads), st), "decoder_train_bwd")
-            else:
-                self._ck(self.lib.lxo_decoder_train_bwd_active(self.sref(), _p(self.params), _p(self.wpack), _p(self.ws), _p(self._formula),
-                                                               _p(self.grads), act, st), "decoder_train_bwd_active")
 
         # After the first backward of this shape has been looked at (below), the whole pass is ONE call: lxo_train_bwd joins the weight-gradient
         # side stream once, at the end (the decoder's deferred weight gradients then also run beside conv6's data gradient), and records
@@ -417,7 +406,7 @@ class Engine(object):
         key = (self.shape.B, self.shape.H, self.shape.W)
         looked = self._xdec_bwd_checked or key in self._nochain_shapes_bwd or not chain
         ready_ok = comm is None or (getattr(comm, "takes_ready", False) and chain)      # (no chain: y_W_o's bucket goes out while the recurrence runs)
-        if (self.device.type == "cuda" and self._active is None and looked and ready_ok and phase_hook is None
+        if (self.device.type == "cuda" and looked and ready_ok and phase_hook is None
                 and os.environ.get("LXO_TRAIN_BWD_FUSED", "1") != "0"):
             self.grads.zero_()
             table = None
@@ -539,9 +528,6 @@ class Engine(object):
             self.drop_step = getattr(self, "drop_step", 0) + 1
             world, rank = (dist.world, dist.rank) if dist is not None else (1, 0)
             drop = (float(dropout), dropout_seed if dropout_seed is not None else self.drop_step * world + rank)
-        active = None
-        if self.skip_padded:
-            img, formula, lengths, active = self.sort_by_length(img, formula, lengths)
         n_local = int(np.asarray(lengths).sum()) if not isinstance(lengths, torch.Tensor) else int(lengths.sum().item())
         if self._health_ring is not None and dist is None:
             # error words of the steps the device has finished meanwhile (no stall).  Not under data parallelism: WHEN the host notices a
@@ -551,10 +537,10 @@ class Engine(object):
         if dist is not None:
             # the global token count travels rank -> device -> all-reduce -> loss kernel; no host sync inside the step
             ntok, ev = dist.sum_count_async(n_local)
-            self.forward(img, formula, dropout=drop, active_rows=active, before_decoder=ev)
+            self.forward(img, formula, dropout=drop, before_decoder=ev)
             stats = self.loss(lengths, ntok_dev=ntok, ntok_event=ev)
         else:
-            self.forward(img, formula, dropout=drop, active_rows=active)
+            self.forward(img, formula, dropout=drop)
             stats = self.loss(lengths, 1.0 / float(n_local))
         self.backward(comm=dist.reduce_range_fn(self.grads) if dist is not None else None)
         if dist is not None:
@@ -579,24 +565,6 @@ class Engine(object):
             finally:
                 self._redoing = False
         return float(s[0]) / float(s[1])
-
-    def sort_by_length(self, img, formula, lengths):
-        """Longest formula first (stable), plus active_rows[t] = #samples with length > t for the *_active calls."""
-        l = lengths.cpu().numpy() if isinstance(lengths, torch.Tensor) else np.asarray(lengths)
-        order = np.argsort(-l, kind="stable")
-        T = int(formula.shape[1])
-        ls = l[order]
-        active = (ls[None, :] > np.arange(T)[:, None]).sum(axis=1).astype(np.int32)
-        if isinstance(img, torch.Tensor):
-            idx = torch.from_numpy(order).to(img.device)
-            img = img.index_select(0, idx)
-        else:
-            img = np.asarray(img)[order]
-        if isinstance(formula, torch.Tensor):
-            formula = formula.index_select(0, torch.from_numpy(order).to(formula.device))
-        else:
-            formula = np.asarray(formula)[order]
-        return img, formula, ls, active
 
     def evaluate_batch(self, img, formula, lengths):
         """(sum CE, n_words) of img2seq.py:74-75 for one batch (teacher forced)."""
@@ -623,8 +591,8 @@ class Engine(object):
         or B itself where they would not run anyway (mirrors lxo_launch_xdec_fwd's conditions).  LXO_TRAIN_PAD=0 / Engine.pad_train = False
         switch the padding off (the launch-per-step kernels then take the batch as it is)."""
         d = self.dims
-        if (self.device.type != "cuda" or self.dtype != _abi.LXO_BF16 or self.step_kernels != 0 or self.skip_padded or B >= 64 or B in (8, 16, 32)
-                or not getattr(self, "pad_train", True)
+        if (self.device.type != "cuda" or self.dtype != _abi.LXO_BF16 or self.step_kernels != 0 or B >= 64 or B in (8, 16, 32)
+                or not getattr(self, "pad_train", True) or d.get("row_bilstm")
                 or not (d["C"] == 512 and d["U"] == 512 and d["O"] == 512 and d["E"] == 256)
                 or "0" in (os.environ.get("LXO_TRAIN_PAD", "1"), os.environ.get("LXO_XDEC", "1"))):
             return B

@@ -95,8 +95,9 @@ def test_bf16_step_repeats_to_atomic_order_noise(B, H, W):
     print("B=%d: bf16 gradients run to run: max |difference| / max |g| = %.1e" % (B, worst))
 
 
-def _one_pass_bf16_det(V, img, f, l, dims=None):
+def _one_pass_bf16_det(V, img, f, l, dims=None, pad=True):
     eng = Engine(V, dtype="bf16", seed=3, dims=dims, deterministic=True)
+    eng.pad_train = pad                                          # False: a batch the chains do not take stays on the launch-per-step kernels
     eng.forward(img, f)
     stats = eng.loss(l, 1.0 / int(l.sum())).cpu().numpy().copy()
     eng.backward()
@@ -104,13 +105,14 @@ def _one_pass_bf16_det(V, img, f, l, dims=None):
     return stats, eng.grad_dict(), (eng.chain_used, eng.chain_used_bwd)
 
 
-@pytest.mark.parametrize("shape", [(16, 64, 256, 120, 5, 24), (12, 64, 256, 120, 5, 24), (64, 32, 128, 50, 3, 9)])
+@pytest.mark.parametrize("shape", [(16, 64, 256, 120, 5, 24, True), (12, 64, 256, 120, 5, 24, False), (12, 64, 256, 120, 5, 24, True), (64, 32, 128, 50, 3, 9, True)])
 def test_bf16_deterministic_mode_bit_identical_run_to_run(shape):
-    n, H, W, V, lo, hi = shape
+    n, H, W, V, lo, hi, pad = shape
     img, f, l = batch(n, H, W, V, lo, hi, seed=11)
-    runs = [_one_pass_bf16_det(V, img, f, l) for _ in range(3)]
+    runs = [_one_pass_bf16_det(V, img, f, l, pad=pad) for _ in range(3)]
     s0, g0, chains = runs[0]
-    assert chains == ((n % 8 == 0), (n % 8 == 0)), chains          # B = 16 / 64: through xdec_fwd_kernel / xdec_bwd_kernel; B = 12: the launch-per-step kernels
+    # B = 16 / 64, and 12 filled up to 16 with dead rows: through xdec_fwd_kernel / xdec_bwd_kernel; B = 12 as it is: the launch-per-step kernels
+    assert chains == ((n % 8 == 0 or pad), (n % 8 == 0 or pad)), chains
     assert len(g0) == 28
     for s, g, _ in runs[1:]:
         assert s.tobytes() == s0.tobytes(), (s, s0)
@@ -118,6 +120,7 @@ def test_bf16_deterministic_mode_bit_identical_run_to_run(shape):
         assert not bad, "bf16 deterministic-mode gradients differ between two runs of the same step: %s" % bad
     # and it is the same mathematics as the default (atomic) bf16 mode: loss identical to f32 rounding, gradients to summation order
     eng = Engine(V, dtype="bf16", seed=3)
+    eng.pad_train = pad                                          # the same kernels (chains / launch-per-step) in both modes
     eng.forward(img, f)
     st = eng.loss(l, 1.0 / int(l.sum())).cpu().numpy().copy()
     eng.backward()
@@ -139,17 +142,18 @@ def test_bf16_deterministic_encoder_variants_bit_identical_run_to_run():
         assert not bad, (dims, bad)
 
 
-@pytest.mark.parametrize("B", [16, 20])
-def test_bf16_deterministic_adam_trajectory_bit_identical_run_to_run(B):
-    """30 Adam steps with clipping, bf16 deterministic mode, through the chains (B = 16) and the launch-per-step kernels (B = 20)"""
+@pytest.mark.parametrize("B,pad", [(16, True), (20, False), (20, True)])
+def test_bf16_deterministic_adam_trajectory_bit_identical_run_to_run(B, pad):
+    """30 Adam steps with clipping, bf16 deterministic mode, through the chains (B = 16; B = 20 filled up to 32) and the launch-per-step kernels (B = 20 as it is)"""
     V = 50
     img, f, l = batch(B, 32, 128, V, 5, 12, seed=13)
     out = []
     for _ in range(2):
         eng = Engine(V, dtype="bf16", seed=0, deterministic=True)
+        eng.pad_train = pad
         curve = np.array([eng.train_step(img, f, l, 1e-3, clip=5.0) for _ in range(30)], np.float64)
         out.append((curve, eng.params.detach().cpu().numpy().copy(), eng.chain_used and eng.chain_used_bwd))
-    assert out[0][2] == (B % 8 == 0)
+    assert out[0][2] == (B % 8 == 0 or pad)
     assert out[0][0].tobytes() == out[1][0].tobytes(), np.abs(out[0][0] - out[1][0]).max()
     assert out[0][1].tobytes() == out[1][1].tobytes()
     assert out[0][0][-1] < out[0][0][0]

@@ -26,8 +26,8 @@ def full():
     return eng, img, f, l
 
 
-def _loss_and_grads(eng, img, f, l, n_global=None, active=None):
-    eng.forward(img, f, active_rows=active)
+def _loss_and_grads(eng, img, f, l, n_global=None):
+    eng.forward(img, f)
     n = int(l.sum()) if n_global is None else n_global
     stats = eng.loss(l, 1.0 / n).cpu().numpy()
     eng.backward()
@@ -66,17 +66,6 @@ def test_batch_order_and_half_batches_do_not_change_the_gradients(full):
     cb, _, gb = _loss_and_grads(eng, img[32:], f[32:], l[32:], n_global=n)
     assert abs((ca + cb) - ce0) / ce0 < 1e-5
     cos = float(torch.nn.functional.cosine_similarity(g0.double(), (ga + gb).double(), dim=0))
-    assert cos > 0.9999, cos
-
-
-def test_skipping_padded_steps_is_exact_at_full_size(full):
-    eng, img, f, l = full
-    si, sf, sl, active = eng.sort_by_length(img, f, l)
-    ce0, n0, g0 = _loss_and_grads(eng, si, sf, sl)
-    ce1, n1, g1 = _loss_and_grads(eng, si, sf, sl, active=active)
-    assert int(active.sum()) == int(l.sum()) and active[0] == B
-    assert abs(ce1 - ce0) / ce0 < 1e-5
-    cos = float(torch.nn.functional.cosine_similarity(g0.double(), g1.double(), dim=0))
     assert cos > 0.9999, cos
 
 

@@ -234,34 +234,6 @@ def test_greedy_attention_export_f32():
     assert np.abs(alpha.reshape(B, T, -1).sum(-1) - 1).max() < 1e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 2e-3)])
-def test_skip_padded_steps_same_loss_and_gradients(dtype, tol):
-    """Extension: running each decoder step only for the samples still inside their formula (batch sorted by length)
-    leaves loss and every gradient unchanged -- the skipped steps are masked out of the loss (img2seq.py:68-71)."""
-    V = 50
-    img, f, l = batch(7, 32, 128, V, 3, 14, seed=17)
-    out = []
-    for skip in (False, True):
-        eng = Engine(V, dtype=dtype, seed=3, skip_padded=skip)
-        a = None
-        im, ff, ll = img, f, l
-        if skip:
-            im, ff, ll, a = eng.sort_by_length(img, f, l)
-            assert a[0] == 7 and a[-1] >= 1 and np.all(np.diff(a) <= 0) and int(a.sum()) == int(l.sum())
-        eng.forward(im, ff, active_rows=a)
-        stats = eng.loss(ll, 1.0 / int(l.sum())).cpu().numpy()
-        eng.backward()
-        torch.cuda.synchronize()
-        out.append((stats[0] / stats[1], eng.grad_dict()))
-    assert abs(out[0][0] - out[1][0]) / out[0][0] < tol
-    for k in out[0][1]:
-        a0, a1 = out[0][1][k], out[1][1][k]
-        if dtype == "f32":
-            assert np.abs(a0 - a1).max() <= 2e-5 * max(np.abs(a0).max(), 1e-6) + 1e-9, k
-        else:
-            assert cosine(a0, a1) > 0.98, (k, cosine(a0, a1))
-
-
 def test_beam_attention_export_f32():
     """lxo_beam_decode_attn: the attention weights of every decoder row (image x hypothesis slot) of every beam-search step, as the step ran
     -- what the reference's py_func tap is handed on the merged batch x beam tensor under config.decoding = "beam_search"

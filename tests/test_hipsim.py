@@ -480,38 +480,6 @@ def test_encoder_cnn_variant_and_no_positional_vs_oracle(dtype):
                 assert float(g @ r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30) > 0.97, k
 
 
-def test_skip_padded_steps_same_loss_and_gradients():
-    """lxo_decoder_train_*_active: only live (sample, step) pairs run; loss and gradients equal the full recurrence."""
-    img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
-    order = np.argsort(-l, kind="stable")
-    img, f, l = np.ascontiguousarray(img[order]), np.ascontiguousarray(f[order]), np.ascontiguousarray(l[order])
-    T = f.shape[1]
-    active = np.ascontiguousarray((l[None, :] > np.arange(T)[:, None]).sum(axis=1).astype(np.int32))
-    assert active[0] == 2 and active[-1] < 2          # the golden batch has two different lengths
-    res = []
-    for act in (None, active):
-        S = Sim(2, 32, 48, T, 11, dtype=0, seed=0, dims=SMALL)
-        S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
-        if act is None:
-            S.ck(S.L.lxo_decoder_train_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), None), "dec")
-        else:
-            S.ck(S.L.lxo_decoder_train_fwd_active(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(act), None), "dec")
-        S.ck(S.L.lxo_ce_loss_fwd_bwd(S.sref(), ptr(S.ws), ptr(f), ptr(l), ctypes.c_float(1.0 / int(l.sum())), None), "loss")
-        if act is None:
-            S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), None), "decbwd")
-        else:
-            S.ck(S.L.lxo_decoder_train_bwd_active(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(S.grads), ptr(act), None), "decbwd")
-        S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, None), "encbwd")
-        st = S.region("loss", np.float32)[:2]
-        res.append((st[0] / st[1], {k: S.grad(k).copy() for k, _, _ in S.specs}))
-    assert abs(res[0][0] - res[1][0]) < 1e-6
-    for k in res[0][1]:
-        a0, a1 = res[0][1][k], res[1][1][k]
-        assert np.abs(a0 - a1).max() <= 1e-5 * max(np.abs(a0).max(), 1e-6) + 1e-9, k
-    bad = active.copy(); bad[0] = 1
-    assert S.L.lxo_decoder_train_fwd_active(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(f), ptr(bad), None) != 0
-
-
 def test_train_bwd_and_ready_entry_points_vs_golden():
     """lxo_encoder_bwd_ready (one call for a layer range, with a per-layer event table whose NULL entries are skipped) behind
     lxo_decoder_train_bwd against the golden gradients, and lxo_train_bwd (the backward pass in one call) from the same forward state: the
