@@ -318,6 +318,13 @@ int lxo_launch_conv_wgrad(const GemmTN& p, hipStream_t s) {
     const int tiles = tiles_ci * tiles_co;
     int nsplit = cdiv(256, tiles);
     if (nsplit > nblocks) nsplit = nblocks;
+    // every split ends with the atomic epilogue of a whole (64 ci x 128 co x 9 taps) tile -- 295 KB of f32 atomics onto addresses its sibling
+    // splits hit too -- whatever its pixel range: on the small maps of the reference's real buckets (configs/data.json: 50 x 120 ... at batch 20)
+    // a range of one or two pixel blocks made the launch all epilogue.  At least LXO_WG_MINBLK = 8 blocks per split (the benchmark shape has 16 .. 56: unchanged)
+    // (swept over four real buckets at batch 20 / 64, profiles/r06_wgrad_minblk.txt: 1 / 4 / 8 / 16 blocks -> 1.678 / 1.644 / 1.615 / 1.672 ms per step at 50 x 120)
+    static const int min_blk = getenv("LXO_WG_MINBLK") ? atoi(getenv("LXO_WG_MINBLK")) : 8;
+    if (min_blk > 1 && nsplit > cdiv(nblocks, min_blk)) nsplit = cdiv(nblocks, min_blk);
+    if (nsplit < 1) nsplit = 1;
     const int per_split = cdiv(nblocks, nsplit);
     nsplit = cdiv(nblocks, per_split);
     // the end-of-range spread that hides the atomic epilogue in units of blocks at each end of the ramp (swept in-step: 0 / 4.3 / 10 / 14 / 20 -> 0.48 / 0.50 / 0.526 / 0.50 / 0.48 of the MFMA peak; the

@@ -70,26 +70,42 @@ def edit_distance(references, hypotheses):
     return 1.0 - d / tot if tot else 1.0
 
 
-def bleu_score(references, hypotheses, max_n=4):
-    """Corpus BLEU-4 with uniform weights, one reference per hypothesis
-    (what `nltk.translate.bleu_score.corpus_bleu` computes for the call at
-    evaluation/text.py:70-72, unsmoothed)."""
-    num = [0] * max_n
-    den = [0] * max_n
+def _ngrams(seq, n):
+    return Counter(tuple(seq[i:i + n]) for i in range(len(seq) - n + 1))
+
+
+def corpus_bleu(list_of_references, hypotheses, max_n=4):
+    """nltk.translate.bleu_score.corpus_bleu(list_of_references, hypotheses, weights = uniform over 1 .. max_n), no smoothing -- the
+    published algorithm of the third-party call at evaluation/text.py:70-72 (nltk is not installed here), restated: per n the clipped
+    n-gram matches (a hypothesis n-gram counts at most as often as in the reference that has it most) and the hypothesis n-gram totals
+    (max(1, .) per sentence, as nltk's `modified_precision` does for hypotheses shorter than n) are summed over the corpus BEFORE the
+    division; brevity penalty from the summed hypothesis lengths and the summed closest reference lengths (ties -> the shorter reference).
+    Held to nltk's own documented values in tests/test_host_surface.py."""
+    num, den = [0] * max_n, [0] * max_n
     hyp_len = ref_len = 0
-    for ref, hyp in zip(references, hypotheses):
+    for refs, hyp in zip(list_of_references, hypotheses):
         hyp_len += len(hyp)
-        ref_len += len(ref)
+        ref_len += min((len(r) for r in refs), key=lambda rl: (abs(rl - len(hyp)), rl))
         for n in range(1, max_n + 1):
-            h = Counter(tuple(hyp[i:i + n]) for i in range(len(hyp) - n + 1))
-            r = Counter(tuple(ref[i:i + n]) for i in range(len(ref) - n + 1))
-            num[n - 1] += sum(min(c, r[g]) for g, c in h.items())
-            den[n - 1] += max(1, len(hyp) - n + 1)      # nltk modified_precision: Fraction(num, max(1, sum(counts))) also for hypotheses shorter than n
+            h = _ngrams(hyp, n)
+            best = Counter()
+            for r in refs:
+                for g, c in _ngrams(r, n).items():
+                    if c > best[g]:
+                        best[g] = c
+            num[n - 1] += sum(min(c, best[g]) for g, c in h.items())
+            den[n - 1] += max(1, len(hyp) - n + 1)
     if num[0] == 0 or min(num) == 0 or min(den) == 0:
         return 0.0
     logp = sum(math.log(n / d) for n, d in zip(num, den)) / max_n
     bp = 1.0 if hyp_len > ref_len else math.exp(1 - ref_len / float(max(hyp_len, 1)))
     return bp * math.exp(logp)
+
+
+def bleu_score(references, hypotheses, max_n=4):
+    """Corpus BLEU-4 with uniform weights, one reference per hypothesis: the call at evaluation/text.py:57-72
+    (`references = [[ref] for ref in references]`, then nltk's corpus_bleu)."""
+    return corpus_bleu([[ref] for ref in references], hypotheses, max_n)
 
 
 def score_files(path_ref, path_hyp):

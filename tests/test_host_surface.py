@@ -131,3 +131,28 @@ def test_data_generator_vs_reference_class(tmp_path):
     for g, w in zip(got, want):
         assert g["kw"] == w["kw"] and g["len"] == w["len"], (g["kw"], g["len"], w["len"])
         assert g["items"] == w["items"], g["kw"]
+
+
+def test_text_metrics_vs_the_published_values_of_the_third_party_libraries():
+    """model/evaluation/text.py:57-92 delegates BLEU to nltk (`nltk.translate.bleu_score.corpus_bleu`) and the edit distance to the `distance`
+    package; neither is installed here, so both are restated (latex_ocr_amd/model/evaluation/text.py).  What pins the restatements: the
+    known answers those libraries PUBLISH -- the doctest values in nltk's bleu_score.py (sentence_bleu 0.5045..., the mean of two sentence
+    scores 0.6223..., corpus_bleu of the two-sentence corpus 0.5920...: same sentences, one to three references, default uniform 4-gram
+    weights, no smoothing) and the examples of the `distance` README (levenshtein("lenvestein", "levenshtein") == 3)."""
+    from latex_ocr_amd.model.evaluation.text import corpus_bleu, bleu_score, levenshtein, edit_distance, exact_match_score
+    hyp1 = "It is a guide to action which ensures that the military always obeys the commands of the party".split()
+    ref1a = "It is a guide to action that ensures that the military will forever heed Party commands".split()
+    ref1b = "It is the guiding principle which guarantees the military forces always being under the command of the Party".split()
+    ref1c = "It is the practical guide for the army always to heed the directions of the party".split()
+    hyp2 = "he read the book because he was interested in world history".split()
+    ref2a = "he was interested in world history because he read the book".split()
+    s1 = corpus_bleu([[ref1a, ref1b, ref1c]], [hyp1])             # a one-sentence corpus = nltk's sentence_bleu
+    s2 = corpus_bleu([[ref2a]], [hyp2])
+    # (the doctests print the value and elide the rest: "0.5045..." = a prefix of repr(value))
+    assert repr(s1).startswith("0.5045")
+    assert repr((s1 + s2) / 2).startswith("0.6223")
+    assert repr(corpus_bleu([[ref1a, ref1b, ref1c], [ref2a]], [hyp1, hyp2])).startswith("0.5920")
+    assert bleu_score([ref2a], [hyp2]) == s2                      # the reference's call shape: one reference per hypothesis (evaluation/text.py:69-71)
+    assert levenshtein("lenvestein", "levenshtein") == 3 and levenshtein("kitten", "sitting") == 3 and levenshtein([], [1, 2]) == 2
+    assert abs(edit_distance([list("kitten")], [list("sitting")]) - (1 - 3 / 7.0)) < 1e-12
+    assert exact_match_score([[1, 2], [3]], [[1, 2], [4]]) == 0.5

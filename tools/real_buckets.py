@@ -24,7 +24,8 @@ def log(r):
         r["conv_fwd_dgrad_frac"], r["conv_wgrad_frac"], r["chain_fwd_us_per_step"], r["chain_bwd_us_per_step"], "" if r["chains"] else "NO CHAIN"), flush=True)
 
 
-rows = bench.real_buckets(torch, "cuda:0", steps=steps, batches=batches, log=log)
+shapes = [tuple(int(v) for v in x.split("x")) for x in os.environ["RB_SHAPES"].split(",")] if os.environ.get("RB_SHAPES") else None
+rows = bench.real_buckets(torch, "cuda:0", steps=steps, batches=batches, shapes=shapes, log=log)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"workload": "one training step (bf16, V=500, Adam) per real bucket of configs/data.json (after /2), lengths per latex_ocr_amd.synthetic.bucket_lengths", "rows": rows},
           open(os.path.join(ROOT, "gpurun_out", "%s_buckets.json" % tag), "w"), indent=1)
