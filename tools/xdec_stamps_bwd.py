@@ -9,8 +9,9 @@ from latex_ocr_amd.engine import Engine, _p
 from latex_ocr_amd.model.utils.image import pad_batch_images
 from latex_ocr_amd.model.utils.text import pad_batch_formulas
 
-B, H, W, V = 64, 128, 512, 500
-imgs, forms = synthetic.make_set(B, H, W, V, 30, 101, seed=1234)
+B, H, W, V = [int(x) for x in os.environ.get("XS_SHAPE", "64,128,512").split(",")] + [500]
+LLO, LHI = [int(x) for x in os.environ.get("XS_LEN", "30,101").split(",")]
+imgs, forms = synthetic.make_set(B, H, W, V, LLO, LHI, seed=1234)
 img = pad_batch_images(imgs)
 f, l = pad_batch_formulas(forms, V - 2, V - 1)
 T = f.shape[1]
