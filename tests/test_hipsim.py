@@ -480,6 +480,36 @@ def test_encoder_cnn_variant_and_no_positional_vs_oracle(dtype):
                 assert float(g @ r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30) > 0.97, k
 
 
+def test_dead_padding_rows_live_B_same_loss_and_gradients():
+    """lxo_shape.live_B (include/lxo.h): a batch filled up with DEAD rows -- formula length 0, so outside the loss mask of img2seq.py:68-71 -- gives the
+    loss and the gradients of the batch it was filled up from; the encoder reads the live images only (the image buffer handed over here HAS only the
+    live ones) and leaves zero features for the dead row.  f32, small widths: 2 live samples in a batch of 3 against the 2 alone."""
+    img, f, l = GOLD["img"], GOLD["formula"], GOLD["lengths"]
+    T = f.shape[1]
+    res = []
+    for pad in (0, 1):
+        B = 2 + pad
+        S = Sim(B, 32, 48, T, 11, dtype=0, seed=0, dims=SMALL)
+        ff = np.ascontiguousarray(np.concatenate([f, f[:pad]]))                     # the dead row: any valid token ids
+        ll = np.ascontiguousarray(np.concatenate([l, np.zeros(pad, l.dtype)]))      # ... and length 0
+        S.shape.live_B = 2 if pad else 0
+        S.ck(S.L.lxo_encoder_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), None), "enc")
+        S.ck(S.L.lxo_decoder_train_fwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(ff), None), "dec")
+        S.ck(S.L.lxo_ce_loss_fwd_bwd(S.sref(), ptr(S.ws), ptr(ff), ptr(ll), ctypes.c_float(1.0 / int(l.sum())), None), "loss")
+        S.ck(S.L.lxo_decoder_train_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(ff), ptr(S.grads), None), "decbwd")
+        S.ck(S.L.lxo_encoder_bwd(S.sref(), ptr(S.params), ptr(S.wpack), ptr(S.ws), ptr(img), ptr(S.grads), 6, 1, None), "encbwd")
+        st = S.region("loss", np.float32)[:2].copy()
+        if pad:
+            R = S.region("img", np.float32).size // B
+            assert np.all(S.region("img", np.float32)[2 * R:3 * R] == 0.0)                # the dead row's features
+        res.append((st, {k: S.grad(k).copy() for k, _, _ in S.specs}))
+    assert res[0][0][1] == res[1][0][1] == int(l.sum())                                    # n_words does not see the dead row
+    assert abs(res[0][0][0] - res[1][0][0]) <= 1e-6 * abs(res[0][0][0])
+    for k in res[0][1]:
+        a0, a1 = res[0][1][k], res[1][1][k]
+        assert np.abs(a0 - a1).max() <= 2e-6 * max(np.abs(a0).max(), 1e-6) + 1e-10, k
+
+
 def test_train_bwd_and_ready_entry_points_vs_golden():
     """lxo_encoder_bwd_ready (one call for a layer range, with a per-layer event table whose NULL entries are skipped) behind
     lxo_decoder_train_bwd against the golden gradients, and lxo_train_bwd (the backward pass in one call) from the same forward state: the
