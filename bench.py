@@ -199,10 +199,15 @@ def chain_phases(eng, torch, backward=False):
         hook(ctypes.c_void_p(0))
     s = buf.cpu().numpy().reshape(256, T, 16).astype(np.float64) * 0.01            # us
     d = s[:, 2:, 1:9] - s[:, 2:, 0:8]
+    # round 6: the chunk partials are polled hand-over words, no barrier behind the stream phase; the wait for them sits at the head of the NEXT phase
+    # (P4 / Q3) and ends at stamp 12 (0 where the build keeps the barrier)
+    poll = s[:, 2:, 12] - s[:, 2:, 4 if backward else 6]
+    poll_wait = float(poll[poll > 0].mean()) if (poll > 0).any() else 0.0
     names = (["Q1_dh_dctx", "barrier1", "Q2_attention_stream", "barrier2", "Q3_lstm_bwd", "barrier3", "Q4_carries", "barrier4"] if backward else
              ["P1_lstm", "barrier1", "P2_att_h", "barrier2", "P3_attention_stream", "barrier3", "P4_merge_o", "barrier4"])
     out = {n: round(float(d[:, :, i].mean()), 3) for i, n in enumerate(names)}
     out["step_us"] = round(float((s[:, 2:, 8] - s[:, 2:, 0]).mean()), 3)
+    out["partials_poll_wait"] = round(poll_wait, 3)
     return out
 
 
@@ -705,7 +710,7 @@ def main():
                     bytes_step = chain[0][2] / T                     # algorithmic bytes of one step: B * R * (E + C) * 2
                     # the stream's time = phase P3 + the wait behind it: the first blocks of the NEXT step are requested at the end of P3 and
                     # land before that barrier (loads return in order), so a quarter of a step's bytes arrives there
-                    stream_us = ph["P3_attention_stream"] + ph["barrier3"]
+                    stream_us = ph["P3_attention_stream"] + ph["barrier3"] + ph.get("partials_poll_wait", 0.0)      # phase + the hand-over wait behind it
                     a = bytes_step / (stream_us * 1e-6)
                     out["roofline_attention"] = {
                         "kernel": "xdec_fwd_kernel, phase P3 + the wait behind it (attention stream of one decoder step: B samples, att_exp + img streamed once; the other phases of the step are the LSTM / att_h / o-projection GEMMs and four XCD barriers)",
@@ -725,7 +730,7 @@ def main():
                 chain = [r for r in recs if r[0] == "xdec_bwd"]
                 if ph and chain:
                     bytes_step = chain[0][2] / T
-                    stream_us = ph["Q2_attention_stream"] + ph["barrier2"]       # as for the forward chain: phase + the wait behind it
+                    stream_us = ph["Q2_attention_stream"] + ph["barrier2"] + ph.get("partials_poll_wait", 0.0)       # as for the forward chain: phase + the wait behind it
                     a = bytes_step / (stream_us * 1e-6)
                     out["roofline_attention_bwd"] = {
                         "kernel": "xdec_bwd_kernel, phase Q2 + the wait behind it (attention stream of one BPTT step: d_e and d_att_h from att_exp + img streamed once; the other phases are the [d_h~ | d_ctx] / d_att_h W^T / carry GEMMs with the LSTM backward and four XCD barriers)",

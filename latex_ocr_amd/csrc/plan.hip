@@ -158,7 +158,7 @@ Plan::Plan(const lxo_shape& sh, int /*unused*/) : s(sh) {
     const size_t TB = (size_t)T * B;
     wb[W_DATTHB] = bf ? TB * E * 2 : 0;
     wb[W_ATT_IMG] = BL * R * E * esz;
-    wb[W_APART] = BK_ * 32 * (C + 4) * f4;         // chunk partials of the attention forward: at most 32 chunks per row, [max, sum, context] (the persistent chain pads a partial to C + 4)
+    wb[W_APART] = BK_ * 32 * (C + 16) * f4;        // chunk partials of the attention forward: at most 32 chunks per row, [max, sum, context] (the persistent chain pads a partial to C + 4 floats, or -- polled hand-over form, xdec.hip: PLW -- to C / 2 + 8 words of 8 bytes)
     wb[W_MEAN] = BL * C * f4;
     wb[W_EMB_IN] = TB * Dp * esz;
     wb[W_ZX] = TB * 4 * U * f4;

@@ -43,15 +43,15 @@ constexpr int XXH = XO + XU, XHC = XU + XC;
 constexpr int OFF_H = XO, OFF_HT = XO + XU, OFF_CTX = XO + 2 * XU;
 constexpr int XW = 8;                                            // waves per workgroup
 // which hand-overs of the forward chain are polled from {value, tag} words instead of meeting at an XCD barrier: 1 = h~ (P1 -> P2),
-// 2 = att_h (P2 -> P3), 8 = o (P4 -> the next step's P1).  A compile-time choice (a run-time one costs registers the chain does not have);
+// 2 = att_h (P2 -> P3), 8 = o (P4 -> the next step's P1), 4 (round 6) = the chunk partials (P3 -> P4; chains of four and eight samples).  A compile-time choice (a run-time one costs registers the chain does not have);
 // `make EXTRA=-DLXO_XDEC_LLMASK=0` builds the all-barriers variant for A/B runs (LXO_LIB_PATH selects the library).
 #ifndef LXO_XDEC_LLMASK
-#define LXO_XDEC_LLMASK 11
+#define LXO_XDEC_LLMASK 15
 #endif
 constexpr int kLL = LXO_XDEC_LLMASK;
-// the same for the backward chain: 1 = g_{t-1} (Q4 -> the next step's Q1), 2 = d_ctx (Q1 -> Q2)
+// the same for the backward chain: 1 = g_{t-1} (Q4 -> the next step's Q1), 2 = d_ctx (Q1 -> Q2), 4 (round 6) = the d_att_h chunk partials (Q2 -> Q3)
 #ifndef LXO_XDEC_LLMASK_B
-#define LXO_XDEC_LLMASK_B 3
+#define LXO_XDEC_LLMASK_B 7
 #endif
 constexpr int kLLB = LXO_XDEC_LLMASK_B;
 
@@ -76,6 +76,14 @@ constexpr int kPF = LXO_XDEC_PF;
 constexpr int kPFB = LXO_XDEC_PFB;
 
 constexpr int PST = XC + 4;                                      // floats per chunk partial: [context 512 | max | sum | pad] (16-byte rows)
+// kLL & 4: the chunk partials (P3 -> P4) as polled hand-over words too: per (sample, chunk) PLW 8-byte words -- word j < 256 = channels 2j, 2j + 1 of the
+// unnormalised context as a pack28 pair (below: two 28-bit floats + an 8-bit step tag, so that a 16-byte request still carries four channels),
+// words 256 / 257 = {the chunk's max, step tag} / {its sum, step tag} (f32 bits).  They live in the same ws region as the plain
+// partials ("att_part"); the launcher zeroes them (a tag of an earlier launch must not pass).  No XCD barrier is left in a forward step then: every
+// buffer a workgroup rewrites in step t + 1 was last read in a phase that ALL workgroups have left before any of them can get there (the data
+// dependence o_t -> h~_{t+1} -> att_h_{t+1} runs through every workgroup of the chain).
+constexpr int PLW = 264;                                        // = XC / 2 + 8: ws region "att_part" is sized for it (plan.hip)
+static_assert(PLW * 2 <= XC + 16, "plan.hip sizes att_part with C + 16 floats per partial");
 constexpr int SCMAX = 2432;                                      // rows of one attention chunk (raw scores stay in LDS until P4; static LDS is 64 KB, 58.4 KB used).  2432: the largest bucket of the reference (800 x 800 -> 9604 regions, configs/data.json:28) at B = 64 is 4 chunks of 2401 rows
 
 typedef __attribute__((ext_vector_type(4))) float v4f;
@@ -168,6 +176,36 @@ LXO_DEV bool ll_wait(u32x4 (&w)[N], rsrc_t r, const unsigned (&off)[N], unsigned
     }
 }
 
+// Hand-over words for the chunk partials (round 6): TWO values of 28 bits each -- an f32 cut to 19 mantissa bits (relative error 2^-20) -- and an
+// 8-bit step tag in one 8-byte word, so that a 16-byte request still carries four values (the merges that consume them are the kernels' register
+// peaks and cannot afford twice the requests) without the 2^-9 of a bf16 pair: the partial contexts of a sample feed s = <ctx, d_ctx> in BPTT and
+// the d_att_h partials cancel (sum_r d_e_r = 0), so bf16 pairs cost dW_att_h a factor of 5 in noise (cosine against the oracle 0.99993 at B = 64
+// where this form gives 0.99996+).  Tags are 1 .. 255 (the words are zeroed per launch; the word of step t - 1 is what a step-t poll may still see).
+LXO_DEV u32x2 pack28(float x0, float x1, unsigned tag8) {
+    const unsigned a = (__float_as_uint(x0) + 8u) >> 4, b = (__float_as_uint(x1) + 8u) >> 4;      // round to nearest (a carry into the exponent is the right answer)
+    return u32x2{(a & 0x0FFFFFFFu) | (b << 28), ((b >> 4) & 0x00FFFFFFu) | (tag8 << 24)};
+}
+LXO_DEV float unpack28_lo(unsigned lo) { return __uint_as_float(lo << 4); }
+LXO_DEV float unpack28_hi(unsigned lo, unsigned hi) { return __uint_as_float(((lo >> 28) | (hi << 4)) << 4); }
+LXO_DEV unsigned tag8_of(int t) { return (unsigned)(t % 255) + 1u; }
+// ll_wait for such words: the tag is the top byte of every odd dword
+template <int N>
+LXO_DEV bool ll_wait8(u32x4 (&w)[N], rsrc_t r, const unsigned (&off)[N], unsigned tag8, unsigned* err, int* s_dead) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { w[j] = l2_load16(r, off[j]); }
+#pragma unroll
+        for (int j = 0; j < N; ++j) ok = ok && (w[j][1] >> 24) == tag8 && (w[j][3] >> 24) == tag8;
+        if (__ballot(!ok) == 0ull) return true;
+        if (*s_dead || wall_clock64() - t0 > 20000000ull) {
+            if ((threadIdx.x & 63) == 0) { *s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 3u; }
+            return false;
+        }
+    }
+}
+
 // One block of ATT_U rows per wave of the attention chunk: scores from the att_img rows (raw bf16 words in xa), online-softmax update of
 // (m, l, acc) with the img rows (xi).  Rows at or beyond `an` were loaded clamped and contribute nothing.
 // EXPD: xa holds E_x = e^{2x}, ah holds E_a = e^{2 att_h}, bt holds -2 beta: with r = 1 / (1 + E_x E_a), tanh = 1 - 2r and the score is
@@ -236,6 +274,7 @@ LXO_DEV void att_load(u32x4 (&xi)[ATT_U], u32x2 (&xa)[ATT_U], rsrc_t rim, rsrc_t
 template <int NB, int ATT_U, bool EXPD>
 __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     constexpr int NQ = 32 / NB;                                  // attention chunks per sample = workgroups per sample
+    constexpr bool PP = (kLL & 4) != 0 && NB >= 4;               // polled chunk partials (one or two samples per chain: their 4-request poll groups spill 80 .. 260 bytes; they keep the barrier)
     // cross-wave partial tiles of the GEMM phases ([wave][row][column]) and the waves' partial contexts of P3 ([wave][channel]) share 16 KB:
     // the phases that use one are a workgroup barrier away from the phases that use the other
     __shared__ __attribute__((aligned(16))) float redbuf[XW * 8 * 64];
@@ -531,6 +570,21 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e] * sw;
             __syncthreads();
+            if constexpr (PP) {
+                unsigned* pw = reinterpret_cast<unsigned*>(p.part) + ((long long)ab * NQ + aq) * (PLW * 2);
+                if (tid == 0) {
+                    float lt = 0.f;
+#pragma unroll
+                    for (int w = 0; w < XW; ++w) lt += wred[XW + w];
+                    const u32x4 st4 = {__float_as_uint(mc), (unsigned)(t + 1), __float_as_uint(lt), (unsigned)(t + 1)};
+                    *reinterpret_cast<u32x4*>(pw + 256 * 2) = st4;
+                }
+                float tsum = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) tsum += redc[w][tid];
+                const float other = __shfl_xor(tsum, 1);
+                if (!(tid & 1)) *reinterpret_cast<u32x2*>(pw + (tid >> 1) * 2) = pack28(tsum, other, tag8_of(t));
+            } else {
             if (tid == 0) {
                 float lt = 0.f;
 #pragma unroll
@@ -543,13 +597,15 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 for (int w = 0; w < XW; ++w) tsum += redc[w][tid];
                 pout[tid] = tsum;
             }
+            }
         }
         XSTAMP(5);
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        if constexpr (!PP) xbar(xsync, rank, ++ph, err, &s_dead);
         XSTAMP(6);
         // =========================== P4: merge the chunks; alpha; ctx; o projection ===========================
         {
-            const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * PST, (unsigned)(NB * NQ * PST) * 4u);
+            const rsrc_t rpart = PP ? make_rsrc(reinterpret_cast<const unsigned*>(p.part) + (long long)b0 * NQ * (PLW * 2), (unsigned)(NB * NQ * PLW) * 8u)
+                                           : make_rsrc(p.part + (long long)b0 * NQ * PST, (unsigned)(NB * NQ * PST) * 4u);
             // the h~ half of the A operand (waves 0..3) and the chunk partials of this thread's 4 channels for its thread group's samples
             // (four groups of 128 threads split the NB samples): all requested up front, 16 bytes per request
             u32x4 a[4];
@@ -565,6 +621,30 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             // B = 64) costs the merge one more L2 round trip and the step 1 us less: decoder forward 2.40 -> 2.30 ms
             constexpr int QG = NB >= 4 ? 2 : 4;
             u32x4 pc[SPG][QG];
+            if constexpr (PP) {
+                // polled: the words of this thread's channel pair pairs ({bf16 x 2, tag} x 2 per 16 bytes) of the first chunk group, and -- wave 0 -- the
+                // {max, tag, sum, tag} words of every (sample, chunk) of the chain (NB * NQ = 32 of them: lanes 32 .. 63 repeat lane 31's)
+                if (wave == 0) {
+                    u32x4 w1[1];
+                    const unsigned off1[1] = {(unsigned)((min(tid, NB * NQ - 1) * PLW + 256) * 8)};
+                    ll_wait<1>(w1, rpart, off1, (unsigned)(t + 1), err, &s_dead);
+                    if (tid < NB * NQ) { (&stm[0][0])[tid] = __uint_as_float(w1[0][0]); (&stl[0][0])[tid] = __uint_as_float(w1[0][2]); }
+                }
+                if (tg < NG) {
+                    u32x4 wq[SPG * QG];
+                    unsigned offq[SPG * QG];
+#pragma unroll
+                    for (int si = 0; si < SPG; ++si)
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) offq[si * QG + q] = (unsigned)((((tg * SPG + si) * NQ + q) * PLW + (c4 >> 1)) * 8);
+                    ll_wait8<SPG * QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
+#pragma unroll
+                    for (int si = 0; si < SPG; ++si)
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) pc[si][q] = wq[si * QG + q];
+                }
+                XSTAMP(12);                                       // measurement only: the polled partials have arrived (stamp 6 -> 12 = the wait that used to sit at the barrier behind P3)
+            } else {
             if (tg < NG) {
 #pragma unroll
                 for (int si = 0; si < SPG; ++si)
@@ -574,6 +654,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
             if (tid < NB * NQ) {
                 const unsigned o = (unsigned)((tid * PST + XC) * 4);
                 (&stm[0][0])[tid] = l2_load4(rpart, o); (&stl[0][0])[tid] = l2_load4(rpart, o + 4);
+            }
             }
             __syncthreads();
             if (tid < NB) {
@@ -600,12 +681,27 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
 #pragma unroll
                         for (int q = 0; q < QG; ++q) {
                             const float w = wgt[sidx][q0 + q];
+                            if constexpr (PP) {
+                                v[0] = fmaf(unpack28_lo(pc[si][q][0]), w, v[0]); v[1] = fmaf(unpack28_hi(pc[si][q][0], pc[si][q][1]), w, v[1]);
+                                v[2] = fmaf(unpack28_lo(pc[si][q][2]), w, v[2]); v[3] = fmaf(unpack28_hi(pc[si][q][2], pc[si][q][3]), w, v[3]);
+                            } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaf(__uint_as_float(pc[si][q][e]), w, v[e]);
+                            }
                         }
                         if (q0 + QG < NQ) {                       // next group of chunks (compile-time condition: NQ, QG are constants)
+                            if constexpr (PP) {
+                                u32x4 wq[QG];
+                                unsigned offq[QG];
+#pragma unroll
+                                for (int q = 0; q < QG; ++q) offq[q] = (unsigned)(((sidx * NQ + q0 + QG + q) * PLW + (c4 >> 1)) * 8);
+                                ll_wait8<QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
+#pragma unroll
+                                for (int q = 0; q < QG; ++q) pc[si][q] = wq[q];
+                            } else {
 #pragma unroll
                             for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + q0 + QG + q) * PST + c4) * 4));
+                            }
                         }
                     }
                     const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
@@ -1390,27 +1486,52 @@ __global__ __launch_bounds__(512) void xdec_bwd_kernel(XDecBwd p) {
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < XW; ++w) v += redc[w][tid];
-                p.part[((long long)ab * NQ + aq) * XE + tid] = v;
+                if constexpr (kLLB & 4) {
+                    // polled hand-over: 128 pack28 words per (sample, chunk) -- the kilobyte the plain f32 partial took
+                    const float other = __shfl_xor(v, 1);
+                    if (!(tid & 1)) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned*>(p.part) + (((long long)ab * NQ + aq) * (XE / 2) + (tid >> 1)) * 2) = pack28(v, other, tag8_of(t));
+                } else p.part[((long long)ab * NQ + aq) * XE + tid] = v;
             }
         }
         XSTAMP(3);
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        // (kLLB & 4: no barrier here.  Q3 also reads d_h~ (Q1 of other workgroups) and the carried d_h (Q4 of the previous step): both were stored in front of a
+        // workgroup barrier -- on gfx950 a wait for the store acknowledgements -- that their producers passed before they stored the partial / d_ctx words Q3's
+        // and Q2's polls have seen; and nobody rewrites the partial words of this step before every workgroup has read them: the next Q2 needs d_ctx of
+        // workgroups that are past this step's Q3.)
+        if constexpr (!(kLLB & 4)) xbar(xsync, rank, ++ph, err, &s_dead);
         XSTAMP(4);
         // =========================== Q3: d_att_h; d_h; LSTM cell backward ===========================
         {
-            const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * XE, (unsigned)(NB * NQ * XE) * 4u);
+            const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * XE, (unsigned)(NB * NQ * XE) * 4u);      // (kLLB & 4: 128 pack28 words per partial = the same kilobyte)
             const rsrc_t rcar = make_rsrc(p.carry_h, (unsigned)B * XU * 4u);
             // wave `slot` sums 4 of the NQ chunk partials of sample slot / QS; the QS groups of a sample meet in LDS
             const int srow = wave / QS, sqg = wave - srow * QS;
             u32x4 pc[4];
+            if constexpr (kLLB & 4) {
+                unsigned off[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) off[j] = (unsigned)((((srow * NQ + sqg * 4 + j) * (XE / 2)) + lane * 2) * 8);
+                ll_wait8<4>(pc, rpart, off, tag8_of(t), err, &s_dead);
+                XSTAMP(12);                                       // measurement only: the polled d_att_h partials have arrived
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) pc[j] = l2_load16(rpart, (unsigned)((((srow * NQ + sqg * 4 + j) * XE) + lane * 4) * 4));
+            }
             const float dhm = l2_load4(rdh, (unsigned)(((b0 + e3r) * XHC + u0 + e3u) * 4));
             const float chv = l2_load4(rcar, (unsigned)(((b0 + e3r) * XU + u0 + e3u) * 4));
             {
                 f32x4 v;
+                if constexpr (kLLB & 4) {
+                    // chunk j: words {c0 c1 tag}{c2 c3 tag}; the same association as the plain form: (p0 + p1) + (p2 + p3)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        v[2 * h] = (unpack28_lo(pc[0][2 * h]) + unpack28_lo(pc[1][2 * h])) + (unpack28_lo(pc[2][2 * h]) + unpack28_lo(pc[3][2 * h]));
+                        v[2 * h + 1] = (unpack28_hi(pc[0][2 * h], pc[0][2 * h + 1]) + unpack28_hi(pc[1][2 * h], pc[1][2 * h + 1])) + (unpack28_hi(pc[2][2 * h], pc[2][2 * h + 1]) + unpack28_hi(pc[3][2 * h], pc[3][2 * h + 1]));
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (__uint_as_float(pc[0][e]) + __uint_as_float(pc[1][e])) + (__uint_as_float(pc[2][e]) + __uint_as_float(pc[3][e]));
+                }
                 *reinterpret_cast<f32x4*>(&redc[wave][lane * 4]) = v;
             }
             __syncthreads();
@@ -1546,6 +1667,7 @@ int lxo_launch_xdec_fwd(const XDecFwd& p0, int U, int O, int C, int E, hipStream
     }
     if (!dev_ok) return -2;
     HIPRC(hipMemsetAsync(p.sync, 0, kXDecBlockBytes, st));
+    if (kLL & 4) HIPRC(hipMemsetAsync(p.part, 0, (size_t)p.B * nq * PLW * 8, st));      // the polled chunk partials: no tag of an earlier launch may pass
 
     // rows per wave and block (two blocks in flight).  4: the largest count whose two blocks + the resident weights fit the register file
     // without spills (5 .. 7 spill 68 .. 208 bytes per lane into the serial phases and lose more there than their fewer padded rows gain:
@@ -1611,6 +1733,7 @@ int lxo_launch_xdec_bwd(const XDecBwd& p0, int U, int O, int C, int E, hipStream
     if (dev_ok < 0) dev_ok = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256) ? 1 : 0;
     if (!dev_ok) return -2;
     HIPRC(hipMemsetAsync(p.sync, 0, kXDecBlockBytes, st));
+    if (kLLB & 4) HIPRC(hipMemsetAsync(p.part, 0, (size_t)p.B * nq * XE * 4, st));      // the polled d_att_h partials (the forward chain's words lie there: no tag of theirs may pass)
     int rc;
     switch (nb) {
     case 1: rc = launch_bwd_nb<1>(p, st); break;

@@ -28,6 +28,9 @@ s = buf.cpu().numpy().reshape(256, T, 16).astype(np.float64) * 0.01      # us
 names = ["P1 lstm", "barrier 1", "P2 att_h", "barrier 2", "P3 attention", "barrier 3", "P4 merge + o", "barrier 4"]
 d = s[:, 2:, 1:9] - s[:, 2:, 0:8]                                          # [wg][t][phase]
 print("chain status", eng.chain_status(), " step (stamp 0 -> 8), mean over workgroups and steps: %.2f us" % (s[:, 2:, 8] - s[:, 2:, 0]).mean())
+pw = s[:, 2:, 12] - s[:, 2:, 6]
+if (pw > 0).any():
+    print("inside P4: the polled chunk partials arrived %.2f us after the phase start (mean; the wait that used to sit at the XCD barrier behind the stream phase)" % pw[pw > 0].mean())
 for i, n in enumerate(names):
     print("%-14s mean %6.2f us   min over workgroups %6.2f   max over workgroups %6.2f" % (n, d[:, :, i].mean(), d[:, :, i].mean(1).min(), d[:, :, i].mean(1).max()))
 # the barrier waits are the phase imbalance: work phase of the slowest workgroup of the XCD
