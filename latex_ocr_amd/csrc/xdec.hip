@@ -777,6 +777,7 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
     // 2 rows per wave and block in flight (the training chain: 4): the decode form carries more loop-invariant addresses (token table, ids,
     // arg-max words) and with 4 rows the allocator spills 55 dwords of them into the serial phases; with 2 it spills 9
     constexpr int NQ = 32 / NB, ATT_U = 2;
+    constexpr bool PP = (kLL & 4) != 0 && NB >= 4;               // polled chunk partials, as in the training chain (tags restart with every launch: the launcher zeroes the words)
     __shared__ __attribute__((aligned(16))) float redbuf[XW * 8 * 64];
     float (*red)[8][64] = reinterpret_cast<float (*)[8][64]>(redbuf);
     float (*redc)[XC] = reinterpret_cast<float (*)[XC]>(redbuf);
@@ -1078,6 +1079,21 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) redc[wave][c0 + e] = acc[e] * sw;
             __syncthreads();
+            if constexpr (PP) {
+                unsigned* pw = reinterpret_cast<unsigned*>(p.part) + ((long long)ab * NQ + aq) * (PLW * 2);
+                if (tid == 0) {
+                    float lt = 0.f;
+#pragma unroll
+                    for (int w = 0; w < XW; ++w) lt += wred[XW + w];
+                    const u32x4 st4 = {__float_as_uint(mc), (unsigned)(t + 1), __float_as_uint(lt), (unsigned)(t + 1)};
+                    *reinterpret_cast<u32x4*>(pw + 256 * 2) = st4;
+                }
+                float tsum = 0.f;
+#pragma unroll
+                for (int w = 0; w < XW; ++w) tsum += redc[w][tid];
+                const float other = __shfl_xor(tsum, 1);
+                if (!(tid & 1)) *reinterpret_cast<u32x2*>(pw + (tid >> 1) * 2) = pack28(tsum, other, tag8_of(t));
+            } else {
             if (tid == 0) {
                 float lt = 0.f;
 #pragma unroll
@@ -1090,14 +1106,16 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                 for (int w = 0; w < XW; ++w) tsum += redc[w][tid];
                 pout[tid] = tsum;
             }
+            }
         }
-        xbar(xsync, rank, ++ph, err, &s_dead);
+        if constexpr (!PP) xbar(xsync, rank, ++ph, err, &s_dead);
 #ifdef LXO_TEST_DEC_FAULT          // diagnostic build only (never in liblxo.so): chain 3 declares itself broken in step 21 -- profiles/r05_dec_fault_fallback.txt
         if (tg == 21 && xcc == 3u && tid == 0) { s_dead = 1; *reinterpret_cast<volatile unsigned*>(err) = 9u; }
 #endif
         // =========================== P4: merge the chunks; ctx; o projection ===========================
         {
-            const rsrc_t rpart = make_rsrc(p.part + (long long)b0 * NQ * PST, (unsigned)(NB * NQ * PST) * 4u);
+            const rsrc_t rpart = PP ? make_rsrc(reinterpret_cast<const unsigned*>(p.part) + (long long)b0 * NQ * (PLW * 2), (unsigned)(NB * NQ * PLW) * 8u)
+                                    : make_rsrc(p.part + (long long)b0 * NQ * PST, (unsigned)(NB * NQ * PST) * 4u);
             u32x4 a[4];
             if (wave < 4) {
 #pragma unroll
@@ -1107,6 +1125,27 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
             const int tg4 = tid >> 7, c4 = (tid & 127) * 4;
             constexpr int QG = NB >= 4 ? 2 : 4;
             u32x4 pc[SPG][QG];
+            if constexpr (PP) {
+                if (wave == 0) {
+                    u32x4 w1[1];
+                    const unsigned off1[1] = {(unsigned)((min(tid, NB * NQ - 1) * PLW + 256) * 8)};
+                    ll_wait<1>(w1, rpart, off1, (unsigned)(t + 1), err, &s_dead);
+                    if (tid < NB * NQ) { (&stm[0][0])[tid] = __uint_as_float(w1[0][0]); (&stl[0][0])[tid] = __uint_as_float(w1[0][2]); }
+                }
+                if (tg4 < NG) {
+                    u32x4 wq[SPG * QG];
+                    unsigned offq[SPG * QG];
+#pragma unroll
+                    for (int si = 0; si < SPG; ++si)
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) offq[si * QG + q] = (unsigned)((((tg4 * SPG + si) * NQ + q) * PLW + (c4 >> 1)) * 8);
+                    ll_wait8<SPG * QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
+#pragma unroll
+                    for (int si = 0; si < SPG; ++si)
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) pc[si][q] = wq[si * QG + q];
+                }
+            } else {
             if (tg4 < NG) {
 #pragma unroll
                 for (int si = 0; si < SPG; ++si)
@@ -1116,6 +1155,7 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
             if (tid < NB * NQ) {
                 const unsigned o = (unsigned)((tid * PST + XC) * 4);
                 (&stm[0][0])[tid] = l2_load4(rpart, o); (&stl[0][0])[tid] = l2_load4(rpart, o + 4);
+            }
             }
             __syncthreads();
             if (tid < NB) {
@@ -1140,12 +1180,27 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
 #pragma unroll
                         for (int q = 0; q < QG; ++q) {
                             const float w = wgt[sidx][q0 + q];
+                            if constexpr (PP) {
+                                v[0] = fmaf(unpack28_lo(pc[si][q][0]), w, v[0]); v[1] = fmaf(unpack28_hi(pc[si][q][0], pc[si][q][1]), w, v[1]);
+                                v[2] = fmaf(unpack28_lo(pc[si][q][2]), w, v[2]); v[3] = fmaf(unpack28_hi(pc[si][q][2], pc[si][q][3]), w, v[3]);
+                            } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaf(__uint_as_float(pc[si][q][e]), w, v[e]);
+                            }
                         }
                         if (q0 + QG < NQ) {
+                            if constexpr (PP) {
+                                u32x4 wq[QG];
+                                unsigned offq[QG];
+#pragma unroll
+                                for (int q = 0; q < QG; ++q) offq[q] = (unsigned)(((sidx * NQ + q0 + QG + q) * PLW + (c4 >> 1)) * 8);
+                                ll_wait8<QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
+#pragma unroll
+                                for (int q = 0; q < QG; ++q) pc[si][q] = wq[q];
+                            } else {
 #pragma unroll
                             for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + q0 + QG + q) * PST + c4) * 4));
+                            }
                         }
                     }
                     const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
@@ -1706,6 +1761,7 @@ int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_
     HIPRC(hipMemsetAsync(p.sync, 0, 8 * 64 * 4, st));
     HIPRC(hipMemsetAsync(p.sync + 8 * 64 + 1, 0, kXDecBlockBytes - (8 * 64 + 1) * 4, st));
     HIPRC(hipMemsetAsync(p.sync + kXDecBlockBytes / 4 + kXDecSyncBytes / 4, 0, (size_t)p.B * 32 * 8, st));      // the arg-max words (block 1's hand-over area)
+    if ((kLL & 4) && nb >= 4) HIPRC(hipMemsetAsync(p.part, 0, (size_t)p.B * nq * PLW * 8, st));               // the polled chunk partials (tags restart with every launch)
     switch (nb) {
     case 1: return launch_dec_nb<1>(p, st);
     case 2: return launch_dec_nb<2>(p, st);
