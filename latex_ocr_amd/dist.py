@@ -25,7 +25,8 @@ How a bucket's all-reduce is ordered behind the kernels that produce it: NOT wit
 dependent-launch chains by ~0.25 ms per step (tools/queue_probe.py: one such wait per step is enough, every event flag
 behaves the same, the reverse direction -- the compute stream waiting for another stream -- is free).  So the compute
 stream only RECORDS an event per bucket; a helper thread waits for it on the host and then enqueues the collective on
-the side stream ("host-ordered", the default on a GPU; LXO_DP_HOST_ORDERED=0 restores the stream-side wait).
+the side stream ("host-ordered": LXO_DP_HOST_ORDERED=1; the default on a GPU in rounds 3-5).  Round 6: with the decoder in two persistent launches
+the stream-side wait measures FASTER than the helper thread (7.47 vs 7.52 ms at world 1) and is the default again.
 """
 import ctypes
 import os
@@ -97,7 +98,11 @@ class DataParallel(object):
         self._cnt_i = 0
         self.grad_dtype = None                 # None = reduce gradients as f32 (34.5 MB); torch.bfloat16 halves the bytes (opt-in, see reduce_range_fn)
         self.exposed_ms = []                   # (start, end) event pairs around finish(): the all-reduce time the compute stream waited for
-        ho = os.environ.get("LXO_DP_HOST_ORDERED", "1")
+        # round 6: the default is the stream-side wait (side.wait_event) again.  Host ordering was introduced in round 3 because a stream waiting for a
+        # compute-stream event slowed the ~1000 dependent launches of the launch-per-step decoder by 0.25 ms per step; with the decoder in two persistent
+        # launches that cost is gone (world 1 on RCCL: 7.46-7.48 ms stream-ordered, 7.50-7.55 host-ordered, 7.37 without the exchange) and the
+        # stream-ordered form needs no helper thread and does not stop the host in finish().  LXO_DP_HOST_ORDERED=1 restores the helper thread.
+        ho = os.environ.get("LXO_DP_HOST_ORDERED", "0")
         self.host_ordered = (self.cuda and ho == "1") or ho == "force"       # "force": also on CPU tensors (gloo tests of the helper thread)
         self._q = None
         self._err = None

@@ -31,9 +31,10 @@ def _data(n, seed=5):
     return pad_batch_images(imgs), f, l
 
 
-def _worker(rank, port, mode, q):
+def _worker(rank, port, mode, q, host_ordered="0"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["LXO_DP_HOST_ORDERED"] = host_ordered            # "0": buckets ordered by stream waits (the default), "1": by the helper thread
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as td
     td.init_process_group("gloo", rank=rank, world_size=2)      # control plane only: the 128-byte RCCL id, host barriers
@@ -69,11 +70,11 @@ def _worker(rank, port, mode, q):
     td.destroy_process_group()
 
 
-def _run(mode):
+def _run(mode, host_ordered="0"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 34500 + os.getpid() % 2000 + (31 if mode == "f32" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, port, mode, q)) for r in range(2)]
+    port = 34500 + os.getpid() % 2000 + (31 if mode == "f32" else 0) + (7 if host_ordered == "1" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, port, mode, q, host_ordered)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda r: r[0])
@@ -99,8 +100,9 @@ def test_two_rccl_ranks_equal_one_process_f32():
     assert np.array_equal(res[0][3], res[1][3])                 # replicas bit-identical
 
 
-def test_fifty_steps_with_the_chains_beside_rccl_bf16():
-    res = _run("bf16")
+@pytest.mark.parametrize("host_ordered", ["0", "1"])
+def test_fifty_steps_with_the_chains_beside_rccl_bf16(host_ordered):
+    res = _run("bf16", host_ordered)
     for rank, losses, _, w, info in res:
         assert info["ranks_seen"] == 2
         assert info["chain_used"] and info["chain_used_bwd"], info
