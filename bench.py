@@ -770,6 +770,14 @@ def main():
                         out.update(cpu_baselines_secondary(eng, torch, dev, V))
                     except Exception as e:
                         out["cpu_baselines_secondary_error"] = repr(e)
+        # librccl prints a version banner through C stdio at its first communicator (secondary.data_parallel_world1, or the N > 1 run itself): on a pipe it
+        # would sit in the C buffer until exit and land BEHIND the JSON line -- flush it out first, so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist is not None:
         import torch.distributed as td
