@@ -54,6 +54,10 @@ class LxoComm(object):
             td.broadcast_object_list(box, src=0)
         self.handle = ctypes.c_void_p()
         self._ck(self.lib.lxo_comm_init(box[0], rank, world, ctypes.byref(self.handle)), "lxo_comm_init")
+        try:                                                       # librccl prints its version banner through C stdio at the first communicator: out with it now,
+            ctypes.CDLL(None).fflush(None)                         # not at process exit behind whatever the caller prints last (bench.py's JSON line, on every rank's pipe)
+        except Exception:
+            pass
         r, w = ctypes.c_int(-1), ctypes.c_int(-1)
         self._ck(self.lib.lxo_comm_info(self.handle, ctypes.byref(r), ctypes.byref(w)), "lxo_comm_info")
         assert (r.value, w.value) == (rank, world), (r.value, w.value, rank, world)
