@@ -3,7 +3,8 @@
 The reference trains at batch 3 (configs/training.json:6), buckets by image shape in groups of 20 (model/utils/data_generator.py:41,84-122)
 and evaluates at 20 (evaluate_txt.py:42); its images come in the 21 sizes of configs/data.json:22-28 (halved by the build-time downsample:
 50x120 ... 160x400, 800x800).  The persistent decoder chains (csrc/xdec.hip) take 8 / 16 / 32 / 64 rows, so Engine.forward fills such a
-batch up with DEAD rows (copies of its own samples with formula length 0: outside the loss mask of img2seq.py:68-71).  Held here:
+batch up with DEAD rows (token ids copied from its own samples, formula length 0: outside the loss mask of img2seq.py:68-71; lxo_shape.live_B keeps the
+encoder on the live images and gives the dead rows zero features).  Held here:
 
 * B = 3 and B = 20 report chain_used and chain_used_bwd;
 * the padded bf16 chain step == the f32 parity mode on the UNPADDED batch (launch-per-step kernels) within the existing bf16 bars, and the
