@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     __shared__ __attribute__((aligned(16))) bf16_t actx[16][XC + 8];   // P4: merged contexts as the A tile of the o projection   16.6 KB
     __shared__ float sc[SCMAX];                                  // raw scores of this workgroup's chunk                   16 KB
     __shared__ float cst[8][16];                                 // c state of this workgroup's 16 units (lives here for all T steps)
-    __shared__ float stm[NB][NQ], stl[NB][NQ], wgt[NB][NQ], smax[NB], sinv[NB];
+    __shared__ float wgt[NB][NQ], smax[NB], sinv[NB];
     __shared__ float wred[2 * XW];
     __shared__ int s_rank, s_dead;
 
@@ -614,13 +614,18 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rn, (unsigned)(((b0 + arow) * p.RECB + OFF_HT + wave * 128 + ks * 32 + g4 * 8) * 2));
             }
             constexpr int SPG = NB >= 4 ? NB / 4 : 1, NG = NB / SPG;      // samples per thread group, groups that have samples
+            // chains of one or two samples: the 32 / 16 chunk partials of a sample are split over the 4 / 2 thread groups (8 chunks each = two rounds of
+            // four requests; one group per sample walked them in eight / four dependent rounds: P4 5.6 us of a 12.2 us step at B = 8) and the groups' sums meet in LDS
+            constexpr int GPS = NB >= 4 ? 1 : 4 / NB, CPG = NQ / GPS;
             const int tg = tid >> 7, c4 = (tid & 127) * 4;
+            const int gsm = tg / GPS, cb = (tg - gsm * GPS) * CPG;      // this thread group's sample (block) and first chunk
             // chunks requested at a time per sample.  Every request in flight pins four destination registers, and this merge is where the
             // kernel's register demand peaks: with 8 x 16 bytes in flight per thread the allocator kept 17 dwords of loop-invariant
             // addresses in scratch and reloaded them (behind `vmcnt(0)`) in every serial phase -- 4 in flight (2 samples x 2 chunks at
             // B = 64) costs the merge one more L2 round trip and the step 1 us less: decoder forward 2.40 -> 2.30 ms
             constexpr int QG = NB >= 4 ? 2 : 4;
             u32x4 pc[SPG][QG];
+            float st_m = 0.f, st_l = 0.f;                       // wave 0: {max, sum} of (sample, chunk) = lane (lanes 32 .. 63 repeat lane 31's)
             if constexpr (PP) {
                 // polled: the words of this thread's channel pair pairs ({bf16 x 2, tag} x 2 per 16 bytes) of the first chunk group, and -- wave 0 -- the
                 // {max, tag, sum, tag} words of every (sample, chunk) of the chain (NB * NQ = 32 of them: lanes 32 .. 63 repeat lane 31's)
@@ -628,15 +633,15 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                     u32x4 w1[1];
                     const unsigned off1[1] = {(unsigned)((min(tid, NB * NQ - 1) * PLW + 256) * 8)};
                     ll_wait<1>(w1, rpart, off1, (unsigned)(t + 1), err, &s_dead);
-                    if (tid < NB * NQ) { (&stm[0][0])[tid] = __uint_as_float(w1[0][0]); (&stl[0][0])[tid] = __uint_as_float(w1[0][2]); }
+                    st_m = __uint_as_float(w1[0][0]); st_l = __uint_as_float(w1[0][2]);
                 }
-                if (tg < NG) {
+                if (gsm < NG) {
                     u32x4 wq[SPG * QG];
                     unsigned offq[SPG * QG];
 #pragma unroll
                     for (int si = 0; si < SPG; ++si)
 #pragma unroll
-                        for (int q = 0; q < QG; ++q) offq[si * QG + q] = (unsigned)((((tg * SPG + si) * NQ + q) * PLW + (c4 >> 1)) * 8);
+                        for (int q = 0; q < QG; ++q) offq[si * QG + q] = (unsigned)((((gsm * SPG + si) * NQ + cb + q) * PLW + (c4 >> 1)) * 8);
                     ll_wait8<SPG * QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
 #pragma unroll
                     for (int si = 0; si < SPG; ++si)
@@ -645,42 +650,45 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                 }
                 XSTAMP(12);                                       // measurement only: the polled partials have arrived (stamp 6 -> 12 = the wait that used to sit at the barrier behind P3)
             } else {
-            if (tg < NG) {
+            if (gsm < NG) {
 #pragma unroll
                 for (int si = 0; si < SPG; ++si)
 #pragma unroll
-                    for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)((((tg * SPG + si) * NQ + q) * PST + c4) * 4));
+                    for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)((((gsm * SPG + si) * NQ + cb + q) * PST + c4) * 4));
             }
-            if (tid < NB * NQ) {
-                const unsigned o = (unsigned)((tid * PST + XC) * 4);
-                (&stm[0][0])[tid] = l2_load4(rpart, o); (&stl[0][0])[tid] = l2_load4(rpart, o + 4);
+            if (wave == 0) {
+                const unsigned o = (unsigned)((min(tid, NB * NQ - 1) * PST + XC) * 4);
+                st_m = l2_load4(rpart, o); st_l = l2_load4(rpart, o + 4);
             }
             }
-            __syncthreads();
-            if (tid < NB) {
-                float mm = -3.0e38f;
+            // softmax over the chunks of a sample, one lane per (sample, chunk) -- NB * NQ = 32 lanes of wave 0, log2(NQ) exchange rounds (one thread per
+            // sample walked its NQ chunks three times: ~2 us of serial code per step at NQ = 32, the chains of one sample)
+            if (wave == 0) {
+                float mm = st_l > 0.f ? st_m : -3.0e38f;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) if (stl[tid][q] > 0.f) mm = fmaxf(mm, stm[tid][q]);
-                float ll = 0.f;
+                for (int o = NQ / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+                const float w = st_l > 0.f ? __expf(st_m - mm) : 0.f;
+                float ll = st_l * w;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) { const float w = stl[tid][q] > 0.f ? __expf(stm[tid][q] - mm) : 0.f; wgt[tid][q] = w; ll += stl[tid][q] * w; }
+                for (int o = NQ / 2; o > 0; o >>= 1) ll += __shfl_xor(ll, o);
                 const float inv = 1.0f / ll;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) wgt[tid][q] *= inv;
-                smax[tid] = mm; sinv[tid] = inv;
+                if (tid < NB * NQ) {
+                    (&wgt[0][0])[tid] = w * inv;
+                    if ((tid & (NQ - 1)) == 0) { smax[tid / NQ] = mm; sinv[tid / NQ] = inv; }
+                }
             }
             __syncthreads();
             // ctx[s][c4 .. c4+3]: A tile of the o projection; the 16 channels this workgroup owns also go to the record
-            if (tg < NG) {
+            if (gsm < NG) {
 #pragma unroll
                 for (int si = 0; si < SPG; ++si) {
-                    const int sidx = tg * SPG + si;
+                    const int sidx = gsm * SPG + si;
                     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q0 = 0; q0 < NQ; q0 += QG) {
+                    for (int q0 = 0; q0 < CPG; q0 += QG) {
 #pragma unroll
                         for (int q = 0; q < QG; ++q) {
-                            const float w = wgt[sidx][q0 + q];
+                            const float w = wgt[sidx][cb + q0 + q];
                             if constexpr (PP) {
                                 v[0] = fmaf(unpack28_lo(pc[si][q][0]), w, v[0]); v[1] = fmaf(unpack28_hi(pc[si][q][0], pc[si][q][1]), w, v[1]);
                                 v[2] = fmaf(unpack28_lo(pc[si][q][2]), w, v[2]); v[3] = fmaf(unpack28_hi(pc[si][q][2], pc[si][q][3]), w, v[3]);
@@ -689,21 +697,30 @@ __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
                             for (int e = 0; e < 4; ++e) v[e] = fmaf(__uint_as_float(pc[si][q][e]), w, v[e]);
                             }
                         }
-                        if (q0 + QG < NQ) {                       // next group of chunks (compile-time condition: NQ, QG are constants)
+                        if (q0 + QG < CPG) {                       // next group of chunks (compile-time condition: NQ, QG are constants)
                             if constexpr (PP) {
                                 u32x4 wq[QG];
                                 unsigned offq[QG];
 #pragma unroll
-                                for (int q = 0; q < QG; ++q) offq[q] = (unsigned)(((sidx * NQ + q0 + QG + q) * PLW + (c4 >> 1)) * 8);
+                                for (int q = 0; q < QG; ++q) offq[q] = (unsigned)(((sidx * NQ + cb + q0 + QG + q) * PLW + (c4 >> 1)) * 8);
                                 ll_wait8<QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
 #pragma unroll
                                 for (int q = 0; q < QG; ++q) pc[si][q] = wq[q];
                             } else {
 #pragma unroll
-                            for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + q0 + QG + q) * PST + c4) * 4));
+                            for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + cb + q0 + QG + q) * PST + c4) * 4));
                             }
                         }
                     }
+                    if constexpr (GPS > 1) {                      // the groups of a sample meet in LDS (the waves' partial-context buffer of P3 is free here)
+                        *reinterpret_cast<f32x4*>(&redc[tg][c4]) = f32x4{v[0], v[1], v[2], v[3]};
+                        __syncthreads();
+                        if (cb == 0) {
+#pragma unroll
+                            for (int g = 1; g < GPS; ++g) { const f32x4 o4 = *reinterpret_cast<const f32x4*>(&redc[tg + g][c4]); v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
+                        }
+                    }
+                    if (GPS > 1 && cb != 0) continue;
                     const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
                     *reinterpret_cast<u32x2*>(&actx[sidx][c4]) = vb;
                     if ((c4 >> 4) == rank) {
@@ -786,7 +803,7 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
     __shared__ __attribute__((aligned(16))) bf16_t actx[8][XC + 8];
     __shared__ float redl[XW][8][16];                            // logits partial tiles [wave][row][column]   4 KB
     __shared__ float cst[8][16];
-    __shared__ float stm[NB][NQ], stl[NB][NQ], wgt[NB][NQ];
+    __shared__ float wgt[NB][NQ];
     __shared__ float wred[2 * XW];
     __shared__ int ids_l[8], unf_l[8];
     __shared__ int s_rank, s_dead, s_stop;
@@ -1122,23 +1139,28 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                 for (int ks = 0; ks < 4; ++ks) a[ks] = l2_load16(rn, (unsigned)(((b0 + arow) * p.RECB + OFF_HT + wave * 128 + ks * 32 + g4 * 8) * 2));
             }
             constexpr int SPG = NB >= 4 ? NB / 4 : 1, NG = NB / SPG;
+            // chains of one or two samples: the 32 / 16 chunk partials of a sample are split over the 4 / 2 thread groups (8 chunks each = two rounds of
+            // four requests; one group per sample walked them in eight / four dependent rounds: P4 5.6 us of a 12.2 us step at B = 8) and the groups' sums meet in LDS
+            constexpr int GPS = NB >= 4 ? 1 : 4 / NB, CPG = NQ / GPS;
             const int tg4 = tid >> 7, c4 = (tid & 127) * 4;
+            const int gsm = tg4 / GPS, cb = (tg4 - gsm * GPS) * CPG;      // this thread group's sample (block) and first chunk
             constexpr int QG = NB >= 4 ? 2 : 4;
             u32x4 pc[SPG][QG];
+            float st_m = 0.f, st_l = 0.f;                       // wave 0: {max, sum} of (sample, chunk) = lane (lanes 32 .. 63 repeat lane 31's)
             if constexpr (PP) {
                 if (wave == 0) {
                     u32x4 w1[1];
                     const unsigned off1[1] = {(unsigned)((min(tid, NB * NQ - 1) * PLW + 256) * 8)};
                     ll_wait<1>(w1, rpart, off1, (unsigned)(t + 1), err, &s_dead);
-                    if (tid < NB * NQ) { (&stm[0][0])[tid] = __uint_as_float(w1[0][0]); (&stl[0][0])[tid] = __uint_as_float(w1[0][2]); }
+                    st_m = __uint_as_float(w1[0][0]); st_l = __uint_as_float(w1[0][2]);
                 }
-                if (tg4 < NG) {
+                if (gsm < NG) {
                     u32x4 wq[SPG * QG];
                     unsigned offq[SPG * QG];
 #pragma unroll
                     for (int si = 0; si < SPG; ++si)
 #pragma unroll
-                        for (int q = 0; q < QG; ++q) offq[si * QG + q] = (unsigned)((((tg4 * SPG + si) * NQ + q) * PLW + (c4 >> 1)) * 8);
+                        for (int q = 0; q < QG; ++q) offq[si * QG + q] = (unsigned)((((gsm * SPG + si) * NQ + cb + q) * PLW + (c4 >> 1)) * 8);
                     ll_wait8<SPG * QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
 #pragma unroll
                     for (int si = 0; si < SPG; ++si)
@@ -1146,40 +1168,43 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                         for (int q = 0; q < QG; ++q) pc[si][q] = wq[si * QG + q];
                 }
             } else {
-            if (tg4 < NG) {
+            if (gsm < NG) {
 #pragma unroll
                 for (int si = 0; si < SPG; ++si)
 #pragma unroll
-                    for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)((((tg4 * SPG + si) * NQ + q) * PST + c4) * 4));
+                    for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)((((gsm * SPG + si) * NQ + cb + q) * PST + c4) * 4));
             }
-            if (tid < NB * NQ) {
-                const unsigned o = (unsigned)((tid * PST + XC) * 4);
-                (&stm[0][0])[tid] = l2_load4(rpart, o); (&stl[0][0])[tid] = l2_load4(rpart, o + 4);
+            if (wave == 0) {
+                const unsigned o = (unsigned)((min(tid, NB * NQ - 1) * PST + XC) * 4);
+                st_m = l2_load4(rpart, o); st_l = l2_load4(rpart, o + 4);
             }
             }
-            __syncthreads();
-            if (tid < NB) {
-                float mm = -3.0e38f;
+            // softmax over the chunks of a sample, one lane per (sample, chunk) -- NB * NQ = 32 lanes of wave 0, log2(NQ) exchange rounds (one thread per
+            // sample walked its NQ chunks three times: ~2 us of serial code per step at NQ = 32, the chains of one sample)
+            if (wave == 0) {
+                float mm = st_l > 0.f ? st_m : -3.0e38f;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) if (stl[tid][q] > 0.f) mm = fmaxf(mm, stm[tid][q]);
-                float ll = 0.f;
+                for (int o = NQ / 2; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+                const float w = st_l > 0.f ? __expf(st_m - mm) : 0.f;
+                float ll = st_l * w;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) { const float w = stl[tid][q] > 0.f ? __expf(stm[tid][q] - mm) : 0.f; wgt[tid][q] = w; ll += stl[tid][q] * w; }
+                for (int o = NQ / 2; o > 0; o >>= 1) ll += __shfl_xor(ll, o);
                 const float inv = 1.0f / ll;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) wgt[tid][q] *= inv;
+                if (tid < NB * NQ) {
+                    (&wgt[0][0])[tid] = w * inv;
+                }
             }
             __syncthreads();
-            if (tg4 < NG) {
+            if (gsm < NG) {
 #pragma unroll
                 for (int si = 0; si < SPG; ++si) {
-                    const int sidx = tg4 * SPG + si;
+                    const int sidx = gsm * SPG + si;
                     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q0 = 0; q0 < NQ; q0 += QG) {
+                    for (int q0 = 0; q0 < CPG; q0 += QG) {
 #pragma unroll
                         for (int q = 0; q < QG; ++q) {
-                            const float w = wgt[sidx][q0 + q];
+                            const float w = wgt[sidx][cb + q0 + q];
                             if constexpr (PP) {
                                 v[0] = fmaf(unpack28_lo(pc[si][q][0]), w, v[0]); v[1] = fmaf(unpack28_hi(pc[si][q][0], pc[si][q][1]), w, v[1]);
                                 v[2] = fmaf(unpack28_lo(pc[si][q][2]), w, v[2]); v[3] = fmaf(unpack28_hi(pc[si][q][2], pc[si][q][3]), w, v[3]);
@@ -1188,21 +1213,30 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
                             for (int e = 0; e < 4; ++e) v[e] = fmaf(__uint_as_float(pc[si][q][e]), w, v[e]);
                             }
                         }
-                        if (q0 + QG < NQ) {
+                        if (q0 + QG < CPG) {
                             if constexpr (PP) {
                                 u32x4 wq[QG];
                                 unsigned offq[QG];
 #pragma unroll
-                                for (int q = 0; q < QG; ++q) offq[q] = (unsigned)(((sidx * NQ + q0 + QG + q) * PLW + (c4 >> 1)) * 8);
+                                for (int q = 0; q < QG; ++q) offq[q] = (unsigned)(((sidx * NQ + cb + q0 + QG + q) * PLW + (c4 >> 1)) * 8);
                                 ll_wait8<QG>(wq, rpart, offq, tag8_of(t), err, &s_dead);
 #pragma unroll
                                 for (int q = 0; q < QG; ++q) pc[si][q] = wq[q];
                             } else {
 #pragma unroll
-                            for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + q0 + QG + q) * PST + c4) * 4));
+                            for (int q = 0; q < QG; ++q) pc[si][q] = l2_load16(rpart, (unsigned)(((sidx * NQ + cb + q0 + QG + q) * PST + c4) * 4));
                             }
                         }
                     }
+                    if constexpr (GPS > 1) {                      // the groups of a sample meet in LDS (the waves' partial-context buffer of P3 is free here)
+                        *reinterpret_cast<f32x4*>(&redc[tg4][c4]) = f32x4{v[0], v[1], v[2], v[3]};
+                        __syncthreads();
+                        if (cb == 0) {
+#pragma unroll
+                            for (int g = 1; g < GPS; ++g) { const f32x4 o4 = *reinterpret_cast<const f32x4*>(&redc[tg4 + g][c4]); v[0] += o4[0]; v[1] += o4[1]; v[2] += o4[2]; v[3] += o4[3]; }
+                        }
+                    }
+                    if (GPS > 1 && cb != 0) continue;
                     const u32x2 vb = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
                     *reinterpret_cast<u32x2*>(&actx[sidx][c4]) = vb;
                     if ((c4 >> 4) == rank) {
