@@ -769,6 +769,11 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<4, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
             HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 4, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+            HIPRC(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo2wg_kernel<2, 4, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
         }
         const int B = p.M / (p.Ho * p.Wo);
         const int tiles_x = cdiv(p.Wo, QTW), tiles_y = cdiv(p.Ho, QTH);
@@ -780,7 +785,12 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
         } else if (!p.C) return -2;
         const dim3 g4(B * tiles_x * tiles_y * (p.N / 128)), g2(B * tiles_x * tiles_y * (p.N / 64));
         if (p.colsum_part && (size_t)B * tiles_x * tiles_y * p.N > p.colsum_part_floats) return -6;
-        if (p.N % 128 == 0) {
+        // A launch of 128-channel tiles that cannot give every CU a workgroup (the reference's own batches: 3 .. 20 images of 50 x 120 .. 100 x 360) runs on
+        // 64-channel tiles instead: twice the workgroups, half the matrix work per workgroup -- a tile's time is its K loop (Cin / 32 slices x 9 taps x
+        // 2 RI MFMAs per wave, ~35 us at Cin = 512 whatever the grid), so the layer takes about half as long.  Same arithmetic per output element.
+        static int small_thr = -1;
+        if (small_thr < 0) { const char* e = getenv("LXO_CONV_SMALL"); small_thr = e ? atoi(e) : 256; }
+        if (p.N % 128 == 0 && (int)g4.x >= small_thr) {
             if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 0>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
             else if (epi == 1) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 1>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
             else if (epi == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<4, 2>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
@@ -790,6 +800,11 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
             else hipLaunchKernelGGL((conv_halo2wg_kernel<4, 3>), g4, dim3(WTHR), LDS4, s, p, p.N / 128, tiles_x, tiles_y);
         } else {
             if (epi == 0) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 0>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+            else if (epi == 1) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 1>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+            else if (epi == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 2>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+            else if (epi == 4 && p.pool_h == 2 && p.pool_w == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 4, 2, 2>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+            else if (epi == 4 && p.pool_h == 2) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 4, 2, 1>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
+            else if (epi == 4) hipLaunchKernelGGL((conv_halo2wg_kernel<2, 4, 1, 2>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
             else hipLaunchKernelGGL((conv_halo2wg_kernel<2, 3>), g2, dim3(WTHR), LDS2, s, p, p.N / 64, tiles_x, tiles_y);
         }
         if (p.colsum_part) return lxo_k_det_reduce(p.colsum_part, B * tiles_x * tiles_y, p.N, p.N, p.colsum, s);      // the tiles' sums in tile order
