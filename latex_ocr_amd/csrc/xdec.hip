@@ -274,7 +274,7 @@ LXO_DEV void att_load(u32x4 (&xi)[ATT_U], u32x2 (&xa)[ATT_U], rsrc_t rim, rsrc_t
 template <int NB, int ATT_U, bool EXPD>
 __global__ __launch_bounds__(512) void xdec_fwd_kernel(XDecFwd p) {
     constexpr int NQ = 32 / NB;                                  // attention chunks per sample = workgroups per sample
-    constexpr bool PP = (kLL & 4) != 0 && NB >= 4;               // polled chunk partials (one or two samples per chain: their 4-request poll groups spill 80 .. 260 bytes; they keep the barrier)
+    constexpr bool PP = (kLL & 4) != 0;                          // polled chunk partials (chains of one or two samples too since their merge is spread over all four thread groups: no scratch)
     // cross-wave partial tiles of the GEMM phases ([wave][row][column]) and the waves' partial contexts of P3 ([wave][channel]) share 16 KB:
     // the phases that use one are a workgroup barrier away from the phases that use the other
     __shared__ __attribute__((aligned(16))) float redbuf[XW * 8 * 64];
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(512) void xdec_dec_kernel(XDecDec p) {
     // 2 rows per wave and block in flight (the training chain: 4): the decode form carries more loop-invariant addresses (token table, ids,
     // arg-max words) and with 4 rows the allocator spills 55 dwords of them into the serial phases; with 2 it spills 9
     constexpr int NQ = 32 / NB, ATT_U = 2;
-    constexpr bool PP = (kLL & 4) != 0 && NB >= 4;               // polled chunk partials, as in the training chain (tags restart with every launch: the launcher zeroes the words)
+    constexpr bool PP = (kLL & 4) != 0;                          // polled chunk partials, as in the training chain (tags restart with every launch: the launcher zeroes the words)
     __shared__ __attribute__((aligned(16))) float redbuf[XW * 8 * 64];
     float (*red)[8][64] = reinterpret_cast<float (*)[8][64]>(redbuf);
     float (*redc)[XC] = reinterpret_cast<float (*)[XC]>(redbuf);
@@ -1795,7 +1795,7 @@ int lxo_launch_xdec_dec(const XDecDec& p, int U, int O, int C, int E, hipStream_
     HIPRC(hipMemsetAsync(p.sync, 0, 8 * 64 * 4, st));
     HIPRC(hipMemsetAsync(p.sync + 8 * 64 + 1, 0, kXDecBlockBytes - (8 * 64 + 1) * 4, st));
     HIPRC(hipMemsetAsync(p.sync + kXDecBlockBytes / 4 + kXDecSyncBytes / 4, 0, (size_t)p.B * 32 * 8, st));      // the arg-max words (block 1's hand-over area)
-    if ((kLL & 4) && nb >= 4) HIPRC(hipMemsetAsync(p.part, 0, (size_t)p.B * nq * PLW * 8, st));               // the polled chunk partials (tags restart with every launch)
+    if (kLL & 4) HIPRC(hipMemsetAsync(p.part, 0, (size_t)p.B * nq * PLW * 8, st));               // the polled chunk partials (tags restart with every launch)
     switch (nb) {
     case 1: return launch_dec_nb<1>(p, st);
     case 2: return launch_dec_nb<2>(p, st);
