@@ -405,11 +405,11 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
     torch.cuda.synchronize()
     dtp = (time.perf_counter() - t0) / max(n, 1)
     try:
-        rows = real_buckets(torch, dev, V=V, batches=(20, 64), steps=4, warm=2)
+        rows = real_buckets(torch, dev, V=V, batches=(3, 20, 64), steps=4, warm=2)
         keep = ("H", "W", "B", "chain_batch", "T", "regions", "ms_per_step", "img_per_s", "us_per_image", "chains", "conv_fwd_dgrad_frac", "conv_wgrad_frac",
                 "chain_fwd_us_per_step", "chain_bwd_us_per_step", "error")
         out["real_buckets"] = {"rows": [{k: r[k] for k in keep if k in r} for r in rows],
-                               "note": "one training step (bf16, V=%d, Adam) on each of the reference's 21 image sizes (configs/data.json:22-28 after the build-time /2 downsample) at the reference's bucket / evaluation batch 20 (data_generator.py:41, evaluate_txt.py:42; filled up to a chain batch of 32 with dead rows) and at 64; formula lengths per latex_ocr_amd.synthetic.bucket_lengths; conv fractions = algorithmic FLOPs of THAT shape / HIP-event time of the launches / 2.5 PFLOP/s; chain us per step = whole persistent launch / T; 4 timed steps per row (tools/real_buckets.py takes 8; profiles/r06_buckets.json)" % V}
+                               "note": "one training step (bf16, V=%d, Adam) on each of the reference's 21 image sizes (configs/data.json:22-28 after the build-time /2 downsample) at the reference's training batch 3 (configs/training.json:6; chain batch 8), its bucket / evaluation batch 20 (data_generator.py:41, evaluate_txt.py:42; filled up to a chain batch of 32 with dead rows) and at 64; formula lengths per latex_ocr_amd.synthetic.bucket_lengths; conv fractions = algorithmic FLOPs of THAT shape / HIP-event time of the launches / 2.5 PFLOP/s; chain us per step = whole persistent launch / T; 4 timed steps per row (tools/real_buckets.py takes 8; profiles/r06_buckets.json)" % V}
     except Exception as e:
         out["real_buckets"] = {"error": repr(e)}
     out["pipeline_fed"] = {"img_per_s": round(B / dtp, 1), "ms_per_step": round(dtp * 1e3, 3), "steps": n, "host_pad_ms_per_batch": round(t_host * 1e3, 2),
@@ -418,7 +418,7 @@ def secondary(args, eng_train, torch, dev, B, H, W, V):
     return out
 
 
-def real_buckets(torch, dev, V=500, batches=(20, 64), steps=8, warm=3, shapes=None, log=None):
+def real_buckets(torch, dev, V=500, batches=(3, 20, 64), steps=8, warm=3, shapes=None, log=None):
     """SURVEY 8(f)2 / VERDICT r5 #1: the training step on the reference's REAL image sizes (latex_ocr_amd.synthetic.REAL_BUCKETS =
     configs/data.json:22-28 after the /2 downsample) at the reference's bucket / evaluation batch (20: data_generator.py:41,
     evaluate_txt.py:42) and at the benchmark's 64.  Per bucket: ms per step, img/s, us per image, the conv fwd+dgrad and wgrad

@@ -1,4 +1,4 @@
-"""The training step over the reference's 21 real image sizes (configs/data.json:22-28, halved) at batch 20 and 64 -> a table on stdout and
+"""The training step over the reference's 21 real image sizes (configs/data.json:22-28, halved) at batch 3, 20 and 64 -> a table on stdout and
 gpurun_out/<tag>_buckets.json (bench.py: real_buckets).  python tools/real_buckets.py [tag] [steps]"""
 import json
 import os
@@ -11,7 +11,7 @@ import bench  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-batches = tuple(int(x) for x in os.environ.get("RB_BATCHES", "20,64").split(","))
+batches = tuple(int(x) for x in os.environ.get("RB_BATCHES", "3,20,64").split(","))
 print("%4s %4s %3s %3s %4s %6s | %8s %9s %8s | %6s %6s | %7s %7s" % ("H", "W", "B", "Bc", "T", "R", "ms/step", "img/s", "us/img", "conv", "wgrad", "fwd us", "bwd us"))
 
 
