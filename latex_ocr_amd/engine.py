@@ -237,8 +237,16 @@ class Engine(object):
         Bp = B if drop_on else self._train_chain_batch(B, H, W)
         if Bp != B:
             # (lxo_shape.live_B: the encoder computes the B live images only -- `img` stays as it is -- and leaves zero features for the dead rows)
-            formula = self._to_dev(formula, torch.int32)
-            formula = formula.index_select(0, torch.arange(Bp, device=self.device) % B)
+            # (host rows are repeated on the host, before the upload; device rows by ONE index_select with a cached index: at batch 3 the arange / remainder /
+            # index_select triple was 3 launches with their gaps -- ~30 us of a 1.25 ms step)
+            if isinstance(formula, torch.Tensor):
+                cache = self.__dict__.setdefault("_pad_rows", {})
+                idx = cache.get((Bp, B, formula.device))
+                if idx is None:
+                    idx = cache[(Bp, B, formula.device)] = (torch.arange(Bp, device=formula.device) % B)
+                formula = formula.index_select(0, idx)
+            else:
+                formula = np.ascontiguousarray(np.asarray(formula)[np.arange(Bp) % B])
         self.ensure(Bp, H, W, T)
         self.shape.live_B = B if Bp != B else 0
         B = Bp
@@ -359,7 +367,11 @@ class Engine(object):
         dead = int(self.shape.B) - int(getattr(self, "live_B", self.shape.B))
         if dead > 0:                                               # the dead rows forward() appended: length 0 = outside the loss mask
             if isinstance(lengths, torch.Tensor):
-                lengths = torch.cat([lengths.to(torch.int32), torch.zeros(dead, dtype=torch.int32, device=lengths.device)])
+                zc = self.__dict__.setdefault("_pad_zeros", {})
+                z = zc.get((dead, lengths.device))
+                if z is None:
+                    z = zc[(dead, lengths.device)] = torch.zeros(dead, dtype=torch.int32, device=lengths.device)
+                lengths = torch.cat([lengths.to(torch.int32), z])
             else:
                 lengths = np.concatenate([np.asarray(lengths, dtype=np.int32).reshape(-1), np.zeros(dead, np.int32)])
         self._lengths = self._lengths_dev(lengths)
