@@ -487,16 +487,10 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
         HIPRC(hipStreamWaitEvent(side, g_dbw_fork, 0));
     }
     hipStream_t sd = side ? side : st;
-    // ---- initial states (first on the side stream: d_img below needs d_mean) ----
+    // ---- initial states (first on the side stream: d_img below needs d_mean; d_mean before the initial projections' own weight gradients) ----
     float* dpre = P.ws<float>(ws, W_DPRE0); float* mean = P.ws<float>(ws, W_MEAN); float* dmean = P.ws<float>(ws, W_DMEAN);
     const int W3 = 2 * U + O;
     { const Slabs one = {dxh, 1, 0, P.XH}; RC(lxo_k_init_bwd(dcc, one, cs, rec, P.REC, dpre, B, U, O, sd)); }
-    RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, sd));
-    RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, sd));
-    RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, sd));
-    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, det_s, sd));
-    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, det_s, sd));
-    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, det_s, sd));
     const char* wi = (const char*)P.pk(wp, K_INIT);
     if (fused_steps(P)) {
         RC(rs_dense(P, dpre, W3, wi, U, dmean, C, B, C, U, nullptr, false, false, sd));
@@ -507,7 +501,13 @@ int lxo_impl_decoder_train_bwd(const Plan& P, const float* prm, const void* wp, 
     RC(nt(P, true, true, true, dpre + U, W3, wi + (size_t)C * U * P.esz, U, dmean, C, B, C, U, nullptr, 0, true, sd));
     RC(nt(P, true, true, true, dpre + 2 * U, W3, wi + (size_t)2 * C * U * P.esz, O, dmean, C, B, C, O, nullptr, 0, true, sd));
     }
-    if (side) HIPRC(hipEventRecord(g_dbw_init, sd));
+    if (side) HIPRC(hipEventRecord(g_dbw_init, sd));      // d_mean is complete: the compute stream's d_img waits for THIS, not for the six small launches below
+    RC(tn(P, true, true, mean, C, dpre, W3, gw(P_WC0), U, B, C, U, sd));
+    RC(tn(P, true, true, mean, C, dpre + U, W3, gw(P_WH0), U, B, C, U, sd));
+    RC(tn(P, true, true, mean, C, dpre + 2 * U, W3, gw(P_WO0), O, B, C, O, sd));
+    RC(lxo_k_colsum(dpre, W3, gw(P_BC0), B, U, det_s, sd));
+    RC(lxo_k_colsum(dpre + U, W3, gw(P_BH0), B, U, det_s, sd));
+    RC(lxo_k_colsum(dpre + 2 * U, W3, gw(P_BO0), B, O, det_s, sd));
     if (P.bf && fused) {
         // the bf16 mirrors the step kernels left (record, g_t, d_z_t) are the operands: half the bytes of the f32 originals, and
         // these reductions over T*B rows are bound by operand re-reads (every 128 x 128 tile walks all rows of both operands)
