@@ -46,7 +46,8 @@ def _one(dtype, img, f, l, pad=True, seed=5, deterministic=None):
     return eng, stats, eng.grad_dict()
 
 
-@pytest.mark.parametrize("B,H,W", [(3, 50, 120), (20, 50, 120), (20, 40, 160), (3, 60, 360), (20, 60, 360), (5, 40, 160), (40, 50, 120)])
+@pytest.mark.parametrize("B,H,W", [(3, 50, 120), (20, 50, 120), (20, 40, 160), (3, 60, 360), (20, 60, 360), (5, 40, 160), (40, 50, 120),
+                                   (3, 32, 128), (12, 32, 128)])      # config 1's crops: 28 regions -- fewer than the 32 chunks a one-sample chain deals them over
 def test_real_batches_run_the_chains_and_match_f32_and_oracle(B, H, W):
     _threads()
     img, f, l = batch(B, H, W, V, 5, 30, seed=100 + B + H)
