@@ -1627,38 +1627,86 @@ __global__ __launch_bounds__(256) void beam_step_kernel(float* __restrict__ logi
     }
 }
 
-// The same step with every candidate score held in REGISTERS (k * V <= 256 * BS_NPT, no diversity penalty): beam_step_kernel re-reads and
+// The same step with every candidate score held in REGISTERS (k * V <= BS_TH * BS_NPT = 4096, k <= 64 / BS_NW, no diversity penalty): beam_step_kernel re-reads and
 // re-forms all k * V scores (an integer division each) for every one of its k selections and makes two passes over a row for its
 // log-sum-exp -- 31 us of a 161 us beam-5 step at B = 64, on 64 workgroups.  Here a lane loads its share of a row ONCE (max, then the
 // exponentials, from registers), a thread forms its <= BS_NPT scores ONCE, and a selection is a register scan + the block-wide arg-max.
 // Same expressions, same summation order inside a wave, same tie rule (lower flat index first): the ids and parents are the slow kernel's.
-constexpr int BS_NPT = 16;
-__global__ __launch_bounds__(256) void beam_step_fast_kernel(const float* __restrict__ logits, int Vp, int V, int k, int id_end, int time,
+constexpr int BS_TH = 512, BS_NW = BS_TH / 64, BS_NPT = 4096 / BS_TH;      // 8 waves x 8 candidates per thread (it was 4 x 16: a selection round scans a thread's candidates, k rounds per step)
+// (value, index) arg-max over the 64 lanes of a wave -- value descending, index ascending -- every lane ends with the winner.  The four steps inside a
+// row of 16 lanes are DPP moves, the two across rows permlane swaps (as bm_wave_sum_dpp: no LDS crossbar round trips).
+#ifdef LXO_HIPSIM
+LXO_DEV void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+#else
+template <int CTRL> LXO_DEV void amax_dpp(float& v, int& i) {
+    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+    const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, true);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+LXO_DEV void wave_argmax(float& v, int& i) {
+    amax_dpp<0xB1>(v, i); amax_dpp<0x4E>(v, i); amax_dpp<0x141>(v, i); amax_dpp<0x140>(v, i);
+    {
+        const auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const auto ri = __builtin_amdgcn_permlane16_swap((unsigned)i, (unsigned)i, false, false);
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]); const int i0 = (int)ri[0], i1 = (int)ri[1];
+        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
+        v = first ? v0 : v1; i = first ? i0 : i1;
+    }
+    {
+        const auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const auto ri = __builtin_amdgcn_permlane32_swap((unsigned)i, (unsigned)i, false, false);
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]); const int i0 = (int)ri[0], i1 = (int)ri[1];
+        const bool first = v0 > v1 || (v0 == v1 && i0 < i1);
+        v = first ? v0 : v1; i = first ? i0 : i1;
+    }
+}
+#endif
+__global__ __launch_bounds__(BS_TH) void beam_step_fast_kernel(const float* __restrict__ logits, int Vp, int V, int k, int id_end, int time,
                                                             float* __restrict__ logp, int* __restrict__ finished,
                                                             int* __restrict__ ids_step, int* __restrict__ parents_step,
                                                             int* __restrict__ ids_out, int* __restrict__ par_out, int max_steps,
                                                             int* __restrict__ n_unfinished) {
     __shared__ float lse[16];
-    __shared__ float cand_v[4]; __shared__ int cand_i[4];
     __shared__ float sel_v[16]; __shared__ int sel_i[16];
     __shared__ int fin_old[16];
     __shared__ float lp_old[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float FMIN = -3.40282347e38f;
-    if (V <= 64 * 8 && k <= 8) {
-        // log-sum-exp per hypothesis: a wave takes hypotheses `wave` and `wave + 4`, BOTH rows requested before either is reduced (one
-        // memory round trip instead of two), each row in registers for its two passes
-        float x[2][8];
+    __shared__ float wc_v[BS_NW * 16]; __shared__ int wc_i[BS_NW * 16];      // the waves' k best each
+    const int nb = time > 0 ? k : 1;
+    const int total = nb * V;
+    float raw[BS_NPT];                                         // raw logits of this thread's candidates (unconditional, clamped: requested before anything is waited for)
+    {
+        int jq = tid / V, cq = tid - jq * V;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int j = min(wave + 4 * q, k - 1);
+        for (int u = 0; u < BS_NPT; ++u) {
+            const int j = min(jq, k - 1), c = cq;
+            cq += BS_TH;
+            while (cq >= V) { cq -= V; ++jq; }
+            raw[u] = logits[((long long)b * k + j) * Vp + c];
+        }
+    }
+    if (V <= 64 * 8 && k <= 8) {
+        // log-sum-exp per hypothesis: a wave takes hypothesis `wave` (+ BS_NW q: every row requested before any is reduced), the row in registers
+        // for its two passes
+        constexpr int RQ = 8 / BS_NW > 0 ? 8 / BS_NW : 1;
+        float x[RQ][8];
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            const int j = min(wave + BS_NW * q, k - 1);
             const float* lg = logits + ((long long)b * k + j) * Vp;
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int c = lane + 64 * u; x[q][u] = lg[c < V ? c : V - 1]; }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int j = wave + 4 * q;
+        for (int q = 0; q < RQ; ++q) {
+            const int j = wave + BS_NW * q;
             float m = -3.0e38f;
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (lane + 64 * u < V) m = fmaxf(m, x[q][u]);
@@ -1670,7 +1718,7 @@ __global__ __launch_bounds__(256) void beam_step_fast_kernel(const float* __rest
             if (lane == 0 && j < k) lse[j] = m + logf(l);
         }
     } else
-    for (int j = wave; j < k; j += 4) {                       // the general form: one wave per hypothesis, round-robin
+    for (int j = wave; j < k; j += BS_NW) {                   // the general form: one wave per hypothesis, round-robin
         const float* lg = logits + ((long long)b * k + j) * Vp;
         float m = -3.0e38f;
         if (V <= 64 * 16) {
@@ -1696,48 +1744,57 @@ __global__ __launch_bounds__(256) void beam_step_fast_kernel(const float* __rest
     }
     if (tid < k) { fin_old[tid] = finished[b * k + tid]; lp_old[tid] = logp[b * k + tid]; }
     __syncthreads();
-    const int nb = time > 0 ? k : 1;
-    const int total = nb * V;
+    // candidates of this thread: i = tid + BS_TH u -> (hypothesis, id) walked instead of divided; their raw logits were requested in front of the
+    // log-sum-exp pass (raw[]: the second read of the rows no longer waits behind the first)
     float val[BS_NPT];
-    int jq = tid / V, cq = tid - jq * V;                         // (hypothesis, id) of candidate i = tid + 256 u, walked instead of divided
+    {
+        int jq = tid / V, cq = tid - jq * V;
 #pragma unroll
-    for (int u = 0; u < BS_NPT; ++u) {
-        const int i = tid + 256 * u;
-        val[u] = -INFINITY;
-        const int j = jq, c = cq;
-        cq += 256;
-        while (cq >= V) { cq -= V; ++jq; }
-        if (i < total) {
-            float sl = logits[((long long)b * k + j) * Vp + c] - lse[j];
-            const float f = fin_old[j] ? 1.f : 0.f;
-            sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
-            val[u] = lp_old[j] + sl;
+        for (int u = 0; u < BS_NPT; ++u) {
+            const int i = tid + BS_TH * u;
+            val[u] = -INFINITY;
+            const int j = jq, c = cq;
+            cq += BS_TH;
+            while (cq >= V) { cq -= V; ++jq; }
+            if (i < total) {
+                float sl = raw[u] - lse[j];
+                const float f = fin_old[j] ? 1.f : 0.f;
+                sl = (1.f - f) * sl + f * (c == id_end ? 0.f : FMIN);
+                val[u] = lp_old[j] + sl;
+            }
         }
     }
-    unsigned taken = 0u;                                       // bit u: this thread's candidate u has been selected
-    for (int sel = 0; sel < k; ++sel) {
-        float best = -INFINITY; int bi = 0x7fffffff;
+    // top-k in two stages, ONE workgroup barrier between them (it was two per selection): every wave selects the k best of ITS candidates by itself
+    // -- the k best of the block are among them -- then wave 0 selects the k best of the BS_NW k survivors, one per lane.  Order everywhere:
+    // value descending, flat index ascending (tf.nn.top_k over the flattened [k * V] scores: the lower index of equal values first).
+    {
+        unsigned taken = 0u;                                   // bit u: this thread's candidate u has been selected
+        for (int sel = 0; sel < k; ++sel) {
+            float best = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-        for (int u = 0; u < BS_NPT; ++u) {                      // ascending flat index: the first of equal values wins, as in the slow kernel
-            const int i = tid + 256 * u;
-            if (i < total && !((taken >> u) & 1u) && (val[u] > best || (val[u] == best && i < bi))) { best = val[u]; bi = i; }
+            for (int u = 0; u < BS_NPT; ++u) {
+                const int i = tid + BS_TH * u;
+                if (i < total && !((taken >> u) & 1u) && (val[u] > best || (val[u] == best && i < bi))) { best = val[u]; bi = i; }
+            }
+            wave_argmax(best, bi);
+            if (lane == 0) { wc_v[wave * 16 + sel] = best; wc_i[wave * 16 + sel] = bi; }
+#pragma unroll
+            for (int u = 0; u < BS_NPT; ++u) if (tid + BS_TH * u == bi) taken |= 1u << u;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (lane == 0) { cand_v[wave] = best; cand_i[wave] = bi; }
-        __syncthreads();
-        float bv = cand_v[0]; int bx = cand_i[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (cand_v[w] > bv || (cand_v[w] == bv && cand_i[w] < bx)) { bv = cand_v[w]; bx = cand_i[w]; }
-        if (tid == 0) { sel_v[sel] = bv; sel_i[sel] = bx; }
-#pragma unroll
-        for (int u = 0; u < BS_NPT; ++u) if (tid + 256 * u == bx) taken |= 1u << u;
-        __syncthreads();
     }
+    __syncthreads();
+    if (wave == 0) {
+        const int w = lane / k, e = lane - w * k;              // survivor e of wave w (BS_NW k <= 64 lanes: the launcher's condition)
+        float cv = -INFINITY; int ci = 0x7fffffff;
+        if (w < BS_NW) { cv = wc_v[w * 16 + e]; ci = wc_i[w * 16 + e]; }
+        for (int sel = 0; sel < k; ++sel) {
+            float bv = cv; int bx = ci;
+            wave_argmax(bv, bx);
+            if (lane == 0) { sel_v[sel] = bv; sel_i[sel] = bx; }
+            if (ci == bx) { cv = -INFINITY; ci = 0x7fffffff; }
+        }
+    }
+    __syncthreads();
     if (tid < k) {
         const int idx = sel_i[tid];
         const int id = idx % V, par = idx / V;
@@ -2138,8 +2195,8 @@ int lxo_k_beam_step(float* logits, int Vp, int V, int nimg, int k, int id_end, i
     }
     static int fast = -1;                                      // LXO_BEAM_FAST=0: the general kernel always (A/B)
     if (fast < 0) { const char* e = getenv("LXO_BEAM_FAST"); fast = (e && e[0] == '0') ? 0 : 1; }
-    if (fast && dp.log_gamma == 0.f && (long long)k * V <= 256 * BS_NPT)
-        LAUNCH(beam_step_fast_kernel, nimg, logits, Vp, V, k, id_end, time, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
+    if (fast && dp.log_gamma == 0.f && (long long)k * V <= BS_TH * BS_NPT && k * BS_NW <= 64)
+        hipLaunchKernelGGL(beam_step_fast_kernel, dim3(nimg), dim3(BS_TH), 0, st, logits, Vp, V, k, id_end, time, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
     else
     LAUNCH(beam_step_kernel, nimg, logits, Vp, V, k, id_end, time, dp, logp, finished, ids_step, parents_step, ids_out, par_out, max_steps, n_unfinished);
     DONE;

@@ -316,7 +316,9 @@ int launch_ch(const RStep& p, hipStream_t st) {
     const int kq = p.K / 4;
     const int ncol = EPI == RS_LSTM_FWD ? p.U / 4 : cdiv(p.N, 16);
     // 32-row tiles when 64-row tiles would leave CUs idle (the A tile, re-read by every workgroup, is the bulk of the fetch)
-    const bool half = (long long)ncol * cdiv(p.M, 64) <= 128 && p.M > 32;
+    // ... and for the row counts of a beam step (B x beam = 128 .. 512 rows): 32-row tiles measured 11.0 against 12.5 us (LSTM, 320 rows), 5.25 against 5.65 (o
+    // projection) -- the tall all-step GEMMs (T x B rows) keep their 64-row tiles
+    const bool half = ((long long)ncol * cdiv(p.M, 64) <= 128 && p.M > 32) || (p.M > 64 && p.M <= 512);
     // ... and 16-row tiles when even 32-row tiles leave half the CUs idle (o projection, att_h, the LSTM backward: 64 workgroups):
     // a workgroup's fetch -- the length of these kernels -- shrinks with its A tile
     static int q16 = -1;
