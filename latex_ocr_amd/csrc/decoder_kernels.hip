@@ -515,11 +515,13 @@ __global__ __launch_bounds__(512, OCC) void attn_fwd_part_beam_kernel(const CT* 
             float mn = m[b];
 #pragma unroll
             for (int u = 0; u < ATT_U; ++u) if (base + ATT_W * u < n) mn = fmaxf(mn, pt[u]);
-            const float sc = EXPD ? __expf(m[b] - mn) : expf(m[b] - mn);
-            l[b] *= sc;
+            if (mn != m[b]) {                                    // wave-uniform (the scores are wave sums): a running maximum that stands still rescales by exp(0) = 1 exactly -- skipped
+                const float sc = EXPD ? __expf(m[b] - mn) : expf(m[b] - mn);
+                l[b] *= sc;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[b][e] *= sc;
-            m[b] = mn;
+                for (int e = 0; e < 8; ++e) acc[b][e] *= sc;
+                m[b] = mn;
+            }
 #pragma unroll
             for (int u = 0; u < ATT_U; ++u) {
                 const int r = base + ATT_W * u;
