@@ -154,7 +154,7 @@ static int cell_step_fused(const Plan& P, const float* prm, const void* wp, void
                            const float* zx_t, const float* rec_prev, const float* cs_prev, float* rec_cur, float* cs_cur,
                            const bf16_t* recb_prev, bf16_t* recb_cur,
                            float* gates_t, float* atth_t, float* alpha_t, Drop dr, hipStream_t st,
-                           const int* zx_idx = nullptr, int zx_row = -1) {
+                           const int* zx_idx = nullptr, int zx_row = -1, const int* a_par = nullptr) {
     // zx_t: training = the step's rows of emb K[0:D] + b; decode = the per-token table (zx_idx picks the row of each decoder row,
     // zx_row >= 0 = one row for all: the start token)
     const int C = P.s.C, E = P.s.E, U = P.s.U, O = P.s.O;
@@ -170,6 +170,7 @@ static int cell_step_fused(const Plan& P, const float* prm, const void* wp, void
     k1.W = P.pk(wp, K_LSTM_RT); k1.ldw = P.ldRT; k1.N = 4 * U; k1.K = P.XH; k1.epi = RS_LSTM_FWD;
     k1.zx = zx_t; k1.c_prev = cs_prev; k1.gates = gates_t; k1.c_out = cs_cur;
     k1.zx_idx = zx_idx; k1.zx_vocab = P.s.V; k1.zx_row = zx_row;
+    k1.a_par = a_par; k1.a_k = beam;                         // beam decode: the previous state is read through the parents (no re-ordering launch)
     k1.out = rec_cur + O; k1.out2 = rec_cur + P.OFF_HT; k1.ldo = P.REC;
     if (bf) { k1.outb = recb_cur + O; k1.out2b = recb_cur + P.OFF_HT; k1.ldob = P.RECB; }
     RC(lxo_launch_rstep(P.s.dtype, bf, k1, st));
@@ -600,7 +601,7 @@ static int decode_token_table(const Plan& P, const float* prm, const void* wp, v
           prm + P.poff[P_LSTM_B], 0, false, st));
     return 0;
 }
-static int decode_common_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam, int cur, const int* ids_prev, hipStream_t st) {
+static int decode_common_step(const Plan& P, const float* prm, const void* wp, void* ws, int nv, int beam, int cur, const int* ids_prev, hipStream_t st, const int* a_par = nullptr) {
     const int U = P.s.U, O = P.s.O, D = P.s.D, V = P.s.V;
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     const int prev = cur ^ 1;
@@ -610,7 +611,7 @@ static int decode_common_step(const Plan& P, const float* prm, const void* wp, v
                            rec + (size_t)cur * nv * P.REC, cs + (size_t)cur * nv * U,
                            recb + (size_t)prev * nv * P.RECB, recb + (size_t)cur * nv * P.RECB, nullptr,
                            P.ws<float>(ws, W_ATTH), P.ws<float>(ws, W_ALPHA), Drop{0u, 1.f, 0u, cur, 0, 0}, st,      // t = the record slot: only its parity is used (attention direction)
-                           ids_prev, ids_prev ? -1 : V));
+                           ids_prev, ids_prev ? -1 : V, ids_prev ? a_par : nullptr));
     } else {
         // next input embedding (start token at time 0), its LSTM x-part, then the cell step
         float* zx = P.ws<float>(ws, W_DEC_ZX);
@@ -897,15 +898,22 @@ int lxo_impl_beam_decode(const Plan& P, const float* prm, const void* wp, void* 
     HIPRC(hipMemsetAsync(logp, 0, (size_t)nv * 4, st));
     float* rec = P.ws<float>(ws, W_REC); float* cs = P.ws<float>(ws, W_CS);
     if (fused_steps(P)) RC(decode_token_table(P, prm, wp, ws, st));
+    // the state of a step's rows is that of their PARENT hypotheses (beam_search_decoder_cell.py:176-178).  With the fused step kernels the next LSTM launch
+    // reads its [o | h] and c rows through the parents in place; the launch that re-ordered the rows (beam_permute_kernel, 5.3 us + its gap) is only left for
+    // the split-K step kernels and for lxo_decode_step, whose callers may look at the state between steps (LXO_BEAM_INDIRECT=0: always re-order; A/B)
+    static int indirect_on = -1;
+    if (indirect_on < 0) { const char* e = getenv("LXO_BEAM_INDIRECT"); indirect_on = (e && e[0] == '0') ? 0 : 1; }
+    const bool indirect = indirect_on && fused_steps(P);
     RC(decode_loop(max_iter, flags, st, steps_out, [&](int time, int* unfinished) -> int {
         const int cur = (time + 1) & 1;
-        RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st));
+        RC(decode_common_step(P, prm, wp, ws, nv, k, cur, time == 0 ? nullptr : ids_step, st, indirect ? par_step : nullptr));
         if (alpha_out)      // the attention weights of this step's B x k decoder rows, as they ran (row b * k + j = hypothesis slot j BEFORE this step's
                             // re-ordering: what the reference's py_func tap sees on the merged batch x beam rows, attention_mechanism.py:59-65,96-105)
             HIPRC(hipMemcpyAsync(alpha_out + (size_t)time * nv * P.Rp, P.ws<float>(ws, W_ALPHA), (size_t)nv * P.Rp * 4, hipMemcpyDeviceToDevice, st));
         RC(lxo_k_beam_step(P.ws<float>(ws, W_DEC_LOGITS), P.Vp, P.s.V, B, k, id_end, time, P.s.div_gamma, P.s.div_prob, P.s.div_seed, tmp,
                            logp, finished, ids_step, par_step,
                            ids_out, parents_out, ms, unfinished, st));
+        if (!indirect)
         RC(lxo_k_beam_gather(rec + (size_t)cur * nv * P.REC, P.REC, P.XH, cs + (size_t)cur * nv * U, U, par_step, k,
                              tmp, tmp + (size_t)nv * P.XH, nv,
                              (fused_steps(P) && P.bf) ? P.ws<bf16_t>(ws, W_RECB) + (size_t)cur * nv * P.RECB : nullptr, P.RECB, st));    // the re-ordered [o | h] rows (+ their bf16 mirror) feed the next LSTM GEMM

@@ -22,6 +22,8 @@ struct RStep {
     float* out2; bf16_t* out2b;    // LSTM_FWD: h~ (same pitches as out / outb); CARRY: carry_h [M][U]
     // LSTM_FWD
     const float* zx; const float* c_prev; float* gates; float* c_out;
+    const int* a_par; int a_k;     // beam decode (nullable): row m of A and of c_prev is row (m / a_k) * a_k + a_par[m] -- the parent hypothesis' state read in place
+                                   // (beam_search_decoder_cell.py:176-178) instead of a launch that re-orders the rows first
     const int* zx_idx; int zx_vocab, zx_row;   // decode: row m of the x-part = zx[clamp(zx_idx[m], 0, zx_vocab - 1)] (zx = per-token table), or zx[zx_row] for
                                                // every m when zx_idx is null and zx_row >= 0 (start token); training: zx_idx null, zx_row < 0 -> zx[m]
     // LSTM_BWD (c_prev shared with LSTM_FWD)

@@ -62,7 +62,7 @@ LXO_DEV void ld4(const float* p, float (&v)[4]) { const f32x4 a = *reinterpret_c
 // trip overlaps the GEMM.  In-kernel stamps (tools/rstep_stamps.py): a CU accepts one 1-KB wave load per ~24 cycles, so
 // the fetch of A (re-read by every workgroup) sets the kernel's length -- hence MT = 32 / 16 when that fills more CUs.
 template <typename AT, typename WT, int EPI, int MT, int KC, int NCH, int NBUF>
-__global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* kW, int k_lda, int k_ldw, int k_M, int k_N, int k_K, int k_U, RStep p) {
+__global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* kW, int k_lda, int k_ldw, int k_M, int k_N, int k_K, int k_U, const int* k_apar, int k_ak, RStep p) {
     // The leading scalars repeat p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U: scalar kernel arguments are PRELOADED into SGPRs at wave
     // launch (-mllvm -amdgpu-kernarg-preload-count, Makefile), a by-value struct is not -- so the operand addresses and the first
     // loads do not wait for the scalar loads of the 280-byte argument block (a memory round trip at the head of every launch of
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* 
         const int i = j * 64 + lane, row = i / PRA, pc = i - row * PRA;
         int m = m0 + row;
         if (m >= k_M) m = k_M - 1;
+        if (k_apar) m = (m / k_ak) * k_ak + k_apar[m];       // beam decode: the parent hypothesis' row (one dependent load at the head instead of a re-ordering launch)
         aoff[j] = m * k_lda + pc * APL;
     }
 #pragma unroll
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void rstep_kernel(const void* kA, const void* 
         else if (p.zx_row >= 0) zr = p.zx_row;
 #pragma unroll
         for (int q = 0; q < 4; ++q) pz[q] = p.zx[zr * 4 * U + q * U + u];
-        pcp = p.c_prev[(long long)mc * U + u];
+        pcp = p.c_prev[(long long)(k_apar ? (mc / k_ak) * k_ak + k_apar[mc] : mc) * U + u];
     } else if constexpr (EPI == RS_LSTM_BWD) {
         const int U = p.U;
         const float* gr = p.gates_in + (long long)mc * 4 * U + n;
@@ -297,11 +298,11 @@ template <typename AT, typename WT, int EPI, int MT, int KC>
 int launch_nch(const RStep& p, dim3 grid, hipStream_t st) {
     const int nch = (p.K / 4) / KC;
     switch (nch) {
-    case 1: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 1, 1>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
-    case 2: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 2, 2>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
-    case 4: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 4, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
-    case 8: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 8, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
-    case 16: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 16, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p); break;
+    case 1: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 1, 1>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p.a_par, p.a_k > 0 ? p.a_k : 1, p); break;
+    case 2: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 2, 2>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p.a_par, p.a_k > 0 ? p.a_k : 1, p); break;
+    case 4: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 4, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p.a_par, p.a_k > 0 ? p.a_k : 1, p); break;
+    case 8: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 8, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p.a_par, p.a_k > 0 ? p.a_k : 1, p); break;
+    case 16: hipLaunchKernelGGL((rstep_kernel<AT, WT, EPI, MT, KC, 16, 4>), grid, dim3(256), 0, st, p.A, p.W, p.lda, p.ldw, p.M, p.N, p.K, p.U, p.a_par, p.a_k > 0 ? p.a_k : 1, p); break;
     default: return -2;                                     // K / (4 * KC) must be a power of two up to 16 (every shape validate() admits with U, O, E, C in {128, 256, 512})
     }
     return (int)hipGetLastError();

@@ -103,3 +103,35 @@ def test_step_kernel_row_tiles_agree(tmp_path):
     other = _run(tmp_path, "mt32", {"LXO_RSTEP_MT16": "0"}, 32, 128, 40)
     worst = _compare(base, other, 1e-5, 0.99999, 1e-2)
     print("16-row vs 32-row step tiles: f32 bit-identical; bf16 worst cosine %.8f (%s, max rel %.2e)" % worst)
+
+
+_BEAM_SNIPPET = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from latex_ocr_amd import synthetic
+from latex_ocr_amd.engine import Engine
+from latex_ocr_amd.model.utils.image import pad_batch_images
+imgs, _ = synthetic.make_set(6, 40, 160, 60, 3, 9, seed=21)
+img = pad_batch_images(imgs)
+out = {}
+for dt in ("f32", "bf16"):
+    eng = Engine(60, dtype=dt, beam=3, max_steps=24, seed=4)
+    ids, par = eng.beam_decode(img, 59, 3, max_iter=20, return_parents=True)[:2]
+    out[dt + "_ids"] = np.asarray(ids); out[dt + "_par"] = np.asarray(par)
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_beam_parents_read_in_place_equal_the_reordering_launch(tmp_path):
+    """Beam decode on the fused step kernels reads a step's previous state THROUGH the parents (rstep.h: a_par) where it used to re-order the rows with a
+    launch of its own (beam_search_decoder_cell.py:176-178); LXO_BEAM_INDIRECT=0 brings the launch back.  Same arithmetic on the same rows: ids and parents
+    must be identical, in the f32 parity mode and in bf16."""
+    outs = []
+    for name, env in (("inplace", {}), ("reorder", {"LXO_BEAM_INDIRECT": "0"})):
+        out = os.path.join(str(tmp_path), name + ".npz")
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _BEAM_SNIPPET % os.path.dirname(HERE), out], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        outs.append(dict(np.load(out)))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
