@@ -889,7 +889,13 @@ int lxo_k_maxpool_mask_bwd(const unsigned char* mask, const void* dp, void* dy, 
     if (C % 8 || C > 512 || 256 % (C / 8)) return -2;
     const int Ho = (H + ph - 1) / ph, Wo = (W + pw - 1) / pw;
     const int ppb = 256 / (C / 8);
-    const dim3 grid(grid_for((long long)B * Ho * Wo, ppb * 8, 2048));
+    // Workgroup cap (LXO_POOLBWD_CAP, A/B): ALONE on the GPU 512 workgroups (two per CU, 8 rounds of four pixels per thread) run the three pools of the benchmark
+    // shape in 61 / 48 / 47 us where 2048 take 82 / 72 / 72 (fewer, longer streams keep more of the DRAM traffic inside open pages; 384 / 768: 5-10 % behind 512) --
+    // but inside the training step they run beside the weight-gradient kernel of the second stream, and there 2048 is the faster step: 7.418 / 7.422 ms against
+    // 7.433 / 7.439 with 512 (same box, alternating processes).  The step is what counts: 2048.
+    static int pcap = -1;
+    if (pcap < 0) { const char* e = getenv("LXO_POOLBWD_CAP"); pcap = e ? atoi(e) : 2048; }
+    const dim3 grid(grid_for((long long)B * Ho * Wo, ppb * 8, pcap));
     float* db_part = nullptr;                 // deterministic mode: one slot [C] per workgroup
     if (det.p && db) { if ((size_t)grid.x * C > det.floats) return -6; db_part = det.p; }
 #define MB_ARGS mask, (const bf16_t*)dp, (bf16_t*)dy, db, db_part, B, H, W, C, Ho, Wo
