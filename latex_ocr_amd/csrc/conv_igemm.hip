@@ -380,16 +380,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
     // reads: 12.5 % of that launch's matrix work.  Wave-uniform (scalar branch); the accumulators of those rows keep the bias and are
     // masked by every epilogue like any row >= Ho.
     const bool short_tile = __builtin_amdgcn_readfirstlane((RI == 8 && oy0 + 6 >= p.Ho) ? 1 : 0) != 0;
-    // Patch rows outside the image are zero padding: an MFMA whose pixel operand is such a row adds nothing and is skipped (bit pr of `dead` =
-    // patch row pr of this wave's RI + 2; wave-uniform, a scalar branch per MFMA like short_tile's).  The data gradient of the VALID conv6 is a
-    // pad-2 correlation over 14 rows -> 16: 6 of its 48 (output row, tap row) pairs; a SAME layer of H rows has 2 of 3 H.
-    unsigned dead_rows = 0u;
-#pragma unroll
-    for (int pr = 0; pr < RI + 2; ++pr) {
-        const int iy = oy0 + wm * RI + pr - p.pad;
-        if (iy < 0 || iy >= p.H) dead_rows |= 1u << pr;
-    }
-    dead_rows = __builtin_amdgcn_readfirstlane((p.diag & 8) ? 0u : dead_rows);      // (LXO_CONV_DEADROWS=0: A/B switch, every MFMA issued)
+    // (Round 6 tried skipping the MFMAs whose pixel rows are zero padding -- the pad-2 data gradient of the VALID conv6 has 12.5 % of them -- behind a wave-uniform
+    // mask, a scalar branch per MFMA: compiled into every instantiation it cost the step 1.1 % (conv fraction 0.534-0.54 against 0.55-0.566, two builds on one
+    // box; a run-time switch had not shown it, the branches stay), in an instantiation of its own it bought that one launch 1 us of 190.  Not in.)
 #define CSTAMP(i) do { if (p.dbg && tid == 0 && (i) < 64) p.dbg[(long long)bid * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
     CSTAMP(0);
     if (p.dbg && tid == 0) p.dbg[(long long)bid * 64 + 63] = __builtin_amdgcn_s_getreg(63492);      // HW_ID: which CU / SIMD this workgroup landed on
@@ -440,7 +433,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
 #pragma unroll
             for (int i = 0; i < RI; ++i) {
                 if (RI == 8 && i >= 6 && short_tile) continue;
-                if (!((dead_rows >> (i + kh)) & 1u))
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[0]),
                                                                  __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
                 af[i] = *reinterpret_cast<const u32x4*>(lxo_conv_lds + a_lane + ((i + kh) * QPW + kw) * WPIX + 32);
@@ -454,7 +446,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo2wg_kernel(GemmNT p, int tile
 #pragma unroll
             for (int i = 0; i < RI; ++i) {
                 if (RI == 8 && i >= 6 && short_tile) continue;      // (the bookkeeping below sits at i == 0 and i == RI - 3)
-                if (!((dead_rows >> (i + kh)) & 1u))
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bfr[1]),
                                                                  __builtin_bit_cast(bf16x8_t, af[i]), acc[i], 0, 0, 0);
                 if (i == 0 && (tap + 3 < 9 || !last)) issue_w(tap + 3 < 9 ? c : c + 1, t3, tap % 3);
@@ -764,7 +755,6 @@ int lxo_launch_conv_igemm(const GemmNT& p0, hipStream_t s) {
 #else
     p.diag = 0;
 #endif
-    { static int dead_off = -1; if (dead_off < 0) { const char* e = getenv("LXO_CONV_DEADROWS"); dead_off = (e && e[0] == '0') ? 1 : 0; } if (dead_off) p.diag |= 8; }
     if (!p.conv || p.Cin % 64 || p.K % 64) return -2;
     static int use_2wg = -1;
     if (use_2wg < 0) { const char* e = getenv("LXO_CONV_2WG"); use_2wg = (e && e[0] == '0') ? 0 : 1; }

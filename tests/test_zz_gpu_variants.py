@@ -17,7 +17,6 @@ mathematics with different kernels, so they must agree far more tightly than eit
 * the two-workgroup conv kernel with fused pools (default)  vs  the general halo conv kernel + separate pools (LXO_CONV_2WG=0: the
   kernel that shapes outside the model's -- Cout % 64 != 0, tensors of 2 GB and more -- run on);
 * 64-channel conv tiles for launches too small to give every CU a 128-channel tile (default)  vs  128-channel tiles always (LXO_CONV_SMALL=0);
-* conv MFMAs on patch rows that are zero padding skipped (default)  vs  issued (LXO_CONV_DEADROWS=0);
 * the stream switches: LXO_DUAL_STREAM=1 (off by default: measured slower) and LXO_ENC_OVERLAP=0 (the weight gradients -- the encoder's and the
   decoder's deferred ones -- on the compute stream instead of beside it on a second stream, the default since round 5).
 Odd image sizes exercise the clipped pool windows of both generations."""
@@ -74,8 +73,6 @@ def test_kernel_generations_agree(tmp_path, h, w):
             # 128-channel conv tiles for every launch (the default gives a launch of fewer than 256 such tiles -- this batch of 4 -- 64-channel tiles): the
             # same products in the same order per output element; only the bias-gradient atomics group differently
             ("conv_128_channel_tiles", {"LXO_CONV_SMALL": "0"}, (1e-5, 0.99999, 1e-2)),
-            # every MFMA of the conv kernel issued, zero-padding patch rows included (the default skips them: adding products with zero operands)
-            ("conv_mfma_on_padding_rows", {"LXO_CONV_DEADROWS": "0"}, (1e-5, 0.99999, 1e-2)),
             # the stream switches: half-batch chains on two streams (on the split-K step kernels; off by default), and every weight gradient on
             # the compute stream instead of the second stream (the same kernels, other order of the f32 atomics)
             ("two_half_batch_chains", {"LXO_DUAL_STREAM": "1"}, (1e-4, 0.9995, 5e-2)),
